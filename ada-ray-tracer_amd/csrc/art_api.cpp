@@ -1,0 +1,521 @@
+// art_api.cpp -- C-ABI driver of the render backend (include/art_hip.h).  Owns the HBM-resident scene,
+// the wavefront path buffers and the per-pass kernel schedule that replaces Ray_Tracer.Render_Pass'
+// task pool (ray_tracer.adb:240-293):
+//
+//   per batch of P = pixels x samples path slots:
+//     raygen -> [ trace(ext + shadow rays) -> shade(bounce) ] x max_depth -> trace(last shadow rays)
+//            -> finish (inside-out radiance fold) -> accumulate (reference summation order)
+//   then resolve (gamma, clamp, pack) when the caller asks for the LDR image.
+//
+// There is no CPU fallback: every entry point that needs the GPU fails with art_last_error() set when
+// HIP reports no usable device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "art_api_internal.h"
+
+namespace art {
+
+Ctx g_ctx;
+std::mutex g_mu;
+static thread_local std::string t_err;
+static std::string g_err;
+
+int fail(const std::string& msg) { g_err = msg; return 1; }
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(_e));   \
+  } while (0)
+
+template <typename T>
+static int upload(DevBuf& b, const std::vector<T>& v) {
+  b.release();
+  if (v.empty()) return 0;
+  HIP_TRY(hipMalloc(&b.p, v.size() * sizeof(T)));
+  b.bytes = v.size() * sizeof(T);
+  HIP_TRY(hipMemcpy(b.p, v.data(), b.bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int ensure(DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes && b.p) return 0;
+  b.release();
+  HIP_TRY(hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  return 0;
+}
+
+void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+
+int ensure_device() {
+  Ctx& c = g_ctx;
+  if (c.device_ready) return 0;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail("no HIP device available (this library has no CPU path): " + std::string(hipGetErrorString(e)));
+  if (c.device >= 0) HIP_TRY(hipSetDevice(c.device));
+  HIP_TRY(hipGetDevice(&c.device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, c.device));
+  c.num_cus = prop.multiProcessorCount;
+  c.arch = prop.gcnArchName;
+  HIP_TRY(hipMalloc(&c.d_cursor, sizeof(int)));
+  HIP_TRY(hipMalloc(&c.d_counters, 8 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(c.d_counters, 0, 8 * sizeof(unsigned long long)));
+  c.device_ready = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int upload_scene_arrays(HostScene& hs) {
+  Ctx& c = g_ctx;
+  if (upload(c.b_spheres, hs.spheres) || upload(c.b_sphere_mat, hs.sphere_mat) || upload(c.b_lights, hs.lights) ||
+      upload(c.b_materials, hs.materials) || upload(c.b_bf_pos, hs.bf_pos) || upload(c.b_bf_nrm, hs.bf_nrm) ||
+      upload(c.b_bf_uv, hs.bf_uv) || upload(c.b_bf_idx, hs.bf_idx) || upload(c.b_nodes, hs.bvh.nodes) ||
+      upload(c.b_tris, hs.bvh.tris) || upload(c.b_m_nrm, hs.m_nrm) || upload(c.b_m_uv, hs.m_uv) ||
+      upload(c.b_m_idx, hs.m_idx) || upload(c.b_m_matid, hs.m_matid))
+    return 1;
+  DevScene& s = c.scene;
+  s = hs.hdr;
+  s.spheres = (const DevSphere*)c.b_spheres.p; s.sphere_mat = (const int32_t*)c.b_sphere_mat.p;
+  s.lights = (const DevLight*)c.b_lights.p; s.materials = (const DevMaterial*)c.b_materials.p;
+  s.bf_pos = (const float*)c.b_bf_pos.p; s.bf_nrm = (const float*)c.b_bf_nrm.p; s.bf_uv = (const float*)c.b_bf_uv.p; s.bf_idx = (const int32_t*)c.b_bf_idx.p;
+  s.nodes = (const float*)c.b_nodes.p; s.tris = (const float*)c.b_tris.p;
+  s.m_nrm = (const float*)c.b_m_nrm.p; s.m_uv = (const float*)c.b_m_uv.p; s.m_idx = (const int32_t*)c.b_m_idx.p; s.m_matid = (const int32_t*)c.b_m_matid.p;
+  return 0;
+}
+
+int upload_scene(const ArtSceneDesc* d) {
+  Ctx& c = g_ctx;
+  if (!d) return fail("art_upload_scene: null scene");
+  if (ensure_device()) return 1;
+  std::string err;
+  HostScene hs;
+  if (!flatten_scene(*d, c.bvh_params, hs, err)) return fail(err);
+  if (hs.bvh.max_stack > kStackEntries) return fail("BVH traversal stack bound " + std::to_string(hs.bvh.max_stack) + " exceeds " + std::to_string(kStackEntries));
+  if (upload_scene_arrays(hs)) return 1;
+  c.stack_entries = std::max(8, hs.bvh.max_stack);
+  c.blocks_per_cu = 0;   // re-query occupancy
+  c.host_scene = std::move(hs);
+  c.scene_ready = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int build_shard() {
+  Ctx& c = g_ctx;
+  const int W = c.width, H = c.height, T = c.tile;
+  std::vector<uint32_t> pm;
+  pm.reserve((size_t)W * H / std::max(1, c.nranks) + 1024);
+  const int tx = (W + T - 1) / T, ty = (H + T - 1) / T;
+  for (int by = 0; by < ty; ++by)
+    for (int bx = 0; bx < tx; ++bx) {
+      if ((by * tx + bx) % c.nranks != c.rank) continue;
+      for (int y = by * T; y < std::min(H, (by + 1) * T); ++y)
+        for (int x = bx * T; x < std::min(W, (bx + 1) * T); ++x) pm.push_back((uint32_t)(y * W + x));
+    }
+  c.npix_local = (int)pm.size();
+  return upload(c.b_pixmap, pm);
+}
+
+int resize(int w, int h) {
+  Ctx& c = g_ctx;
+  if (w <= 0 || h <= 0 || (int64_t)w * h > (1ll << 30)) return fail("art_resize: bad size");
+  if (ensure_device()) return 1;
+  c.width = w; c.height = h;
+  const size_t n = (size_t)w * h;
+  if (ensure(c.b_accum, n * 12) || ensure(c.b_screen, n * 4)) return 1;
+  float* acc = c.ext_accum ? c.ext_accum : (float*)c.b_accum.p;
+  HIP_TRY(hipMemsetAsync(acc, 0, n * 12, c.stream));
+  c.spp = 0;
+  c.stats = ArtStats();
+  c.camera_rays = 0;
+  HIP_TRY(hipMemsetAsync(c.d_counters, 0, 8 * sizeof(unsigned long long), c.stream));
+  return build_shard();
+}
+
+static float* accum_ptr() { return g_ctx.ext_accum ? g_ctx.ext_accum : (float*)g_ctx.b_accum.p; }
+
+// path arrays for P slots and `depth` fold levels, carved out of one allocation
+static size_t path_floats(size_t P, int depth) { return (14 + 8 + 3 + 3 + 6 * (size_t)depth + 3 + 3) * P; }
+
+static int ensure_paths(size_t P, int depth) { return ensure(g_ctx.b_paths, path_floats(P, depth) * 4 + 256); }
+
+static void carve(DevPaths& q, int P, int depth) {
+  float* f = (float*)g_ctx.b_paths.p; const size_t p = (size_t)P;
+  auto take = [&](size_t n) { float* r = f; f += n; return r; };
+  q.ray_ox = take(2 * p); q.ray_oy = take(2 * p); q.ray_oz = take(2 * p);
+  q.ray_dx = take(2 * p); q.ray_dy = take(2 * p); q.ray_dz = take(2 * p); q.ray_tfar = take(2 * p);
+  q.hit_t = take(2 * p); q.hit_key = (uint32_t*)take(2 * p); q.hit_u = take(2 * p); q.hit_v = take(2 * p);
+  q.prev_pdf = take(p); q.flags = (uint32_t*)take(p); q.sh_min_t = take(p);
+  q.cand_r = take(p); q.cand_g = take(p); q.cand_b = take(p);
+  q.e_r = take(depth * p); q.e_g = take(depth * p); q.e_b = take(depth * p);
+  q.w_r = take(depth * p); q.w_g = take(depth * p); q.w_b = take(depth * p);
+  q.term_r = take(p); q.term_g = take(p); q.term_b = take(p);
+  q.rad_r = take(p); q.rad_g = take(p); q.rad_b = take(p);
+}
+
+static int coop_grid() {
+  Ctx& c = g_ctx;
+  if (c.blocks_per_cu <= 0) c.blocks_per_cu = c.opt_blocks_per_cu > 0 ? c.opt_blocks_per_cu : trace_coop_blocks_per_cu(c.stack_entries);
+  return c.num_cus * c.blocks_per_cu;
+}
+
+static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
+  Ctx& c = g_ctx;
+  a.n_rays = n_rays; a.stack_entries = c.stack_entries;
+  a.ray_ox = q.ray_ox; a.ray_oy = q.ray_oy; a.ray_oz = q.ray_oz; a.ray_dx = q.ray_dx; a.ray_dy = q.ray_dy; a.ray_dz = q.ray_dz; a.ray_tfar = q.ray_tfar;
+  a.hit_t = q.hit_t; a.hit_key = q.hit_key; a.hit_u = q.hit_u; a.hit_v = q.hit_v;
+  a.cursor = c.d_cursor; a.stats = c.d_counters + 3;
+}
+
+// one trace launch, bracketed by HIP events on the launch stream
+static int trace(const DevPaths& q, int n_rays) {
+  Ctx& c = g_ctx;
+  TraceArgs a; fill_trace_args(a, q, n_rays);
+  if (c.trace_kernel == TRACE_COOP) HIP_TRY(hipMemsetAsync(c.d_cursor, 0, sizeof(int), c.stream));
+  if (c.ev_pool.size() < c.ev_used + 2) {
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    c.ev_pool.push_back(e0); c.ev_pool.push_back(e1);
+  }
+  HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used], c.stream));
+  launch_trace(c.stream, c.scene, a, c.trace_kernel, c.count_tests, coop_grid());
+  HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used + 1], c.stream));
+  c.ev_used += 2;
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// drain event pairs into stats (requires the stream to be idle)
+static int collect_timing() {
+  Ctx& c = g_ctx;
+  for (size_t i = 0; i + 1 < c.ev_used; i += 2) {
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, c.ev_pool[i], c.ev_pool[i + 1]));
+    c.stats.trace_ms += ms; c.stats.trace_launches += 1;
+  }
+  c.ev_used = 0;
+  unsigned long long cnt[8];
+  HIP_TRY(hipMemcpy(cnt, c.d_counters, sizeof cnt, hipMemcpyDeviceToHost));
+  c.stats.rays = c.camera_rays + cnt[0];
+  c.stats.box_tests = cnt[3]; c.stats.tri_tests = cnt[4]; c.stats.node_visits = cnt[5]; c.stats.leaf_visits = cnt[6]; c.stats.traced_rays = cnt[7];
+  return 0;
+}
+
+static int check_pass(const ArtPassParams* p) {
+  Ctx& c = g_ctx;
+  if (!p) return fail("null ArtPassParams");
+  if (!c.scene_ready) return fail("no scene uploaded (art_upload_scene)");
+  if (c.width <= 0) return fail("no viewport (art_resize)");
+  if (p->max_depth < 1 || p->max_depth > 16) return fail("max_depth must be 1..16");
+  if (p->vthreads < 1) return fail("vthreads must be >= 1");
+  if (p->layout != ART_LAYOUT_ADA_XY && p->layout != ART_LAYOUT_ROW_MAJOR) return fail("unknown layout");
+  return 0;
+}
+
+static void make_frame(const ArtPassParams* p, DevFrame& f) {
+  Ctx& c = g_ctx;
+  f.width = c.width; f.height = c.height;
+  f.render_type = p->render_type; f.aa_on = p->aa_on ? 1 : 0; f.max_depth = p->max_depth;
+  f.seed_lo = (uint32_t)p->seed; f.seed_hi = (uint32_t)(p->seed >> 32);
+  std::memcpy(f.background, p->background, 12);
+  const float fov = kHalfPi;                                   // ray_tracer.adb:63  Pi/2.0
+  f.cam_z = -(float)c.width / safe_tan(fov / 2.0f);            // ray_tracer.adb:67
+}
+
+int render_pass_device(const ArtPassParams* p, int32_t* spp_inout) {
+  Ctx& c = g_ctx;
+  if (check_pass(p)) return 1;
+  if (p->render_type == ART_RT_DEBUG || p->render_type == ART_RT_WHITTED) return fail("debug render types go through art_debug_hit_pass");
+  if (p->render_type < ART_PT_STUPID || p->render_type > ART_PT_MIS) return fail("unknown render_type");
+  const int per = p->aa_on ? 4 : 1;
+  if (spp_inout) c.spp = *spp_inout;
+  if (p->aa_on && (c.spp % 4) != 0) return fail("with anti-aliasing on, spp must be a multiple of 4 (Generate4RayDirections order)");
+  const int S = p->vthreads * per;           // samples this pass
+  const int npix = c.npix_local;
+  DevFrame F; make_frame(p, F);
+  hipEvent_t p0, p1;
+  HIP_TRY(hipEventCreate(&p0)); HIP_TRY(hipEventCreate(&p1));
+  HIP_TRY(hipEventRecord(p0, c.stream));
+  if (npix > 0) {
+    // batch = pixel chunk x sample chunk with pc * sc <= batch_paths
+    const int64_t cap = std::max<int64_t>(c.batch_paths, per);
+    int pc = (int)std::min<int64_t>(npix, std::max<int64_t>(1, cap / per));
+    int sc = (int)std::min<int64_t>(S, std::max<int64_t>(per, (cap / pc) / per * per));
+    if (ensure_paths((size_t)pc * sc, p->max_depth)) return 1;
+    for (int px0 = 0; px0 < npix; px0 += pc) {
+      const int pn = std::min(pc, npix - px0);
+      for (int s0 = 0; s0 < S; s0 += sc) {
+        const int sn = std::min(sc, S - s0);
+        DevPaths q; std::memset(&q, 0, sizeof q);
+        q.P = pn * sn; q.npix = pn; q.pixmap = (const uint32_t*)c.b_pixmap.p + px0; q.sample_base = (uint32_t)(c.spp + s0);
+        carve(q, q.P, p->max_depth);
+        launch_raygen(c.stream, F, c.scene, q);
+        c.camera_rays += (uint64_t)q.P;
+        for (int b = 0; b < p->max_depth; ++b) {
+          if (trace(q, b == 0 ? q.P : 2 * q.P)) return 1;
+          launch_shade(c.stream, F, c.scene, q, b, c.d_counters);
+        }
+        if (p->render_type != ART_PT_STUPID) { if (trace(q, 2 * q.P)) return 1; }
+        launch_finish(c.stream, F, q, p->max_depth - 1);
+        launch_accumulate(c.stream, F, q, sn, accum_ptr());
+        HIP_TRY(hipGetLastError());
+      }
+    }
+  }
+  HIP_TRY(hipEventRecord(p1, c.stream));
+  c.pass_events.push_back(p0); c.pass_events.push_back(p1);
+  c.spp += S;
+  c.stats.samples += (uint64_t)npix * S;
+  if (spp_inout) *spp_inout = c.spp;
+  return 0;
+}
+
+int synchronize() {
+  Ctx& c = g_ctx;
+  if (!c.device_ready) return 0;
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  for (size_t i = 0; i + 1 < c.pass_events.size(); i += 2) {
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, c.pass_events[i], c.pass_events[i + 1]));
+    c.stats.pass_ms += ms;
+    (void)hipEventDestroy(c.pass_events[i]); (void)hipEventDestroy(c.pass_events[i + 1]);
+  }
+  c.pass_events.clear();
+  return collect_timing();
+}
+
+int download(float* accum_host, uint32_t* screen_host, int layout, int spp) {
+  Ctx& c = g_ctx;
+  if (c.width <= 0) return fail("no viewport");
+  const int W = c.width, H = c.height; const size_t n = (size_t)W * H;
+  if (screen_host) launch_resolve(c.stream, accum_ptr(), (int)n, 1.0f / (float)spp, (uint32_t*)c.b_screen.p);
+  if (layout == ART_LAYOUT_ADA_XY) {
+    if (ensure(c.b_stage, n * 12)) return 1;
+    if (accum_host) {
+      launch_to_xmajor_f3(c.stream, accum_ptr(), (float*)c.b_stage.p, W, H);
+      HIP_TRY(hipMemcpyAsync(accum_host, c.b_stage.p, n * 12, hipMemcpyDeviceToHost, c.stream));
+      HIP_TRY(hipStreamSynchronize(c.stream));
+    }
+    if (screen_host) {
+      launch_to_xmajor_u32(c.stream, (const uint32_t*)c.b_screen.p, (uint32_t*)c.b_stage.p, W, H);
+      HIP_TRY(hipMemcpyAsync(screen_host, c.b_stage.p, n * 4, hipMemcpyDeviceToHost, c.stream));
+    }
+  } else {
+    if (accum_host) HIP_TRY(hipMemcpyAsync(accum_host, accum_ptr(), n * 12, hipMemcpyDeviceToHost, c.stream));
+    if (screen_host) HIP_TRY(hipMemcpyAsync(screen_host, c.b_screen.p, n * 4, hipMemcpyDeviceToHost, c.stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int debug_pass(const ArtPassParams* p, float* accum_host, uint32_t* screen_host, int32_t* prim_index, int32_t* mat_id, int32_t* prim_type) {
+  Ctx& c = g_ctx;
+  if (check_pass(p)) return 1;
+  ArtPassParams pp = *p; pp.aa_on = 0;
+  DevFrame F; make_frame(&pp, F);
+  const int npix = c.npix_local; const size_t n = (size_t)c.width * c.height;
+  if (ensure(c.b_ids, n * 12)) return 1;
+  HIP_TRY(hipMemsetAsync(c.b_ids.p, 0xff, n * 12, c.stream));
+  int32_t* d_pi = (int32_t*)c.b_ids.p; int32_t* d_mi = d_pi + n; int32_t* d_pt = d_mi + n;
+  const int pc = (int)std::min<int64_t>(npix, c.batch_paths);
+  if (npix > 0 && ensure_paths((size_t)pc, 1)) return 1;
+  for (int px0 = 0; px0 < npix; px0 += pc) {
+    const int pn = std::min(pc, npix - px0);
+    DevPaths q; std::memset(&q, 0, sizeof q);
+    q.P = pn; q.npix = pn; q.pixmap = (const uint32_t*)c.b_pixmap.p + px0; q.sample_base = 0;
+    carve(q, pn, 1);
+    launch_raygen(c.stream, F, c.scene, q);
+    c.camera_rays += (uint64_t)pn;
+    if (trace(q, pn)) return 1;
+    launch_debug(c.stream, F, c.scene, q, accum_ptr(), d_pi, d_mi, d_pt);
+  }
+  HIP_TRY(hipGetLastError());
+  // ray_tracer.adb:249-257: the debug image is resolved without dividing by spp
+  if (download(accum_host, screen_host, p->layout, 1)) return 1;
+  auto copy_ids = [&](int32_t* host, const int32_t* dev) -> int {
+    if (!host) return 0;
+    if (p->layout == ART_LAYOUT_ADA_XY) {
+      if (ensure(c.b_stage, n * 12)) return 1;
+      launch_to_xmajor_u32(c.stream, (const uint32_t*)dev, (uint32_t*)c.b_stage.p, c.width, c.height);
+      HIP_TRY(hipMemcpyAsync(host, c.b_stage.p, n * 4, hipMemcpyDeviceToHost, c.stream));
+    } else HIP_TRY(hipMemcpyAsync(host, dev, n * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    return 0;
+  };
+  if (copy_ids(prim_index, d_pi) || copy_ids(mat_id, d_mi) || copy_ids(prim_type, d_pt)) return 1;
+  return synchronize();
+}
+
+int trace_rays(const float* origins, const float* dirs, const float* tfar, int64_t n, ArtHit* out, int kernel, ArtStats* st) {
+  Ctx& c = g_ctx;
+  if (!c.scene_ready) return fail("no scene uploaded");
+  if (n <= 0 || n > (1ll << 28) || !origins || !dirs || !out) return fail("art_trace_rays: bad arguments");
+  if (kernel != TRACE_COOP && kernel != TRACE_SIMPLE) return fail("art_trace_rays: unknown kernel");
+  const size_t N = (size_t)n;
+  if (ensure(c.b_rays, N * 11 * 4)) return 1;
+  std::vector<float> soa(7 * N);
+  for (size_t i = 0; i < N; ++i) {
+    soa[i] = origins[3 * i]; soa[N + i] = origins[3 * i + 1]; soa[2 * N + i] = origins[3 * i + 2];
+    soa[3 * N + i] = dirs[3 * i]; soa[4 * N + i] = dirs[3 * i + 1]; soa[5 * N + i] = dirs[3 * i + 2];
+    soa[6 * N + i] = tfar ? tfar[i] : kInfinity;
+  }
+  float* d = (float*)c.b_rays.p;
+  HIP_TRY(hipMemcpyAsync(d, soa.data(), 7 * N * 4, hipMemcpyHostToDevice, c.stream));
+  HIP_TRY(hipMemsetAsync(d + 7 * N, 0xff, 4 * N * 4, c.stream));
+  HIP_TRY(hipMemsetAsync(c.d_counters + 3, 0, 5 * sizeof(unsigned long long), c.stream));
+  DevPaths q; std::memset(&q, 0, sizeof q);
+  q.ray_ox = d; q.ray_oy = d + N; q.ray_oz = d + 2 * N; q.ray_dx = d + 3 * N; q.ray_dy = d + 4 * N; q.ray_dz = d + 5 * N; q.ray_tfar = d + 6 * N;
+  q.hit_t = d + 7 * N; q.hit_key = (uint32_t*)(d + 8 * N); q.hit_u = d + 9 * N; q.hit_v = d + 10 * N;
+  const int saved_kernel = c.trace_kernel; const bool saved_count = c.count_tests;
+  c.trace_kernel = kernel; c.count_tests = (st != nullptr);
+  const int rc = trace(q, (int)n);
+  c.trace_kernel = saved_kernel; c.count_tests = saved_count;
+  if (rc) return 1;
+  std::vector<float> hits(4 * N);
+  HIP_TRY(hipMemcpyAsync(hits.data(), d + 7 * N, 4 * N * 4, hipMemcpyDeviceToHost, c.stream));
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  HIP_TRY(hipGetLastError());
+  HostScene& hs = c.host_scene;
+  bind_host_pointers(hs);
+  for (size_t i = 0; i < N; ++i) {
+    ArtHit& h = out[i];
+    uint32_t key; std::memcpy(&key, &hits[N + i], 4);
+    h.t = hits[i]; h.u = hits[2 * N + i]; h.v = hits[3 * N + i];
+    if (key == KEY_MISS) { h.is_hit = 0; h.prim_type = -1; h.prim_index = -1; h.mat_id = -1; h.mat = -1; h.normal[0] = h.normal[1] = h.normal[2] = 0.0f; continue; }
+    const f3 o = mk3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), dd = mk3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+    const Surface sf = surface_at(hs.hdr, o, dd, h.t, key, h.u, h.v);
+    const uint32_t cls = key & ~KEY_INDEX_MASK;
+    h.is_hit = 1; h.prim_index = (int32_t)(key & KEY_INDEX_MASK); h.mat_id = sf.mat_id; h.mat = sf.mat;
+    h.prim_type = (cls == KEY_CORNELL) ? 0 : (cls == KEY_SPHERE) ? 1 : (cls == KEY_QUAD) ? 3 : 2;
+    h.normal[0] = sf.normal.x; h.normal[1] = sf.normal.y; h.normal[2] = sf.normal.z;
+  }
+  if (synchronize()) return 1;
+  if (st) *st = c.stats;
+  return 0;
+}
+
+void shutdown() {
+  Ctx& c = g_ctx;
+  if (c.device_ready) {
+    (void)hipDeviceSynchronize();
+    DevBuf* bufs[] = {&c.b_spheres, &c.b_sphere_mat, &c.b_lights, &c.b_materials, &c.b_bf_pos, &c.b_bf_nrm, &c.b_bf_uv, &c.b_bf_idx,
+                      &c.b_nodes, &c.b_tris, &c.b_m_nrm, &c.b_m_uv, &c.b_m_idx, &c.b_m_matid, &c.b_accum, &c.b_screen, &c.b_stage,
+                      &c.b_pixmap, &c.b_paths, &c.b_rays, &c.b_ids};
+    for (DevBuf* b : bufs) b->release();
+    if (c.d_cursor) (void)hipFree(c.d_cursor);
+    if (c.d_counters) (void)hipFree(c.d_counters);
+    for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c.pass_events) (void)hipEventDestroy(e);
+  }
+  c = Ctx();
+}
+
+}  // namespace art
+
+// ================================================================================================
+using namespace art;
+
+extern "C" {
+
+int art_init(int device_ordinal) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_ctx.device_ready && device_ordinal >= 0 && device_ordinal != g_ctx.device) return fail("art_init: already bound to another device; call art_shutdown first");
+  g_ctx.device = device_ordinal;
+  if (const char* e = getenv("ART_TRACE_KERNEL")) g_ctx.trace_kernel = (std::strcmp(e, "simple") == 0) ? TRACE_SIMPLE : TRACE_COOP;
+  if (const char* e = getenv("ART_BATCH_PATHS")) g_ctx.batch_paths = std::max<int64_t>(1024, atoll(e));
+  return ensure_device();
+}
+
+int art_set_stream(void* hip_stream) { std::lock_guard<std::mutex> lk(g_mu); g_ctx.stream = (hipStream_t)hip_stream; return 0; }
+
+int art_upload_scene(const ArtSceneDesc* scene) { std::lock_guard<std::mutex> lk(g_mu); return upload_scene(scene); }
+
+int art_resize(int32_t w, int32_t h) { std::lock_guard<std::mutex> lk(g_mu); return resize(w, h); }
+
+int art_set_shard(int32_t rank, int32_t nranks, int32_t tile) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (nranks < 1 || rank < 0 || rank >= nranks || tile < 1) return fail("art_set_shard: bad arguments");
+  g_ctx.rank = rank; g_ctx.nranks = nranks; g_ctx.tile = tile;
+  if (g_ctx.width > 0) return build_shard();
+  return 0;
+}
+
+int art_render_pass(const ArtPassParams* p, float* accum_host, uint32_t* screen_host, int32_t* spp_inout) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (render_pass_device(p, spp_inout)) return 1;
+  if (accum_host || screen_host) { if (download(accum_host, screen_host, p->layout, g_ctx.spp)) return 1; }
+  return synchronize();
+}
+
+int art_debug_hit_pass(const ArtPassParams* p, float* accum_host, uint32_t* screen_host, int32_t* prim_index, int32_t* mat_id, int32_t* prim_type) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return debug_pass(p, accum_host, screen_host, prim_index, mat_id, prim_type);
+}
+
+int art_bind_accum(void* device_accum_rowmajor) { std::lock_guard<std::mutex> lk(g_mu); g_ctx.ext_accum = (float*)device_accum_rowmajor; return 0; }
+void* art_accum_device(void) { return accum_ptr(); }
+
+int art_download(float* accum_host, uint32_t* screen_host, int32_t layout, int32_t spp) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (spp <= 0) return fail("art_download: spp must be positive");
+  return download(accum_host, screen_host, layout, spp);
+}
+
+int art_synchronize(void) { std::lock_guard<std::mutex> lk(g_mu); return synchronize(); }
+
+int art_trace_rays(const float* origins, const float* dirs, const float* tfar, int64_t n, ArtHit* out, int32_t kernel, ArtStats* stats) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return trace_rays(origins, dirs, tfar, n, out, kernel, stats);
+}
+
+int art_export_bvh(float* nodes, int64_t node_cap, float* tris, int64_t tri_cap, ArtBvhInfo* info) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.scene_ready) return fail("no scene uploaded");
+  const Bvh8& b = g_ctx.host_scene.bvh;
+  if (info) { info->n_nodes = b.n_nodes; info->n_tris = b.n_tris; info->max_stack = b.max_stack; info->reserved = 0; info->build_ms = g_ctx.host_scene.bvh_build_ms; }
+  if (nodes) { if (node_cap < (int64_t)b.nodes.size()) return fail("art_export_bvh: node buffer too small"); std::memcpy(nodes, b.nodes.data(), b.nodes.size() * 4); }
+  if (tris) { if (tri_cap < (int64_t)b.tris.size()) return fail("art_export_bvh: triangle buffer too small"); std::memcpy(tris, b.tris.data(), b.tris.size() * 4); }
+  return 0;
+}
+
+int art_get_stats(ArtStats* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!out) return fail("null stats");
+  if (synchronize()) return 1;
+  *out = g_ctx.stats;
+  return 0;
+}
+
+int art_set_option(const char* name, int64_t value) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!name) return fail("null option");
+  const std::string n(name);
+  if (n == "trace_kernel") { if (value != TRACE_COOP && value != TRACE_SIMPLE) return fail("trace_kernel: 0 (cooperative) or 1 (simple)"); g_ctx.trace_kernel = (int)value; }
+  else if (n == "batch_paths") { if (value < 1024) return fail("batch_paths too small"); g_ctx.batch_paths = value; }
+  else if (n == "blocks_per_cu") { g_ctx.opt_blocks_per_cu = (int)value; g_ctx.blocks_per_cu = 0; }
+  else if (n == "count_tests") { g_ctx.count_tests = value != 0; }
+  else if (n == "bvh_max_leaf") { if (value < 1 || value > kMaxLeafTris) return fail("bvh_max_leaf: 1..8"); g_ctx.bvh_params.max_leaf = (int)value; }
+  else if (n == "bvh_leaf_base_milli") { g_ctx.bvh_params.leaf_base = (float)value / 1000.0f; }
+  else if (n == "bvh_node_cost_milli") { g_ctx.bvh_params.node_cost = (float)value / 1000.0f; }
+  else return fail("unknown option " + n);
+  return 0;
+}
+
+const char* art_last_error(void) { t_err = g_err; return t_err.c_str(); }
+
+void art_shutdown(void) { std::lock_guard<std::mutex> lk(g_mu); shutdown(); }
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// art_api_internal.h -- process-wide backend state (the reference keeps the same kind of singleton:
+// g_data in embree_connect.cpp:12-22 and the package-level variables of ray_tracer.ads:20-33,106-109).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/art_hip.h"
+#include "art_host_scene.h"
+#include "art_kernels.h"
+
+namespace art {
+
+struct DevBuf { void* p = nullptr; size_t bytes = 0; void release(); };
+
+struct Ctx {
+  int device = -1; bool device_ready = false; int num_cus = 0; std::string arch;
+  hipStream_t stream = nullptr;
+  // scene
+  bool scene_ready = false;
+  HostScene host_scene;
+  DevScene scene;
+  BvhBuildParams bvh_params;
+  DevBuf b_spheres, b_sphere_mat, b_lights, b_materials, b_bf_pos, b_bf_nrm, b_bf_uv, b_bf_idx, b_nodes, b_tris, b_m_nrm, b_m_uv, b_m_idx, b_m_matid;
+  int stack_entries = 8;
+  // frame
+  int width = 0, height = 0, spp = 0;
+  int rank = 0, nranks = 1, tile = 32, npix_local = 0;
+  DevBuf b_accum, b_screen, b_stage, b_pixmap, b_paths, b_rays, b_ids;
+  float* ext_accum = nullptr;
+  // work distribution / counters
+  int* d_cursor = nullptr;
+  unsigned long long* d_counters = nullptr;   // [0] rays issued by shade, [3..7] box, tri, node, leaf, rays of counting traces
+  uint64_t camera_rays = 0;
+  // options
+  int trace_kernel = TRACE_COOP;
+  int64_t batch_paths = 8ll << 20;
+  int opt_blocks_per_cu = 0, blocks_per_cu = 0;
+  bool count_tests = false;
+  // timing
+  std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+  std::vector<hipEvent_t> pass_events;
+  ArtStats stats = ArtStats();
+};
+
+extern Ctx g_ctx;
+extern std::mutex g_mu;
+
+int fail(const std::string& msg);
+int ensure_device();
+int upload_scene(const ArtSceneDesc* d);
+int resize(int w, int h);
+int trace_rays(const float* origins, const float* dirs, const float* tfar, int64_t n, ArtHit* out, int kernel, ArtStats* st);
+void shutdown();
+
+}  // namespace art

@@ -1,0 +1,34 @@
+// art_bvh.h -- host BVH8 builder interface (see art_bvh.cpp).
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "art_scene.h"
+
+namespace art {
+
+struct BvhBuildParams {
+  int   max_leaf = 8;            // <= kMaxLeafTris: one leaf = one 8-lane packet of triangle tests
+  // SAH costs in units of one cooperative traversal step: a leaf of <= 8 triangles is ONE 8-lane packet whatever
+  // its size, and a BVH2 split only costs a fraction of a BVH8 node step after the collapse.
+  float node_cost = 0.4f;        // cost of one BVH2 inner node
+  float leaf_base = 1.0f;        // fixed cost of visiting a leaf
+  float tri_cost = 0.05f;        // cost per triangle in a leaf
+  int   max_sah_depth = 48;      // beyond this BVH2 depth fall back to median splits
+  int   parallel_depth = 3;      // top levels built by std::async tasks
+  float inflate_rel = 8.0e-6f;   // conservative padding of child boxes (relative to |coordinate|)
+  float inflate_abs = 1.0e-6f;
+  float leaf_cost(int n) const { return leaf_base + tri_cost * (float)n; }
+};
+
+struct Bvh8 {
+  std::vector<float> nodes;      // kNodeFloats per node, node 0 = root
+  std::vector<float> tris;       // kTriFloats per triangle, in leaf order
+  int32_t n_nodes = 0, n_tris = 0;
+  int32_t max_stack = 1;         // worst-case traversal stack entries for this tree
+};
+
+// tri9: 9 floats per triangle (A,B,C); prim_ids: id written into each triangle record (nullptr = 0..n-1)
+bool build_bvh8(const float* tri9, const int32_t* prim_ids, int32_t n, const BvhBuildParams& prm, Bvh8& out, std::string& err);
+
+}  // namespace art

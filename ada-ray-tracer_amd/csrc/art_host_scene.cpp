@@ -1,0 +1,101 @@
+// art_host_scene.cpp -- see art_host_scene.h.  Mirrors what Scene.Init hands to the renderer
+// (scene.adb:89-217 for the internal scene, scene_hydra_embree.adb:251-296 for uploaded meshes).
+#include "art_host_scene.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+namespace art {
+
+static bool finite3(const float* p) { return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]); }
+
+bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& out, std::string& err) {
+  out = HostScene();
+  if (d.n_spheres < 0 || d.n_lights < 1 || d.n_materials < 1 || d.n_meshes < 0) { err = "scene: negative count, or no light / no material (Light_At(0) must exist, scene.adb:45-48)"; return false; }
+  if ((d.n_spheres && !d.spheres) || !d.lights || !d.materials || (d.n_meshes && !d.meshes)) { err = "scene: null array pointer"; return false; }
+  if (d.n_spheres >= (1 << 28) || d.n_lights > 64) { err = "scene: too many spheres / lights (max 64 lights)"; return false; }
+  auto mat_ok = [&](int32_t m) { return m >= 0 && m < d.n_materials; };
+
+  for (int i = 0; i < d.n_materials; ++i) {
+    const ArtMaterial& m = d.materials[i];
+    if (m.type < ART_MAT_NULL || m.type > ART_MAT_PHONG) { err = "scene: unknown material type"; return false; }
+    if (m.type == ART_MAT_LIGHT && (m.light < 0 || m.light >= d.n_lights)) { err = "scene: MaterialLight refers to a missing light"; return false; }
+    DevMaterial dm; dm.type = m.type; dm.light = m.light; std::memcpy(dm.p, m.p, sizeof dm.p);
+    out.materials.push_back(dm);
+  }
+  for (int i = 0; i < d.n_lights; ++i) {
+    const ArtLight& l = d.lights[i];
+    if (l.shape != ART_LIGHT_RECT && l.shape != ART_LIGHT_SPHERE) { err = "scene: unknown light shape"; return false; }
+    if (!mat_ok(l.mat)) { err = "scene: light.mat out of range"; return false; }
+    DevLight dl; std::memset(&dl, 0, sizeof dl);
+    dl.shape = l.shape; dl.mat = l.mat;
+    std::memcpy(dl.boxMin, l.boxMin, 12); std::memcpy(dl.boxMax, l.boxMax, 12); std::memcpy(dl.normal, l.normal, 12);
+    std::memcpy(dl.center, l.center, 12); dl.radius = l.radius; std::memcpy(dl.intensity, l.intensity, 12); dl.surfaceArea = l.surfaceArea;
+    out.lights.push_back(dl);
+  }
+  for (int i = 0; i < d.n_spheres; ++i) {
+    const ArtSphere& s = d.spheres[i];
+    if (!mat_ok(s.mat)) { err = "scene: sphere.mat out of range"; return false; }
+    if (!finite3(s.pos) || !std::isfinite(s.r)) { err = "scene: non-finite sphere"; return false; }
+    DevSphere ds; ds.x = s.pos[0]; ds.y = s.pos[1]; ds.z = s.pos[2]; ds.r = s.r;
+    out.spheres.push_back(ds); out.sphere_mat.push_back(s.mat);
+  }
+  DevScene& h = out.hdr;
+  std::memset(&h, 0, sizeof h);
+  h.n_spheres = d.n_spheres; h.n_lights = d.n_lights; h.n_materials = d.n_materials;
+  h.has_cornell = d.has_cornell ? 1 : 0;
+  std::memcpy(h.cb_min, d.cb_min, 12); std::memcpy(h.cb_max, d.cb_max, 12);
+  std::memcpy(h.cb_mat, d.cb_mat, sizeof h.cb_mat); std::memcpy(h.cb_nrm, d.cb_nrm, sizeof h.cb_nrm);
+  if (h.has_cornell) for (int i = 0; i < 6; ++i) if (!mat_ok(h.cb_mat[i])) { err = "scene: Cornell box material index out of range"; return false; }
+  std::memcpy(h.cam_pos, d.cam_pos, 12); std::memcpy(h.cam_matrix, d.cam_matrix, 64);
+
+  bool have_bf = false, have_closest = false;
+  for (int mi = 0; mi < d.n_meshes; ++mi) {
+    const ArtMesh& m = d.meshes[mi];
+    if (m.nverts <= 0 || m.ntris <= 0 || !m.pos || !m.nrm || !m.idx) { err = "scene: empty mesh or null mesh array"; return false; }
+    if (m.ntris >= (1 << 27)) { err = "scene: mesh too large (max 2^27-1 triangles)"; return false; }
+    for (int64_t i = 0; i < 3 * (int64_t)m.ntris; ++i)
+      if (m.idx[i] < 0 || m.idx[i] >= m.nverts) { err = "scene: triangle index out of range"; return false; }
+    if (m.mode == ART_MESH_REFERENCE_BF) {
+      if (have_bf) { err = "scene: at most one REFERENCE_BF mesh"; return false; }
+      have_bf = true;
+      if (!mat_ok(2)) { err = "scene: REFERENCE_BF mesh needs material 2 (geometry.adb:311)"; return false; }
+      out.bf_pos.assign(m.pos, m.pos + 3 * (size_t)m.nverts);
+      out.bf_nrm.assign(m.nrm, m.nrm + 3 * (size_t)m.nverts);
+      if (m.uv) out.bf_uv.assign(m.uv, m.uv + 2 * (size_t)m.nverts); else out.bf_uv.assign(2 * (size_t)m.nverts, 0.0f);
+      out.bf_idx.assign(m.idx, m.idx + 3 * (size_t)m.ntris);
+      out.bf_ntris = m.ntris; h.bf_ntris = m.ntris;
+      std::memcpy(h.bf_bbmin, m.bbmin, 12); std::memcpy(h.bf_bbmax, m.bbmax, 12);
+    } else if (m.mode == ART_MESH_CLOSEST) {
+      if (have_closest) { err = "scene: at most one CLOSEST mesh"; return false; }
+      have_closest = true;
+      if (!m.matid) { err = "scene: CLOSEST mesh needs material_ids"; return false; }
+      for (int i = 0; i < m.ntris; ++i) if (!mat_ok(m.matid[i])) { err = "scene: triangle material id out of range"; return false; }
+      out.m_pos.assign(m.pos, m.pos + 3 * (size_t)m.nverts);
+      out.m_nrm.assign(m.nrm, m.nrm + 3 * (size_t)m.nverts);
+      if (m.uv) out.m_uv.assign(m.uv, m.uv + 2 * (size_t)m.nverts); else out.m_uv.assign(2 * (size_t)m.nverts, 0.0f);
+      out.m_idx.assign(m.idx, m.idx + 3 * (size_t)m.ntris);
+      out.m_matid.assign(m.matid, m.matid + m.ntris);
+      std::vector<float> tri9(9 * (size_t)m.ntris);
+      for (int i = 0; i < m.ntris; ++i)
+        for (int k = 0; k < 3; ++k) std::memcpy(&tri9[9 * (size_t)i + 3 * k], m.pos + 3 * (size_t)m.idx[3 * (size_t)i + k], 12);
+      const auto t0 = std::chrono::steady_clock::now();
+      if (!build_bvh8(tri9.data(), nullptr, m.ntris, bp, out.bvh, err)) return false;
+      out.bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      h.n_tris = out.bvh.n_tris; h.n_nodes = out.bvh.n_nodes;
+    } else { err = "scene: unknown mesh mode"; return false; }
+  }
+  return true;
+}
+
+void bind_host_pointers(HostScene& hs) {
+  DevScene& h = hs.hdr;
+  h.spheres = hs.spheres.data(); h.sphere_mat = hs.sphere_mat.data();
+  h.lights = hs.lights.data(); h.materials = hs.materials.data();
+  h.bf_pos = hs.bf_pos.data(); h.bf_nrm = hs.bf_nrm.data(); h.bf_uv = hs.bf_uv.data(); h.bf_idx = hs.bf_idx.data();
+  h.nodes = hs.bvh.nodes.data(); h.tris = hs.bvh.tris.data();
+  h.m_nrm = hs.m_nrm.data(); h.m_uv = hs.m_uv.data(); h.m_idx = hs.m_idx.data(); h.m_matid = hs.m_matid.data();
+}
+
+}  // namespace art

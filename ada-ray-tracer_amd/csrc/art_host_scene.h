@@ -1,0 +1,32 @@
+// art_host_scene.h -- validation + flattening of an ArtSceneDesc into the packed host arrays that are
+// copied to HBM (and, in the host-simulation test build, consumed directly).  Scene.Init's job.
+#pragma once
+#include <string>
+#include <vector>
+#include "../../include/art_hip.h"
+#include "art_bvh.h"
+#include "art_scene.h"
+
+namespace art {
+
+struct HostScene {
+  std::vector<DevSphere> spheres; std::vector<int32_t> sphere_mat;
+  std::vector<DevLight> lights;
+  std::vector<DevMaterial> materials;
+  // brute-force (reference) mesh
+  std::vector<float> bf_pos, bf_nrm, bf_uv; std::vector<int32_t> bf_idx;
+  int32_t bf_ntris = 0;
+  // closest-hit mesh
+  std::vector<float> m_nrm, m_uv; std::vector<int32_t> m_idx, m_matid;
+  std::vector<float> m_pos;   // kept for gcore-style geometric normals / export
+  Bvh8 bvh;
+  double bvh_build_ms = 0.0;
+  DevScene hdr;               // scalar part; pointer members are filled by the owner (host or device addresses)
+};
+
+bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& out, std::string& err);
+
+// points hdr's pointer members at the host vectors (host simulation / CPU-side checks)
+void bind_host_pointers(HostScene& hs);
+
+}  // namespace art

@@ -1,0 +1,188 @@
+// art_isect.h -- ray / primitive intersection with the reference's arithmetic, restructured around a
+// single running candidate (t, key, u, v) so that the closest hit is an order-independent
+// lexicographic minimum (needed by a BVH whose traversal order differs from the reference's scan).
+//   spheres      geometry.adb:48-115      Cornell box geometry.adb:146-229
+//   flat light   geometry.adb:118-143     triangle    geometry.adb:231-263
+//   brute-force mesh (reference quirk mode) geometry.adb:266-323
+#pragma once
+#include "art_scene.h"
+
+namespace art {
+
+struct Cand { float t; uint32_t key; float u, v; };
+
+ART_HD Cand cand_init(float tfar) { Cand c; c.t = tfar; c.key = KEY_MISS; c.u = 0.0f; c.v = 0.0f; return c; }
+
+// strict '<' of scene.adb:73 / geometry.adb:72-78 generalised to (t, key); an equal t can only
+// displace an existing hit of higher key, never the initial bound.
+ART_HD bool cand_wins(float t, uint32_t key, const Cand& b) {
+  return (t < b.t) || (t == b.t && b.key != KEY_MISS && key < b.key);
+}
+
+ART_HD void cand_take(Cand& b, float t, uint32_t key, float u, float v) {
+  if (cand_wins(t, key, b)) { b.t = t; b.key = key; b.u = u; b.v = v; }
+}
+
+// one sphere of IntersectAllSpheres: candidate root = t1 if t1 > 0 else t2 if t2 > 0  (t2 >= t1)
+ART_HD void isect_sphere(f3 o, f3 d, const DevSphere& s, uint32_t index, Cand& best) {
+  const f3 k = o - mk3(s.x, s.y, s.z);
+  const float b = dot(k, d);
+  const float c = dot(k, k) - s.r * s.r;
+  const float disc = b * b - c;
+  if (disc >= 0.0f) {
+    const float sq = sqrtf(disc);
+    const float t1 = -b - sq, t2 = -b + sq;
+    if (t1 > 0.0f) { if (t1 < kInfinity) cand_take(best, t1, KEY_SPHERE | index, 0.0f, 0.0f); }
+    else if (t2 > 0.0f) { if (t2 < kInfinity) cand_take(best, t2, KEY_SPHERE | index, 0.0f, 0.0f); }
+  }
+}
+
+// IntersectBox, verbatim slab arithmetic (compare-select min/max, 1/dir may be +-inf)
+ART_HD bool slab_reference(f3 o, f3 d, const float* bmin, const float* bmax, float& tmin, float& tmax) {
+  const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+  const float lo = (bmax[0] - o.x) * ix, hi = (bmin[0] - o.x) * ix;
+  const float lo1 = (bmax[1] - o.y) * iy, hi1 = (bmin[1] - o.y) * iy;
+  const float lo2 = (bmax[2] - o.z) * iz, hi2 = (bmin[2] - o.z) * iz;
+  tmin = amin(lo, hi); tmax = amax(lo, hi);
+  tmin = amax(tmin, amin(lo1, hi1)); tmax = amin(tmax, amax(lo1, hi1));
+  tmin = amax(tmin, amin(lo2, hi2)); tmax = amin(tmax, amax(lo2, hi2));
+  return (tmax > 0.0f) && (tmin <= tmax);
+}
+
+// IntersectCornellBox: exit distance, face by |p - bound| < 1e-5 with later faces overriding, open face 5
+ART_HD void isect_cornell(f3 o, f3 d, const DevScene& s, Cand& best) {
+  float tmin, tmax;
+  if (!slab_reference(o, d, s.cb_min, s.cb_max, tmin, tmax)) return;
+  const f3 p = o + tmax * d;
+  const float eps = 1.0e-5f;
+  uint32_t plane = 0;
+  if (fabsf(p.x - s.cb_min[0]) < eps) plane = 0;
+  if (fabsf(p.x - s.cb_max[0]) < eps) plane = 1;
+  if (fabsf(p.y - s.cb_min[1]) < eps) plane = 2;
+  if (fabsf(p.y - s.cb_max[1]) < eps) plane = 3;
+  if (fabsf(p.z - s.cb_min[2]) < eps) plane = 4;
+  if (fabsf(p.z - s.cb_max[2]) < eps) plane = 5;
+  if (plane != 5) cand_take(best, tmax, KEY_CORNELL | plane, 0.0f, 0.0f);
+}
+
+// IntersectFlatLight for rect light `index`
+ART_HD void isect_quad(f3 o, f3 d, const DevLight& l, uint32_t index, Cand& best) {
+  const float inv_y = 1.0f / d.y;
+  const float t = (l.boxMax[1] - o.y) * inv_y;
+  const f3 hp = o + t * d;
+  const bool hit = (hp.x > l.boxMin[0]) && (hp.x < l.boxMax[0]) && (hp.z > l.boxMin[2]) && (hp.z < l.boxMax[2]) && (t >= 0.0f);
+  if (hit) cand_take(best, t, KEY_QUAD | index, 0.0f, 0.0f);
+}
+
+// IntersectTriangle without the window test: returns whether (v>0, u>0, u+v<1) holds and the raw t,u,v.
+// invDet = 1/max(det, 1e-25) rejects back faces exactly as the reference does.
+ART_HD bool tri_raw(f3 o, f3 d, f3 A, f3 B, f3 C, float& t, float& u, float& v) {
+  const f3 e1 = B - A, e2 = C - A;
+  const f3 pv = cross(d, e2);
+  const f3 tv = o - A;
+  const f3 qv = cross(tv, e1);
+  const float inv = 1.0f / amax(dot(e1, pv), 1.0e-25f);
+  v = dot(tv, pv) * inv;
+  u = dot(qv, d) * inv;
+  t = dot(e2, qv) * inv;
+  return (v > 0.0f) && (u > 0.0f) && (u + v < 1.0f);
+}
+
+ART_HD f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
+// IntersectMeshBF with its (tmin, tmax) window semantics: triangles in index order, the window
+// collapses to (t, t+1e-6) after every accepted hit ("first hit wins").  One candidate results.
+ART_HD void isect_bf_mesh(f3 o, f3 d, const DevScene& s, Cand& best) {
+  if (s.bf_ntris <= 0) return;
+  float bt0, bt1;
+  if (!slab_reference(o, d, s.bf_bbmin, s.bf_bbmax, bt0, bt1)) return;
+  float wmin = 0.0f, wmax = 1000000.0f;
+  bool any = false; uint32_t tri_id = 0; float ht = 0.0f, hu = 0.0f, hv = 0.0f;
+  for (int i = 0; i < s.bf_ntris; ++i) {
+    const int32_t* ix = s.bf_idx + 3 * i;
+    float t, u, v;
+    if (tri_raw(o, d, ld3(s.bf_pos + 3 * ix[0]), ld3(s.bf_pos + 3 * ix[1]), ld3(s.bf_pos + 3 * ix[2]), t, u, v) && t > wmin && t < wmax) {
+      any = true; tri_id = (uint32_t)i; ht = t; hu = u; hv = v;
+      wmin = t; wmax = t + 1.0e-6f;
+    }
+  }
+  if (any) cand_take(best, ht, KEY_BFTRI | tri_id, hu, hv);
+}
+
+// ---- BVH8 traversal, one ray per caller (the cooperative 8-lane kernel lives in art_kernels.hip).
+// Published order (DESIGN.md "Traversal order"): pop; drop if entry.tmin > best.t; inner node: test
+// the valid children against [max(.,0), min(., best.t)], sort hits ascending by
+// key = (bits(tmin) & ~7) | slot, push far-to-near; leaf: test its triangles in storage order.
+struct BvhStats { uint64_t box_tests, tri_tests, node_visits, leaf_visits; };
+
+ART_HD void slab_fast(const float* nd, int j, f3 o, f3 inv, float tbest, float& tmn, float& tmx) {
+  const float t0x = (nd[4 * j + 0] - o.x) * inv.x, t1x = (nd[32 + 4 * j + 0] - o.x) * inv.x;
+  const float t0y = (nd[4 * j + 1] - o.y) * inv.y, t1y = (nd[32 + 4 * j + 1] - o.y) * inv.y;
+  const float t0z = (nd[4 * j + 2] - o.z) * inv.z, t1z = (nd[32 + 4 * j + 2] - o.z) * inv.z;
+  tmn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+  tmx = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tbest));
+}
+
+ART_HD void tri_leaf_test(const float* tr, f3 o, f3 d, Cand& best) {
+  float t, u, v;
+  if (tri_raw(o, d, ld3(tr), ld3(tr + 3), ld3(tr + 6), t, u, v) && t > 0.0f && t < 1000000.0f)
+    cand_take(best, t, KEY_TRI | (uint32_t)__builtin_bit_cast(int32_t, tr[9]), u, v);
+}
+
+template <bool STATS>
+ART_HD void bvh_closest(const DevScene& s, f3 o, f3 d, Cand& best, BvhStats* st) {
+  if (s.n_tris <= 0) return;
+  const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  int32_t stk_ref[kStackEntries]; float stk_t[kStackEntries];
+  int sp = 0;
+  stk_ref[sp] = 0; stk_t[sp] = 0.0f; ++sp;        // entry = (ref << 4) | count
+  while (sp > 0) {
+    --sp;
+    const int32_t e = stk_ref[sp];
+    if (stk_t[sp] > best.t) continue;
+    const int32_t ref = e >> 4, cnt = e & 15;
+    if (cnt == 0) {
+      const float* nd = s.nodes + (size_t)ref * kNodeFloats;
+      uint32_t key[8]; int32_t ent[8]; float tm[8]; int nh = 0;
+      if (STATS) st->node_visits++;
+      for (int j = 0; j < 8; ++j) {
+        const int32_t rj = __builtin_bit_cast(int32_t, nd[4 * j + 3]);
+        if (rj < 0) continue;
+        if (STATS) st->box_tests++;
+        float tmn, tmx;
+        slab_fast(nd, j, o, inv, best.t, tmn, tmx);
+        if (tmn <= tmx) {
+          key[nh] = (__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j;
+          ent[nh] = (rj << 4) | __builtin_bit_cast(int32_t, nd[32 + 4 * j + 3]);
+          tm[nh] = tmn; ++nh;
+        }
+      }
+      for (int a = 1; a < nh; ++a) {                // ascending insertion sort by key
+        const uint32_t k = key[a]; const int32_t ee = ent[a]; const float tt = tm[a];
+        int b = a - 1;
+        while (b >= 0 && key[b] > k) { key[b + 1] = key[b]; ent[b + 1] = ent[b]; tm[b + 1] = tm[b]; --b; }
+        key[b + 1] = k; ent[b + 1] = ee; tm[b + 1] = tt;
+      }
+      for (int a = nh - 1; a >= 0; --a) { stk_ref[sp] = ent[a]; stk_t[sp] = tm[a]; ++sp; }
+    } else {
+      if (STATS) { st->leaf_visits++; st->tri_tests += (uint64_t)cnt; }
+      for (int j = 0; j < cnt; ++j) tri_leaf_test(s.tris + (size_t)(ref + j) * kTriFloats, o, d, best);
+    }
+  }
+}
+
+// Scene.Find_Closest_Hit (scene.adb:56-86) for one ray; tfar clips the search (shadow rays only need
+// hits below maxDist - epsilon2, ray_tracer.adb:119-122; camera/bounce rays pass kInfinity).
+template <bool STATS>
+ART_HD Cand closest_hit(const DevScene& s, f3 o, f3 d, float tfar, BvhStats* st) {
+  Cand best = cand_init(tfar);
+  for (int i = 0; i < s.n_spheres; ++i) isect_sphere(o, d, s.spheres[i], (uint32_t)i, best);
+  if (s.has_cornell) isect_cornell(o, d, s, best);
+  for (int i = 0; i < s.n_lights; ++i)
+    if (s.lights[i].shape == LIGHT_RECT) isect_quad(o, d, s.lights[i], (uint32_t)i, best);
+  isect_bf_mesh(o, d, s, best);
+  bvh_closest<STATS>(s, o, d, best, st);
+  return best;
+}
+
+}  // namespace art

@@ -1,0 +1,34 @@
+// art_kernels.h -- launch interface between art_api.cpp (host driver) and art_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "art_shade.h"
+
+namespace art {
+
+enum { TRACE_COOP = 0, TRACE_SIMPLE = 1 };
+
+struct TraceArgs {
+  int32_t n_rays;
+  int32_t stack_entries;        // per-ray-group LDS stack depth (>= Bvh8::max_stack)
+  const float* ray_ox; const float* ray_oy; const float* ray_oz;
+  const float* ray_dx; const float* ray_dy; const float* ray_dz;
+  const float* ray_tfar;        // < 0: skip
+  float* hit_t; uint32_t* hit_key; float* hit_u; float* hit_v;
+  int* cursor;                  // work cursor, zeroed before every launch
+  unsigned long long* stats;    // [box, tri, node, leaf, rays] when counting
+};
+
+void launch_raygen(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q);
+void launch_shade(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q, int bounce, unsigned long long* ray_counter);
+void launch_finish(hipStream_t st, const DevFrame& F, const DevPaths& Q, int last_level);
+void launch_accumulate(hipStream_t st, const DevFrame& F, const DevPaths& Q, int samples_in_batch, float* accum);
+void launch_resolve(hipStream_t st, const float* accum, int n_pixels, float norm_c, uint32_t* screen);
+void launch_debug(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q, float* accum, int32_t* prim_index, int32_t* mat_id, int32_t* prim_type);
+void launch_to_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, int h);
+void launch_to_xmajor_u32(hipStream_t st, const uint32_t* src, uint32_t* dst, int w, int h);
+void launch_from_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, int h);
+size_t trace_coop_lds_bytes(int stack_entries);
+void launch_trace(hipStream_t st, const DevScene& S, const TraceArgs& A, int kernel, bool stats, int grid_blocks);
+int  trace_coop_blocks_per_cu(int stack_entries);
+
+}  // namespace art

@@ -1,0 +1,382 @@
+// art_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the render backend.
+//
+//   k_trace_coop   the hot kernel.  Persistent workgroups; every wave runs 8 independent rays, one per
+//                  8-lane group.  A BVH8 node is one 256-byte packet: lane j of the group loads child j
+//                  (2 x 16 B, the group reads 2 x 128 contiguous bytes), all 64 lanes run one slab test,
+//                  the hits are ranked with DPP cross-lane compares and pushed far-to-near onto the
+//                  group's traversal stack in LDS.  Leaves hold <= 8 triangles: one Moeller-Trumbore
+//                  test per lane, then a 3-step DPP min-reduction.  Rays are pulled in chunks from a
+//                  global atomic cursor (one atomic per 64 rays) and handed to idle groups by ballot.
+//   k_trace_simple one ray per lane, private stack -- the reference traversal used to cross-check.
+//   k_raygen / k_shade / k_finish / k_accumulate / k_resolve / k_debug   wavefront path-tracing stages
+//                  (thin wrappers over the per-slot functions in art_shade.h).
+//
+// Replaces Scene.Find_Closest_Hit (scene.adb:56-86), the Embree bridge (embree_connect.cpp:196-238),
+// PathTrace (ray_tracer-integrators.adb:82-301) and the DoPass pixel loop (integrators.adb:25-71).
+#include <hip/hip_runtime.h>
+#include "art_kernels.h"
+
+namespace art {
+
+// ------------------------------------------------------------------------------------------------
+// cross-lane helpers for 8-lane groups (DPP: quad_perm + row_half_mirror stay inside 8 lanes)
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
+
+constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int DPP_XOR3 = 0x1B;          // quad_perm [3,2,1,0]
+constexpr int DPP_HALF_MIRROR = 0x141;  // lane i <- lane 7-i  (= xor 7 inside an 8-lane group)
+
+// value of lane (j ^ 4) of the same group: half mirror (xor 7) followed by quad reverse (xor 3)
+__device__ __forceinline__ int xor4_i(int v) { return dpp_i<DPP_XOR3>(dpp_i<DPP_HALF_MIRROR>(v)); }
+__device__ __forceinline__ float xor4_f(float v) { return dpp_f<DPP_XOR3>(dpp_f<DPP_HALF_MIRROR>(v)); }
+
+// number of lanes in my 8-lane group whose key is smaller than mine (keys are < 2^31)
+__device__ __forceinline__ int group_rank(int key) {
+  const int m = dpp_i<DPP_HALF_MIRROR>(key);
+  int r = 0;
+  r += (dpp_i<DPP_XOR1>(key) < key);
+  r += (dpp_i<DPP_XOR2>(key) < key);
+  r += (dpp_i<DPP_XOR3>(key) < key);
+  r += (m < key);
+  r += (dpp_i<DPP_XOR1>(m) < key);
+  r += (dpp_i<DPP_XOR2>(m) < key);
+  r += (dpp_i<DPP_XOR3>(m) < key);
+  return r;
+}
+
+// lexicographic (t, key) minimum across the group; every lane ends with the winner
+__device__ __forceinline__ void group_min_tk(float& t, uint32_t& key) {
+  {
+    const float ot = dpp_f<DPP_XOR1>(t); const uint32_t ok = (uint32_t)dpp_i<DPP_XOR1>((int)key);
+    if (ot < t || (ot == t && ok < key)) { t = ot; key = ok; }
+  }
+  {
+    const float ot = dpp_f<DPP_XOR2>(t); const uint32_t ok = (uint32_t)dpp_i<DPP_XOR2>((int)key);
+    if (ot < t || (ot == t && ok < key)) { t = ot; key = ok; }
+  }
+  {
+    const float ot = xor4_f(t); const uint32_t ok = (uint32_t)xor4_i((int)key);
+    if (ot < t || (ot == t && ok < key)) { t = ot; key = ok; }
+  }
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------------
+// cooperative persistent trace kernel
+// ------------------------------------------------------------------------------------------------
+constexpr int kChunk = 64;   // rays fetched per atomic
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_trace_coop(const DevScene S, const TraceArgs A) {
+  extern __shared__ uint2 lds_stack[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 7, g = lane >> 3;
+  const int gbase = lane & ~7;
+  uint2* const stk = lds_stack + (size_t)(wave * 8 + g) * (A.stack_entries + 1);
+  const uint64_t leaders = 0x0101010101010101ull;
+
+  int chunk_pos = 0, chunk_end = 0;   // wave-uniform
+  bool exhausted = false;             // wave-uniform
+  bool has_ray = false;               // group-uniform
+  int sp = 0, ray = 0;                // group-uniform
+  f3 o = mk3(0, 0, 0), d = o, inv = o;
+  Cand best = cand_init(0.0f);
+  uint64_t st_box = 0, st_tri = 0, st_node = 0, st_leaf = 0, st_rays = 0;
+
+  for (;;) {
+    // ---------------- refill idle groups from the wave's chunk
+    bool need = !has_ray;
+    while (!exhausted) {
+      const uint64_t need_mask = __ballot(need) & leaders;
+      if (need_mask == 0) break;
+      if (chunk_pos == chunk_end) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(A.cursor, kChunk);
+        base = __builtin_amdgcn_readfirstlane(base);
+        chunk_pos = base; chunk_end = min(base + kChunk, A.n_rays);
+        if (chunk_pos >= A.n_rays) { exhausted = true; chunk_pos = chunk_end = 0; break; }
+      }
+      const int avail = chunk_end - chunk_pos;
+      const int n_need = __popcll(need_mask);
+      const int my_rank = __popcll(need_mask & ((1ull << gbase) - 1ull));
+      const bool got = need && (my_rank < avail);
+      if (got) {
+        ray = chunk_pos + my_rank;
+        const float tfar = A.ray_tfar[ray];
+        if (tfar >= 0.0f) {
+          // ---- new live ray: load, intersect the analytic primitives (one per lane), seed the stack
+          o = mk3(A.ray_ox[ray], A.ray_oy[ray], A.ray_oz[ray]);
+          d = mk3(A.ray_dx[ray], A.ray_dy[ray], A.ray_dz[ray]);
+          inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+          Cand c = cand_init(tfar);
+          const int n_items = S.n_spheres + 1 + S.n_lights;
+          for (int it = j; it < n_items; it += 8) {
+            if (it < S.n_spheres) isect_sphere(o, d, S.spheres[it], (uint32_t)it, c);
+            else if (it == S.n_spheres) { if (S.has_cornell) isect_cornell(o, d, S, c); }
+            else { const int li = it - S.n_spheres - 1; if (S.lights[li].shape == LIGHT_RECT) isect_quad(o, d, S.lights[li], (uint32_t)li, c); }
+          }
+          group_min_tk(c.t, c.key);
+          best = c; best.u = 0.0f; best.v = 0.0f;
+          if (best.key == KEY_MISS) best.t = tfar;
+          if (S.bf_ntris > 0) {   // reference brute-force mesh: lanes test 8 triangles, the window scan runs in index order
+            float b0, b1;
+            if (slab_reference(o, d, S.bf_bbmin, S.bf_bbmax, b0, b1)) {
+              float wmin = 0.0f, wmax = 1000000.0f, ht = 0.0f, hu = 0.0f, hv = 0.0f; bool any = false; uint32_t tri_id = 0;
+              for (int base = 0; base < S.bf_ntris; base += 8) {
+                const int i = base + j;
+                float tt = 0.0f, uu = 0.0f, vv = 0.0f; bool pass = false;
+                if (i < S.bf_ntris) {
+                  const int32_t* ix = S.bf_idx + 3 * i;
+                  pass = tri_raw(o, d, ld3(S.bf_pos + 3 * ix[0]), ld3(S.bf_pos + 3 * ix[1]), ld3(S.bf_pos + 3 * ix[2]), tt, uu, vv);
+                }
+                for (int k = 0; k < 8; ++k) {
+                  const float tk = __shfl(tt, gbase + k);
+                  const int pk = __shfl((int)pass, gbase + k);
+                  const float uk = __shfl(uu, gbase + k), vk = __shfl(vv, gbase + k);
+                  if (pk && tk > wmin && tk < wmax) { any = true; tri_id = (uint32_t)(base + k); ht = tk; hu = uk; hv = vk; wmin = tk; wmax = tk + 1.0e-6f; }
+                }
+              }
+              if (any) cand_take(best, ht, KEY_BFTRI | tri_id, hu, hv);
+            }
+          }
+          sp = 0;
+          if (S.n_tris > 0) { if (j == 0) stk[0] = make_uint2(0u, 0u); sp = 1; }
+          has_ray = true; need = false;
+          if (STATS) st_rays += (j == 0);
+        }
+      }
+      chunk_pos += min(avail, n_need);
+      wave_lds_sync();
+    }
+    if (__ballot(has_ray) == 0) break;
+
+    // ---------------- one traversal step per group
+    bool is_node = false, is_leaf = false;
+    int ref = 0, cnt = 0;
+    if (has_ray && sp > 0) {
+      --sp;
+      const uint2 e = stk[sp];
+      if (!(__builtin_bit_cast(float, e.y) > best.t)) {
+        ref = (int)e.x >> 4; cnt = (int)e.x & 15;
+        is_node = (cnt == 0); is_leaf = !is_node;
+      }
+    }
+    if (is_node) {
+      const float4* nd = reinterpret_cast<const float4*>(S.nodes + (size_t)ref * kNodeFloats);
+      const float4 a = nd[j], b = nd[8 + j];
+      const int cref = __builtin_bit_cast(int, a.w), ccnt = __builtin_bit_cast(int, b.w);
+      const float t0x = (a.x - o.x) * inv.x, t1x = (b.x - o.x) * inv.x;
+      const float t0y = (a.y - o.y) * inv.y, t1y = (b.y - o.y) * inv.y;
+      const float t0z = (a.z - o.z) * inv.z, t1z = (b.z - o.z) * inv.z;
+      const float tmn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+      const float tmx = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best.t));
+      const bool hit = (cref >= 0) && (tmn <= tmx);
+      const int key = hit ? (int)((__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j) : 0x7fffffff;
+      const int rank = group_rank(key);
+      const int nh = __popcll((__ballot(hit) >> gbase) & 0xffull);
+      if (hit) stk[sp + (nh - 1 - rank)] = make_uint2((uint32_t)((cref << 4) | ccnt), __builtin_bit_cast(uint32_t, tmn));
+      sp += nh;
+      if (STATS) { st_box += (cref >= 0); st_node += (j == 0); }
+    }
+    if (is_leaf) {
+      float t = kInfinity, u = 0.0f, v = 0.0f; uint32_t key = KEY_MISS;
+      if (j < cnt) {
+        const float4* tr = reinterpret_cast<const float4*>(S.tris + (size_t)(ref + j) * kTriFloats);
+        const float4 q0 = tr[0], q1 = tr[1], q2 = tr[2];
+        float tt, uu, vv;
+        if (tri_raw(o, d, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x), tt, uu, vv) && tt > 0.0f && tt < 1000000.0f) {
+          t = tt; u = uu; v = vv; key = KEY_TRI | (uint32_t)__builtin_bit_cast(int, q2.y);
+        }
+      }
+      float mt = t; uint32_t mk = key;
+      group_min_tk(mt, mk);
+      if (mk != KEY_MISS && cand_wins(mt, mk, best)) {
+        // fetch the winner's barycentrics: exactly one lane of the group holds (mt, mk)
+        const bool mine = (key == mk);
+        const int src = gbase + (__ffsll((unsigned long long)((__ballot(mine) >> gbase) & 0xffull)) - 1);
+        best.t = mt; best.key = mk; best.u = __shfl(u, src); best.v = __shfl(v, src);
+      }
+      if (STATS) { st_tri += (j < cnt); st_leaf += (j == 0); }
+    }
+    wave_lds_sync();
+
+    // ---------------- retire finished rays
+    if (has_ray && sp == 0) {
+      if (j == 0) {
+        A.hit_t[ray] = best.t; A.hit_key[ray] = best.key; A.hit_u[ray] = best.u; A.hit_v[ray] = best.v;
+      }
+      has_ray = false;
+    }
+  }
+  if (STATS) {
+    atomicAdd(&A.stats[0], (unsigned long long)st_box); atomicAdd(&A.stats[1], (unsigned long long)st_tri);
+    atomicAdd(&A.stats[2], (unsigned long long)st_node); atomicAdd(&A.stats[3], (unsigned long long)st_leaf);
+    atomicAdd(&A.stats[4], (unsigned long long)st_rays);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// one ray per lane (cross-check / baseline)
+// ------------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_trace_simple(const DevScene S, const TraceArgs A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A.n_rays) return;
+  const float tfar = A.ray_tfar[i];
+  if (!(tfar >= 0.0f)) return;
+  BvhStats st = {0, 0, 0, 0};
+  const Cand c = closest_hit<STATS>(S, mk3(A.ray_ox[i], A.ray_oy[i], A.ray_oz[i]), mk3(A.ray_dx[i], A.ray_dy[i], A.ray_dz[i]), tfar, &st);
+  A.hit_t[i] = c.t; A.hit_key[i] = c.key; A.hit_u[i] = c.u; A.hit_v[i] = c.v;
+  if (STATS) {
+    atomicAdd(&A.stats[0], (unsigned long long)st.box_tests); atomicAdd(&A.stats[1], (unsigned long long)st.tri_tests);
+    atomicAdd(&A.stats[2], (unsigned long long)st.node_visits); atomicAdd(&A.stats[3], (unsigned long long)st.leaf_visits);
+    atomicAdd(&A.stats[4], 1ull);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wavefront stages
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_raygen(const DevFrame F, const DevScene S, const DevPaths Q) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot < Q.P) raygen_slot(F, S, Q, slot);
+}
+
+__global__ __launch_bounds__(256) void k_shade(const DevFrame F, const DevScene S, const DevPaths Q, int bounce, unsigned long long* ray_counter) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned int live = 0;
+  if (slot < Q.P) {
+    shade_slot(F, S, Q, slot, bounce);
+    live = (Q.ray_tfar[slot] >= 0.0f) + (Q.ray_tfar[(size_t)Q.P + slot] >= 0.0f);
+  }
+  // rays issued for the next trace launch (Mrays/s numerator), one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) live += __shfl_down(live, off);
+  if ((threadIdx.x & 63) == 0 && live) atomicAdd(ray_counter, (unsigned long long)live);
+}
+
+__global__ __launch_bounds__(256) void k_finish(const DevFrame F, const DevPaths Q, int last_level) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot < Q.P) finish_slot(F, Q, slot, last_level);
+}
+
+__global__ __launch_bounds__(256) void k_accumulate(const DevFrame F, const DevPaths Q, int samples_in_batch, float* accum) {
+  const int pl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pl < Q.npix) accumulate_pixel(F, Q, pl, samples_in_batch, accum);
+}
+
+__global__ __launch_bounds__(256) void k_resolve(const float* accum, int n_pixels, float norm_c, uint32_t* screen) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pixels) screen[i] = resolve_pixel(mk3(accum[3 * (size_t)i], accum[3 * (size_t)i + 1], accum[3 * (size_t)i + 2]), norm_c);
+}
+
+// Debug_Ray_Tracing (ray_tracer.adb:208-238): palette colour of the primary hit's matId, plus raw ids
+__global__ __launch_bounds__(256) void k_debug(const DevFrame F, const DevScene S, const DevPaths Q, float* accum,
+                                               int32_t* prim_index, int32_t* mat_id, int32_t* prim_type) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= Q.P) return;
+  uint32_t pixel, sample;
+  slot_to_sample(Q, slot, pixel, sample);
+  const uint32_t key = Q.hit_key[slot];
+  f3 col = mk3(0.0f, 0.0f, 0.0f);
+  int32_t pi = -1, mi = -1, pt = -1;
+  if (key != KEY_MISS) {
+    const f3 o = mk3(Q.ray_ox[slot], Q.ray_oy[slot], Q.ray_oz[slot]), d = mk3(Q.ray_dx[slot], Q.ray_dy[slot], Q.ray_dz[slot]);
+    const Surface sf = surface_at(S, o, d, Q.hit_t[slot], key, Q.hit_u[slot], Q.hit_v[slot]);
+    col = debug_palette(sf.mat_id);
+    mi = sf.mat_id; pi = (int32_t)(key & KEY_INDEX_MASK);
+    const uint32_t cls = key & ~KEY_INDEX_MASK;   // geometry.ads:55 Primitive'Pos: plane 0, sphere 1, triangle 2, quad 3
+    pt = (cls == KEY_CORNELL) ? 0 : (cls == KEY_SPHERE) ? 1 : (cls == KEY_QUAD) ? 3 : 2;
+  }
+  accum[3 * (size_t)pixel] = col.x; accum[3 * (size_t)pixel + 1] = col.y; accum[3 * (size_t)pixel + 2] = col.z;
+  if (prim_index) prim_index[pixel] = pi;
+  if (mat_id) mat_id[pixel] = mi;
+  if (prim_type) prim_type[pixel] = pt;
+}
+
+// layout conversion at the Ada seam: AccumBuff(x,y) / ScreenBufferData(x,y) are x-major (ray_tracer.ads:35,54)
+__global__ __launch_bounds__(256) void k_to_xmajor_f3(const float* src_rowmajor, float* dst_xmajor, int w, int h) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w * h) return;
+  const int x = i / h, y = i - x * h;
+  const size_t s = (size_t)y * w + x;
+  dst_xmajor[3 * (size_t)i] = src_rowmajor[3 * s]; dst_xmajor[3 * (size_t)i + 1] = src_rowmajor[3 * s + 1]; dst_xmajor[3 * (size_t)i + 2] = src_rowmajor[3 * s + 2];
+}
+__global__ __launch_bounds__(256) void k_to_xmajor_u32(const uint32_t* src_rowmajor, uint32_t* dst_xmajor, int w, int h) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w * h) return;
+  const int x = i / h, y = i - x * h;
+  dst_xmajor[i] = src_rowmajor[(size_t)y * w + x];
+}
+__global__ __launch_bounds__(256) void k_from_xmajor_f3(const float* src_xmajor, float* dst_rowmajor, int w, int h) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w * h) return;
+  const int x = i / h, y = i - x * h;
+  const size_t s = (size_t)y * w + x;
+  dst_rowmajor[3 * s] = src_xmajor[3 * (size_t)i]; dst_rowmajor[3 * s + 1] = src_xmajor[3 * (size_t)i + 1]; dst_rowmajor[3 * s + 2] = src_xmajor[3 * (size_t)i + 2];
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers (the only symbols art_api.cpp needs from this translation unit)
+// ------------------------------------------------------------------------------------------------
+static inline int blocks_for(int n) { return (n + 255) / 256; }
+
+void launch_raygen(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q) {
+  hipLaunchKernelGGL(k_raygen, dim3(blocks_for(Q.P)), dim3(256), 0, st, F, S, Q);
+}
+void launch_shade(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q, int bounce, unsigned long long* ray_counter) {
+  hipLaunchKernelGGL(k_shade, dim3(blocks_for(Q.P)), dim3(256), 0, st, F, S, Q, bounce, ray_counter);
+}
+void launch_finish(hipStream_t st, const DevFrame& F, const DevPaths& Q, int last_level) {
+  hipLaunchKernelGGL(k_finish, dim3(blocks_for(Q.P)), dim3(256), 0, st, F, Q, last_level);
+}
+void launch_accumulate(hipStream_t st, const DevFrame& F, const DevPaths& Q, int samples_in_batch, float* accum) {
+  hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(Q.npix)), dim3(256), 0, st, F, Q, samples_in_batch, accum);
+}
+void launch_resolve(hipStream_t st, const float* accum, int n_pixels, float norm_c, uint32_t* screen) {
+  hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n_pixels)), dim3(256), 0, st, accum, n_pixels, norm_c, screen);
+}
+void launch_debug(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q, float* accum, int32_t* prim_index, int32_t* mat_id, int32_t* prim_type) {
+  hipLaunchKernelGGL(k_debug, dim3(blocks_for(Q.P)), dim3(256), 0, st, F, S, Q, accum, prim_index, mat_id, prim_type);
+}
+void launch_to_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, int h) {
+  hipLaunchKernelGGL(k_to_xmajor_f3, dim3(blocks_for(w * h)), dim3(256), 0, st, src, dst, w, h);
+}
+void launch_to_xmajor_u32(hipStream_t st, const uint32_t* src, uint32_t* dst, int w, int h) {
+  hipLaunchKernelGGL(k_to_xmajor_u32, dim3(blocks_for(w * h)), dim3(256), 0, st, src, dst, w, h);
+}
+void launch_from_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, int h) {
+  hipLaunchKernelGGL(k_from_xmajor_f3, dim3(blocks_for(w * h)), dim3(256), 0, st, src, dst, w, h);
+}
+
+size_t trace_coop_lds_bytes(int stack_entries) { return (size_t)4 * 8 * (stack_entries + 1) * sizeof(uint2); }
+
+void launch_trace(hipStream_t st, const DevScene& S, const TraceArgs& A, int kernel, bool stats, int grid_blocks) {
+  if (kernel == TRACE_SIMPLE) {
+    if (stats) hipLaunchKernelGGL(k_trace_simple<true>, dim3(blocks_for(A.n_rays)), dim3(256), 0, st, S, A);
+    else hipLaunchKernelGGL(k_trace_simple<false>, dim3(blocks_for(A.n_rays)), dim3(256), 0, st, S, A);
+    return;
+  }
+  const size_t lds = trace_coop_lds_bytes(A.stack_entries);
+  if (stats) hipLaunchKernelGGL(k_trace_coop<true>, dim3(grid_blocks), dim3(256), lds, st, S, A);
+  else hipLaunchKernelGGL(k_trace_coop<false>, dim3(grid_blocks), dim3(256), lds, st, S, A);
+}
+
+}  // namespace art
+
+namespace art {
+int trace_coop_blocks_per_cu(int stack_entries) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_coop<false>, 256, trace_coop_lds_bytes(stack_entries)) != hipSuccess || nb < 1) nb = 1;
+  return nb;
+}
+}  // namespace art

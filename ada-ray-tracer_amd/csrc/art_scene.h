@@ -1,0 +1,101 @@
+// art_scene.h -- the flattened scene as the kernels see it (SoA / packed arrays resident in HBM),
+// plus the wavefront path-state arrays.  Mirrors scene.ads:61-80 / geometry.ads:15-111 /
+// materials.ads:58-130 / lights.ads:36-55 after flattening the tagged-type hierarchies into tables.
+#pragma once
+#include "art_math.h"
+
+namespace art {
+
+enum MatType : int32_t { MAT_NULL = 0, MAT_LIGHT = 1, MAT_LAMBERT = 2, MAT_MIRROR = 3, MAT_GLASS = 4, MAT_PHONG = 5 };
+enum LightShape : int32_t { LIGHT_RECT = 0, LIGHT_SPHERE = 1 };
+enum RenderType : int32_t { RT_DEBUG = 0, RT_WHITTED = 1, PT_STUPID = 2, PT_SHADOW = 3, PT_MIS = 4 };  // ray_tracer.ads:40
+
+// 40-byte material record: type tag + light back-reference + up to 8 parameters
+//  LAMBERT p0-2 kd | MIRROR p0-2 reflection | GLASS p0-2 reflection p3-5 transparency p6 ior | PHONG p0-2 reflection p3 cosPower
+struct DevMaterial { int32_t type; int32_t light; float p[8]; };
+
+struct DevLight {
+  int32_t shape; int32_t mat;
+  float boxMin[3], boxMax[3], normal[3];
+  float center[3], radius;
+  float intensity[3];
+  float surfaceArea;
+};
+
+struct DevSphere { float x, y, z, r; };
+
+// Hit key: (class << 28) | index.  Class order == candidate order of Scene.Find_Closest_Hit
+// (scene.adb:62-78: spheres, Cornell box, flat light, mesh) so that the reference's strict-'<' merge
+// is the lexicographic minimum over (t, key).
+constexpr uint32_t KEY_SPHERE = 0u << 28, KEY_CORNELL = 1u << 28, KEY_QUAD = 2u << 28, KEY_BFTRI = 3u << 28, KEY_TRI = 4u << 28;
+constexpr uint32_t KEY_MISS = 0x7fffffffu;
+constexpr uint32_t KEY_INDEX_MASK = (1u << 28) - 1u;
+
+// BVH8 node, 256 bytes = 64 floats, 256-byte aligned:
+//   half A (128 B): child j -> { lo.x, lo.y, lo.z, ref }      j = 0..7
+//   half B (128 B): child j -> { hi.x, hi.y, hi.z, count }
+//   ref = -1: empty slot.  count == 0: inner child, ref = node index.  count 1..8: leaf, ref = first
+//   triangle record.  Lane j of an 8-lane ray group loads exactly its 2 x 16 B; a group reads 2 x 128 B.
+// Triangle record, 48 bytes = 12 floats: A.xyz B.xyz C.xyz prim(int) pad pad   (prim = index in the caller's mesh)
+constexpr int kNodeFloats = 64;
+constexpr int kTriFloats = 12;
+constexpr int kMaxLeafTris = 8;
+constexpr int kStackEntries = 160;  // private stack of the one-ray-per-lane traversal; art_upload_scene rejects deeper trees
+
+struct DevScene {
+  int32_t n_spheres; const DevSphere* spheres; const int32_t* sphere_mat;
+  int32_t has_cornell;
+  float cb_min[3], cb_max[3];
+  int32_t cb_mat[6];
+  float cb_nrm[6][3];
+  int32_t n_lights; const DevLight* lights;
+  int32_t n_materials; const DevMaterial* materials;
+  // reference-semantics brute-force mesh (geometry.adb:266-323)
+  int32_t bf_ntris;
+  const float* bf_pos; const float* bf_nrm; const float* bf_uv; const int32_t* bf_idx;
+  float bf_bbmin[3], bf_bbmax[3];
+  // closest-hit mesh behind the BVH
+  int32_t n_tris; int32_t n_nodes;
+  const float* nodes; const float* tris;
+  const float* m_nrm; const float* m_uv; const int32_t* m_idx; const int32_t* m_matid;
+  // camera (scene.ads:27-32)
+  float cam_pos[3];
+  float cam_matrix[16];
+};
+
+struct DevFrame {
+  int32_t width, height;
+  int32_t render_type, aa_on, max_depth;
+  uint32_t seed_lo, seed_hi;
+  float background[3];
+  float cam_z;          // -float(width)/safe_tan(fov/2)   ray_tracer.adb:67 (computed once on the host)
+};
+
+// Wavefront state for a batch of P path slots (slot = local_sample * npix + local_pixel).  All SoA.
+struct DevPaths {
+  int32_t P;                    // slots in this batch
+  int32_t npix;                 // pixels owned by this device (shard)
+  const uint32_t* pixmap;       // local pixel -> global pixel index (y*width + x); nullptr = identity
+  uint32_t sample_base;         // global index of local sample 0
+  // rays: [0,P) extension rays, [P,2P) shadow rays.  tfar < 0 marks a dead / absent ray.
+  float* ray_ox; float* ray_oy; float* ray_oz;
+  float* ray_dx; float* ray_dy; float* ray_dz;
+  float* ray_tfar;
+  // hits, same indexing
+  float* hit_t; uint32_t* hit_key; float* hit_u; float* hit_v;
+  // per-path
+  float* prev_pdf;              // MatSample.pdf of the previous bounce
+  uint32_t* flags;              // bit0 alive, bit1 prev pureSpecular, bit2 shadow pending, bits 8.. levels recorded
+  float* sh_min_t;              // 10*epsilon of Compute_Shadow (ray_tracer.adb:122)
+  float* cand_r; float* cand_g; float* cand_b;   // explicit colour awaiting its shadow test
+  // inside-out fold stack: level k -> e_k (explicit), w_k (|cos| * bxdf)   integrators.adb:299
+  float* e_r; float* e_g; float* e_b;            // [max_depth][P]
+  float* w_r; float* w_g; float* w_b;
+  float* term_r; float* term_g; float* term_b;   // value returned by the deepest PathTrace call
+  // per-sample radiance, consumed by the accumulate kernel in the reference's summation order
+  float* rad_r; float* rad_g; float* rad_b;      // [samples_in_batch][npix]
+};
+
+constexpr uint32_t FLAG_ALIVE = 1u, FLAG_PREV_SPEC = 2u, FLAG_SHADOW_PENDING = 4u;
+
+}  // namespace art

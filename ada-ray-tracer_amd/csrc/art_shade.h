@@ -1,0 +1,502 @@
+// art_shade.h -- light sampling, BSDFs and one bounce of the three integrators, written per path slot
+// for the wavefront pipeline.  The reference recurses (ray_tracer-integrators.adb:82-301); here every
+// bounce records (e_k, w_k) and the final kernel folds them inside-out so the floating-point
+// association of  explicit + (|cos|*bxdf) * PathTrace(next)  (integrators.adb:299) is preserved.
+//   lights.adb:42-96 (rect), :101-266 (sphere)      materials.adb:18-99, :142-410
+//   vector_math.adb:175-326 (sampling helpers)      ray_tracer.adb:61-132 (camera rays, Compute_Shadow)
+#pragma once
+#include "art_isect.h"
+
+namespace art {
+
+constexpr float kGEpsilon = 1.0e-5f;      // ray_tracer.ads:29
+constexpr float kGEpsilonDiv = 1.0e-20f;  // ray_tracer.ads:30
+constexpr float kEpsDiv = 1.0e-20f;       // materials.adb:15 / lights.adb:39
+constexpr float kEpsCos = 1.0e-6f;        // materials.adb:16
+constexpr float kPhongClamp = 0x1.921eaep+0f;  // static M_PI*0.499995 (materials.adb:374)
+
+// ---------------------------------------------------------------- sampling helpers
+ART_HD f3 perpendicular(f3 a) {   // GetPerpendicular
+  const float xp = fabsf(a.x), yp = fabsf(a.y), zp = fabsf(a.z);
+  f3 least;
+  if ((xp <= yp + 1.0e-5f) && (xp <= zp + 1.0e-5f)) least = mk3(1.0f, 0.0f, 0.0f);
+  else if ((yp < xp + 1.0e-5f) && (yp <= zp + 1.0e-5f)) least = mk3(0.0f, 1.0f, 0.0f);
+  else least = mk3(0.0f, 0.0f, 1.0f);
+  return normalize(cross(a, least));
+}
+
+// shared tail of MapSampleToCosineDist / MapSampleToCosineDistFixed: local frame + under-surface fix-up
+ART_HD f3 lobe_to_world(f3 dev, f3 direction, f3 normal) {
+  f3 ny = direction;
+  f3 nx = perpendicular(ny);
+  f3 nz = normalize(cross(nx, ny));
+  { const f3 tmp = ny; ny = nz; nz = tmp; }
+  f3 res = (nx * dev.x + ny * dev.y) + nz * dev.z;
+  const float inv_sign = (dot(direction, normal) >= 0.0f) ? 1.0f : -1.0f;
+  if (inv_sign * dot(res, normal) < 0.0f) {
+    nx = normalize(cross(normal, direction));
+    nz = normalize(cross(nx, ny));
+    if (dot(nz, res) < 0.0f) nz = neg(nz);
+    res = reflect(neg(res), nz);
+    if (dot(res, normal) < 0.0f) res = direction;
+  }
+  return res;
+}
+
+ART_HD f3 sample_cosine(float r1, float r2, f3 direction, f3 normal, float power) {   // vector_math.adb:202-252
+  float sp, cp;
+  asincos_m1(2.0f * r1 * kPi, sp, cp);
+  const float ct = apow(1.0f - r2, 1.0f / (power + 1.0f));
+  const float st = sqrtf(1.0f - ct * ct);
+  return lobe_to_world(mk3(st * cp, st * sp, ct), direction, normal);
+}
+
+ART_HD f3 sample_cosine_fixed(float r1, float r2, f3 direction, f3 normal, float power) {   // vector_math.adb:255-312
+  const float h = sqrtf(1.0f - apow(r1, 2.0f / (power + 1.0f)));
+  float s2, c2;
+  asincos_m1((2.0f * kPi) * r2, s2, c2);
+  return lobe_to_world(mk3(h * c2, h * s2, apow(r1, 1.0f / (power + 1.0f))), direction, normal);
+}
+
+// ---------------------------------------------------------------- lights
+struct LightSample { f3 pos, dir, intensity; float pdf; };
+
+ART_HD float pdf_area_to_solid(float pdfA, float dist, float cos_there) {   // PdfAtoW
+  return pdfA * dist * dist / amax(cos_there, kEpsDiv);
+}
+
+ART_HD float dist2(f3 a, f3 b) { const f3 q = b - a; return dot(q, q); }
+
+ART_HD float sphere_light_pdf(const DevLight& l, f3 p) {   // SphereLight.EvalPDF
+  const f3 c = ld3(l.center);
+  if (dist2(p, c) - l.radius * l.radius < 1.0e-4f) return 1.0f / l.surfaceArea;
+  const float s2 = l.radius * l.radius / dist2(p, c);
+  const float cmax = sqrtf(amax(0.0f, 1.0f - s2));
+  return 1.0f / (2.0f * kPi * (1.0f - cmax));
+}
+
+ART_HD float light_eval_pdf(const DevLight& l, f3 p, f3 ray_dir, float hit_dist) {
+  if (l.shape == LIGHT_RECT) {
+    const float ct = amax(dot(ray_dir, neg(ld3(l.normal))), 0.0f);
+    return pdf_area_to_solid(1.0f / l.surfaceArea, hit_dist, ct);
+  }
+  return sphere_light_pdf(l, p);
+}
+
+ART_HD LightSample light_sample(const DevLight& l, float u1, float u2, f3 p) {
+  LightSample r;
+  r.pos = mk3(0.0f, 0.0f, 0.0f); r.dir = r.pos; r.pdf = 1.0f;
+  r.intensity = ld3(l.intensity);
+  if (l.shape == LIGHT_RECT) {                                   // AreaLight.Sample
+    r.pos.x = l.boxMin[0] + u1 * (l.boxMax[0] - l.boxMin[0]);
+    r.pos.y = l.boxMin[1];
+    r.pos.z = l.boxMin[2] + u2 * (l.boxMax[2] - l.boxMin[2]);
+    r.dir = ld3(l.normal);
+    f3 rd = r.pos - p;
+    const float dd = length(rd);
+    rd = rd * (1.0f / dd);
+    const float ct = amax(dot(rd, neg(ld3(l.normal))), 0.0f);
+    r.pdf = pdf_area_to_solid(1.0f / l.surfaceArea, dd, ct);
+    return r;
+  }
+  const f3 c = ld3(l.center);                                    // SphereLight.Sample
+  if (dist2(p, c) - l.radius * l.radius < 1.0e-4f) {
+    const float z = 1.0f - 2.0f * u1;                            // UniformSampleSphere
+    const float rr = sqrtf(amax(0.0f, 1.0f - z * z));
+    float sph, cph;
+    asincos_m1(2.0f * kPi * u2, sph, cph);
+    r.pos = c + l.radius * mk3(rr * cph, rr * sph, z);
+    r.dir = normalize(r.pos - c);
+    return r;                                                    // pdf stays 1.0 (lights.adb:210-214)
+  }
+  const f3 wc = normalize(c - p);
+  f3 wx, wy;                                                     // CoordinateSystem
+  if (fabsf(wc.x) > fabsf(wc.y)) {
+    const float il = 1.0f / sqrtf(wc.x * wc.x + wc.z * wc.z);
+    wx = mk3(-wc.z * il, 0.0f, wc.x * il);
+  } else {
+    const float il = 1.0f / sqrtf(wc.y * wc.y + wc.z * wc.z);
+    wx = mk3(0.0f, wc.z * il, -wc.y * il);
+  }
+  wy = cross(wc, wx);
+  const float s2 = l.radius * l.radius / dist2(p, c);
+  const float cmax = sqrtf(amax(0.0f, 1.0f - s2));
+  const float ct = alerp(u1, cmax, 1.0f);                        // UniformSampleCone
+  const float st = sqrtf(1.0f - ct * ct);
+  float sph, cph;
+  asincos_m1(u2 * 2.0f * kPi, sph, cph);
+  const f3 rdir = ((cph * st) * wx + (sph * st) * wy) + ct * wc;
+  const f3 rpos = p + rdir * 1.0e-3f;
+  float thit;
+  {                                                              // RaySphereIntersect
+    const f3 k = rpos - c;
+    const float b = dot(k, rdir);
+    const float cc = dot(k, k) - l.radius * l.radius;
+    const float disc = b * b - cc;
+    float hx;
+    if (disc >= 0.0f) { const float sq = sqrtf(disc); hx = amin(-b - sq, -b + sq); }
+    else hx = -kInfinity;
+    thit = (hx < 0.0f) ? dot(c - p, normalize(rdir)) : hx;
+  }
+  r.pos = rpos + thit * rdir;
+  r.dir = normalize(r.pos - c);
+  r.pdf = sphere_light_pdf(l, p);
+  return r;
+}
+
+// ---------------------------------------------------------------- materials
+struct BsdfSample { f3 color, dir; float pdf; bool specular; };
+
+ART_HD float fresnel_unpolarised(float cos1, float eta_ext_in, float eta_int_in) {   // materials.adb:70-99
+  float ext = eta_ext_in, in = eta_int_in;
+  if (cos1 < 0.0f) { const float tmp = ext; ext = in; in = tmp; }
+  const float sin2 = (ext / in) * sqrtf(amax(0.0f, 1.0f - cos1 * cos1));
+  if (sin2 > 1.0f) return 1.0f;
+  const float cos2 = sqrtf(amax(0.0f, 1.0f - sin2 * sin2));
+  const float c1 = fabsf(cos1);
+  // fresnelDielectric(cosTheta1 => |cos1|, cosTheta2, etaExt => in, etaInt => ext)
+  const float rs = (in * c1 - ext * cos2) / (in * c1 + ext * cos2);
+  const float rp = (ext * c1 - in * cos2) / (ext * c1 + in * cos2);
+  return (rs * rs + rp * rp) / 2.0f;
+}
+
+ART_HD BsdfSample bsdf_sample(const DevMaterial& m, float xi1, float xi2, f3 ray_dir, f3 n) {
+  BsdfSample r;
+  switch (m.type) {
+    case MAT_LAMBERT: {                                         // materials.adb:197-215
+      const f3 nd = sample_cosine(xi1, xi2, n, n, 1.0f);
+      const float ct = dot(nd, n);
+      r.pdf = fabsf(ct) * kInvPi;
+      r.color = ld3(m.p) * kInvPi;
+      if (ct < kEpsCos) r.color = mk3(0.0f, 0.0f, 0.0f);
+      r.dir = nd; r.specular = false;
+      return r;
+    }
+    case MAT_MIRROR: {                                          // :247-254
+      const f3 nd = reflect(ray_dir, n);
+      const float cdiv = 1.0f / amax(dot(nd, n), kEpsDiv);
+      r.color = ld3(m.p) * cdiv; r.dir = nd; r.pdf = 1.0f; r.specular = true;
+      return r;
+    }
+    case MAT_GLASS: {                                           // :285-331
+      const float ior = m.p[6];
+      const float f = fresnel_unpolarised(dot(ray_dir, n), ior, 1.0f);
+      const f3 refl = f * ld3(m.p);
+      const f3 trans = (1.0f - f) * ld3(m.p + 3);
+      const float k_trans = length(trans) / (length(refl) + length(trans));
+      const float k_refl = length(refl) / (length(refl) + length(trans));
+      f3 nd, bx;
+      if (xi1 > k_trans) {
+        nd = reflect(ray_dir, n);
+        bx = refl * (1.0f / k_refl);
+      } else {
+        bx = trans * (1.0f / k_trans);
+        float ci = dot(neg(ray_dir), n);                        // TotalInternalReflection :18-32
+        float eta = ior;
+        if (ci < 0.0f) eta = 1.0f / eta;
+        const bool tir = (1.0f - (1.0f - ci * ci) / (eta * eta)) < 0.0f;
+        if (!tir) {                                             // refract :34-52
+          f3 nn = n;
+          const f3 wo = neg(ray_dir);
+          if (ci < 0.0f) { ci = -ci; nn = neg(nn); }
+          const float c2 = sqrtf(1.0f - (1.0f - ci * ci) / (eta * eta));
+          nd = normalize((neg(wo) * (1.0f / eta)) - ((c2 - ci / eta) * nn));
+        } else nd = reflect(ray_dir, n);
+      }
+      const float cdiv = 1.0f / amax(fabsf(dot(nd, n)), kEpsDiv);
+      r.color = bx * cdiv; r.dir = nd; r.pdf = 1.0f; r.specular = true;
+      return r;
+    }
+    case MAT_PHONG: {                                           // :363-387
+      const float pw = m.p[3];
+      const f3 rr = reflect(ray_dir, n);
+      const f3 nd = sample_cosine_fixed(xi1, xi2, rr, n, pw);
+      const float ct = aclamp(dot(nd, rr), 0.0f, kPhongClamp);
+      const float lobe = apow(ct, pw);
+      f3 col = (((ld3(m.p) * (pw + 2.0f)) * 0.5f) * kInvPi) * lobe;
+      r.pdf = lobe * (pw + 1.0f) * (0.5f * kInvPi);
+      const float cg = dot(nd, n);
+      const float cdiv = 1.0f / amax(fabsf(cg), kEpsDiv);
+      if (cg < kEpsCos) col = mk3(0.0f, 0.0f, 0.0f);
+      r.color = col * cdiv; r.dir = nd; r.specular = false;
+      return r;
+    }
+    default:                                                    // MaterialLight :163-166
+      r.color = mk3(0.0f, 0.0f, 0.0f); r.dir = r.color; r.pdf = 1.0f; r.specular = false;
+      return r;
+  }
+}
+
+ART_HD void bsdf_eval(const DevMaterial& m, f3 l, f3 v, f3 n, f3& bxdf, float& pdf) {
+  switch (m.type) {
+    case MAT_LAMBERT:                                           // :217-226
+      bxdf = ld3(m.p) * kInvPi;
+      pdf = amax(dot(n, l), 0.0f) * kInvPi;
+      return;
+    case MAT_PHONG: {                                           // :389-410
+      const float pw = m.p[3];
+      const f3 rr = reflect(neg(v), n);
+      const float ct = aclamp(dot(l, rr), 0.0f, kPhongClamp);
+      const float lobe = apow(ct, pw);
+      const float cdiv = 1.0f / amax(dot(l, n), kEpsDiv);
+      bxdf = ((((ld3(m.p) * (pw + 2.0f)) * 0.5f) * kInvPi) * lobe) * cdiv;
+      pdf = lobe * (pw + 1.0f) * (0.5f * kInvPi);
+      return;
+    }
+    default:                                                    // light / mirror / glass
+      bxdf = mk3(0.0f, 0.0f, 0.0f); pdf = 1.0f;
+      return;
+  }
+}
+
+// ---------------------------------------------------------------- hit record -> shading frame
+struct Surface { f3 normal; int32_t mat; int32_t mat_id; };
+
+ART_HD Surface surface_at(const DevScene& s, f3 o, f3 d, float t, uint32_t key, float u, float v) {
+  Surface sf;
+  const uint32_t cls = key & ~KEY_INDEX_MASK, idx = key & KEY_INDEX_MASK;
+  if (cls == KEY_SPHERE) {                                      // geometry.adb:88,95-96
+    const DevSphere sp = s.spheres[idx];
+    sf.normal = normalize((o + d * t) - mk3(sp.x, sp.y, sp.z));
+    sf.mat = s.sphere_mat[idx]; sf.mat_id = 0;
+  } else if (cls == KEY_CORNELL) {                              // geometry.adb:215-224 + scene.adb:80-82
+    sf.normal = ld3(s.cb_nrm[idx]);
+    sf.mat_id = s.cb_mat[idx]; sf.mat = sf.mat_id;
+  } else if (cls == KEY_QUAD) {                                 // geometry.adb:132-141
+    sf.normal = mk3(0.0f, -1.0f, 0.0f);
+    sf.mat = s.lights[idx].mat; sf.mat_id = 0;
+  } else {
+    const bool bf = (cls == KEY_BFTRI);
+    const int32_t* ix = (bf ? s.bf_idx : s.m_idx) + 3 * (size_t)idx;
+    const float* nr = bf ? s.bf_nrm : s.m_nrm;
+    const float w = 1.0f - u - v;                               // geometry.adb:301
+    sf.normal = (w * ld3(nr + 3 * (size_t)ix[0]) + v * ld3(nr + 3 * (size_t)ix[1])) + u * ld3(nr + 3 * (size_t)ix[2]);
+    sf.mat_id = bf ? 2 : s.m_matid[idx];                        // geometry.adb:311 hard-codes 2
+    sf.mat = sf.mat_id;
+  }
+  return sf;
+}
+
+// ---------------------------------------------------------------- camera (ray_tracer.adb:61-97, integrators.adb:37-58)
+ART_HD void slot_to_sample(const DevPaths& q, int slot, uint32_t& pixel, uint32_t& sample) {
+  const int sl = slot / q.npix, pl = slot - sl * q.npix;
+  pixel = q.pixmap ? q.pixmap[pl] : (uint32_t)pl;
+  sample = q.sample_base + (uint32_t)sl;
+}
+
+ART_HD f3 camera_dir(const DevFrame& f, const DevScene& s, uint32_t pixel, uint32_t sample) {
+  const int x = (int)(pixel % (uint32_t)f.width), y = (int)(pixel / (uint32_t)f.width);
+  float ox = 0.5f, oy = 0.5f;
+  if (f.aa_on) {   // Generate4RayDirections: (1/3,1/3) (1/3,2/3) (2/3,1/3) (2/3,2/3)
+    ox = (sample & 2u) ? 0x1.555556p-1f : 0x1.555556p-2f;
+    oy = (sample & 1u) ? 0x1.555556p-1f : 0x1.555556p-2f;
+  }
+  f3 r;
+  r.x = (float)x + ox - ((float)f.width / 2.0f);
+  r.y = (float)y + oy - ((float)f.height / 2.0f);
+  r.z = f.cam_z;
+  return normalize(xform_point(s.cam_matrix, normalize(r)));
+}
+
+ART_HD void raygen_slot(const DevFrame& f, const DevScene& s, const DevPaths& q, int slot) {
+  uint32_t pixel, sample;
+  slot_to_sample(q, slot, pixel, sample);
+  const f3 d = camera_dir(f, s, pixel, sample);
+  q.ray_ox[slot] = s.cam_pos[0]; q.ray_oy[slot] = s.cam_pos[1]; q.ray_oz[slot] = s.cam_pos[2];
+  q.ray_dx[slot] = d.x; q.ray_dy[slot] = d.y; q.ray_dz[slot] = d.z;
+  q.ray_tfar[slot] = kInfinity;
+  q.ray_tfar[q.P + slot] = -1.0f;
+  q.prev_pdf[slot] = 1.0f;                         // StartSample (materials.ads:25)
+  q.flags[slot] = FLAG_ALIVE | FLAG_PREV_SPEC;
+  q.term_r[slot] = 0.0f; q.term_g[slot] = 0.0f; q.term_b[slot] = 0.0f;
+}
+
+// ---------------------------------------------------------------- one bounce
+ART_HD void kill_path(const DevPaths& q, int slot, uint32_t fl, int levels, f3 terminal) {
+  q.term_r[slot] = terminal.x; q.term_g[slot] = terminal.y; q.term_b[slot] = terminal.z;
+  q.flags[slot] = (fl & ~(FLAG_ALIVE | 0xffffff00u)) | ((uint32_t)levels << 8);
+  q.ray_tfar[slot] = -1.0f;
+}
+
+ART_HD void resolve_pending_shadow(const DevPaths& q, int slot, uint32_t& fl, int level) {
+  if (!(fl & FLAG_SHADOW_PENDING)) return;
+  const size_t si = (size_t)q.P + slot;
+  // Compute_Shadow: hit and t < maxDist - eps2 (enforced by the ray's tfar clip) and t > 10*eps
+  const bool in_shadow = (q.hit_key[si] != KEY_MISS) && (q.hit_t[si] > q.sh_min_t[slot]);
+  const size_t li = (size_t)level * q.P + slot;
+  q.e_r[li] = in_shadow ? 0.0f : q.cand_r[slot];
+  q.e_g[li] = in_shadow ? 0.0f : q.cand_g[slot];
+  q.e_b[li] = in_shadow ? 0.0f : q.cand_b[slot];
+  q.ray_tfar[si] = -1.0f;
+  fl &= ~FLAG_SHADOW_PENDING;
+}
+
+ART_HD void shade_slot(const DevFrame& f, const DevScene& s, const DevPaths& q, int slot, int bounce) {
+  uint32_t fl = q.flags[slot];
+  resolve_pending_shadow(q, slot, fl, bounce - 1);
+  if (!(fl & FLAG_ALIVE)) { q.flags[slot] = fl; return; }
+
+  const uint32_t key = q.hit_key[slot];
+  const f3 zero = mk3(0.0f, 0.0f, 0.0f);
+  if (key == KEY_MISS) { kill_path(q, slot, fl, bounce, zero); return; }            // integrators.adb:218-220
+
+  const f3 o = mk3(q.ray_ox[slot], q.ray_oy[slot], q.ray_oz[slot]);
+  const f3 d = mk3(q.ray_dx[slot], q.ray_dy[slot], q.ray_dz[slot]);
+  const float t = q.hit_t[slot];
+  const Surface sf = surface_at(s, o, d, t, key, q.hit_u[slot], q.hit_v[slot]);
+  if (sf.mat < 0 || sf.mat >= s.n_materials) { kill_path(q, slot, fl, bounce, zero); return; }
+  const DevMaterial m = s.materials[sf.mat];
+  if (m.type == MAT_NULL) { kill_path(q, slot, fl, bounce, zero); return; }
+  const f3 n = sf.normal;
+  const float sel_pdf = 1.0f / (float)s.n_lights;
+
+  if (m.type == MAT_LIGHT) {                                                         // :102-108 / :155-157 / :222-247
+    f3 out = zero;
+    if (f.render_type != PT_SHADOW && !(dot(neg(d), n) < 0.0f)) {
+      const f3 emit = (m.light >= 0 && m.light < s.n_lights) ? ld3(s.lights[m.light].intensity) : zero;
+      if (f.render_type == PT_STUPID) out = emit;
+      else {
+        float mis = 1.0f;
+        if (!(fl & FLAG_PREV_SPEC)) {
+          const float lp = light_eval_pdf(s.lights[m.light], o, d, t) * sel_pdf;
+          const float bp = q.prev_pdf[slot];
+          mis = bp * bp / (lp * lp + bp * bp);
+        }
+        out = emit * mis;
+      }
+    }
+    kill_path(q, slot, fl, bounce, out);
+    return;
+  }
+
+  uint32_t pixel, sample;
+  slot_to_sample(q, slot, pixel, sample);
+  const u4 rnd = philox4x32_10(pixel, sample, (uint32_t)bounce, 0u, f.seed_lo, f.seed_hi);
+  const f3 hpos = o + d * t;
+  const size_t li = (size_t)bounce * q.P + slot;
+
+  if (f.render_type != PT_STUPID) {                                                  // explicit light sampling :159-178 / :251-287
+    int light = 0;
+    if (s.n_lights > 1) {
+      const u4 r1 = philox4x32_10(pixel, sample, (uint32_t)bounce, 1u, f.seed_lo, f.seed_hi);
+      light = (int)(u01(r1.x) * (float)s.n_lights);
+      if (light > s.n_lights - 1) light = s.n_lights - 1;
+    }
+    const LightSample ls = light_sample(s.lights[light], u01(rnd.x), u01(rnd.y), hpos);
+    const f3 sdir = normalize(ls.pos - hpos);
+    const float lp = ls.pdf * sel_pdf;
+    f3 bx; float bp;
+    bsdf_eval(m, sdir, neg(d), n, bx, bp);
+    const float c1 = amax(dot(sdir, n), 0.0f);
+    f3 cand;
+    if (f.render_type == PT_MIS) {
+      const float mis = lp * lp / (lp * lp + bp * bp);
+      cand = ((ls.intensity * (1.0f / amax(lp, kGEpsilonDiv))) * (c1 * bx)) * mis;
+    } else {
+      cand = (ls.intensity * (c1 * bx)) * (1.0f / amax(lp, kGEpsilonDiv));
+    }
+    // Compute_Shadow (ray_tracer.adb:100-132): the closest hit of this ray decides visibility
+    float eps = amax3(fabsf(hpos.x), fabsf(hpos.y), fabsf(hpos.z)) * 0.000000001f;
+    eps = amax(eps, 1.0e-30f);
+    const f3 sd = normalize(ls.pos - hpos);
+    const f3 so = hpos + sd * eps;
+    const float max_dist = length(hpos - ls.pos);
+    const float eps2 = amax(max_dist * 0.000001f, 1.0e-30f);
+    const size_t si = (size_t)q.P + slot;
+    q.ray_ox[si] = so.x; q.ray_oy[si] = so.y; q.ray_oz[si] = so.z;
+    q.ray_dx[si] = sd.x; q.ray_dy[si] = sd.y; q.ray_dz[si] = sd.z;
+    // a NaN / negative bound can never be "in shadow": emit the ray with an empty interval
+    const float bound = max_dist - eps2;
+    q.ray_tfar[si] = (bound > 0.0f) ? bound : 0.0f;
+    q.sh_min_t[slot] = 10.0f * eps;
+    q.cand_r[slot] = cand.x; q.cand_g[slot] = cand.y; q.cand_b[slot] = cand.z;
+    fl |= FLAG_SHADOW_PENDING;
+  } else {
+    q.e_r[li] = 0.0f; q.e_g[li] = 0.0f; q.e_b[li] = 0.0f;
+  }
+
+  const BsdfSample bs = bsdf_sample(m, u01(rnd.z), u01(rnd.w), d, n);                // :116-124 / :183-191 / :291-299
+  const f3 bxv = bs.color * (1.0f / amax(bs.pdf, kGEpsilonDiv));
+  const float ct = dot(bs.dir, n);
+  const f3 no = hpos + (asign(ct) * n) * kGEpsilon;
+  const f3 w = fabsf(ct) * bxv;
+  q.w_r[li] = w.x; q.w_g[li] = w.y; q.w_b[li] = w.z;
+  q.prev_pdf[slot] = bs.pdf;
+  fl = bs.specular ? (fl | FLAG_PREV_SPEC) : (fl & ~FLAG_PREV_SPEC);
+
+  if (bounce + 1 >= f.max_depth) {                                                    // next level returns 0 untraced (:212-214)
+    kill_path(q, slot, fl, bounce + 1, zero);
+    return;
+  }
+  q.ray_ox[slot] = no.x; q.ray_oy[slot] = no.y; q.ray_oz[slot] = no.z;
+  q.ray_dx[slot] = bs.dir.x; q.ray_dy[slot] = bs.dir.y; q.ray_dz[slot] = bs.dir.z;
+  q.ray_tfar[slot] = kInfinity;
+  q.flags[slot] = fl;
+}
+
+// after the last trace: resolve the last shadow test and fold  L = e_k + w_k * L  from the deepest level out
+ART_HD void finish_slot(const DevFrame& f, const DevPaths& q, int slot, int last_level) {
+  uint32_t fl = q.flags[slot];
+  resolve_pending_shadow(q, slot, fl, last_level);
+  const int levels = (int)(fl >> 8);
+  f3 L = mk3(q.term_r[slot], q.term_g[slot], q.term_b[slot]);
+  for (int k = levels - 1; k >= 0; --k) {
+    const size_t li = (size_t)k * q.P + slot;
+    const f3 w = mk3(q.w_r[li], q.w_g[li], q.w_b[li]);
+    if (f.render_type == PT_STUPID) L = w * L;
+    else L = mk3(q.e_r[li], q.e_g[li], q.e_b[li]) + w * L;
+  }
+  q.rad_r[slot] = L.x; q.rad_g[slot] = L.y; q.rad_b[slot] = L.z;
+  q.flags[slot] = fl;
+}
+
+// DoPass accumulation (integrators.adb:42-52 / :60-64) for one local pixel, in sample order
+ART_HD void accumulate_pixel(const DevFrame& f, const DevPaths& q, int pl, int samples_in_batch, float* accum /* row-major rgb */) {
+  const uint32_t pixel = q.pixmap ? q.pixmap[pl] : (uint32_t)pl;
+  float* a = accum + 3 * (size_t)pixel;
+  f3 acc = mk3(a[0], a[1], a[2]);
+  if (f.aa_on) {
+    for (int t = 0; t + 3 < samples_in_batch; t += 4) {
+      f3 color = ld3(f.background);
+      for (int i = 0; i < 4; ++i) {
+        const size_t si = (size_t)(t + i) * q.npix + pl;
+        color = color + mk3(q.rad_r[si], q.rad_g[si], q.rad_b[si]);
+      }
+      acc = color + acc;
+    }
+  } else {
+    for (int t = 0; t < samples_in_batch; ++t) {
+      const size_t si = (size_t)t * q.npix + pl;
+      acc = mk3(q.rad_r[si], q.rad_g[si], q.rad_b[si]) + acc;
+    }
+  }
+  a[0] = acc.x; a[1] = acc.y; a[2] = acc.z;
+}
+
+// resolve (ray_tracer.adb:281-291, :19-57): gamma 2 -> clamp -> round-to-nearest pack R | G<<8 | B<<16
+ART_HD uint32_t ada_round_u32(float v) {
+  if (!(v > 0.0f)) return 0u;
+  uint32_t u = (uint32_t)v;
+  if (v - (float)u >= 0.5f) u += 1u;
+  return u;
+}
+
+ART_HD uint32_t resolve_pixel(f3 acc, float norm_c) {
+  f3 rgb = acc * norm_c;
+  rgb.x = apow(rgb.x, 1.0f / 2.0f); rgb.y = apow(rgb.y, 1.0f / 2.0f); rgb.z = apow(rgb.z, 1.0f / 2.0f);
+  const uint32_t r = ada_round_u32(amin(rgb.x, 1.0f) * 255.0f);
+  const uint32_t g = ada_round_u32(amin(rgb.y, 1.0f) * 255.0f);
+  const uint32_t b = ada_round_u32(amin(rgb.z, 1.0f) * 255.0f);
+  return r | (g << 8) | (b << 16);
+}
+
+ART_HD f3 debug_palette(int32_t mat_id) {   // ray_tracer.adb:210-211
+  switch (mat_id % 8) {
+    case 0: return mk3(0.5f, 0.0f, 0.0f);   case 1: return mk3(0.0f, 0.5f, 0.0f);
+    case 2: return mk3(0.0f, 0.0f, 0.5f);   case 3: return mk3(0.5f, 0.5f, 0.5f);
+    case 4: return mk3(0.5f, 0.5f, 0.0f);   case 5: return mk3(0.5f, 0.0f, 0.5f);
+    case 6: return mk3(0.0f, 0.5f, 0.5f);   default: return mk3(0.75f, 0.75f, 0.75f);
+  }
+}
+
+}  // namespace art

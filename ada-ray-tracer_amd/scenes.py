@@ -1,0 +1,112 @@
+"""Scene inputs for the backend: the material / light tables of the reference's internal scene
+(scene.adb:100-217) and the synthetic N-triangle generator of SURVEY 8(d) used by the benchmark configs
+C3 (100k triangles), C4 (1M) and C5 (mixed).  Pure numpy; everything is deterministic (SplitMix64)."""
+import numpy as np
+
+from . import (LIGHT_RECT, LIGHT_SPHERE, MAT_GLASS, MAT_LAMBERT, MAT_LIGHT, MAT_MIRROR, MAT_NULL, MAT_PHONG,
+               MESH_CLOSEST, SceneDesc)
+
+F = np.float32
+
+CORNELL_BOX = dict(min=(-2.5, 0.0, 0.0), max=(2.5, 5.0, 5.0), mat=(2, 3, 1, 1, 8, 1),            # scene.ads:75-80
+                   nrm=((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)))
+REFERENCE_CAMERA = (0.0, 2.55, 12.5)                                                               # scene.adb:212
+
+
+def cornell_materials():
+    """materials(0..10) of Init_Cornell_Box (scene.adb:155-180); 6 and 7 stay null."""
+    white = dict(type=MAT_LAMBERT, p=(0.5, 0.5, 0.5))
+    return [dict(type=MAT_GLASS, p=(0.75, 0.75, 0.75, 0.85, 0.85, 0.85, 1.75)),
+            white,
+            dict(type=MAT_LAMBERT, p=(0.25, 0.5, 0.0)),
+            dict(type=MAT_LAMBERT, p=(0.5, 0.0, 0.0)),
+            dict(type=MAT_LIGHT, light=0),
+            dict(type=MAT_MIRROR, p=(0.75, 0.75, 0.75)),
+            dict(type=MAT_NULL), dict(type=MAT_NULL),
+            dict(type=MAT_PHONG, p=(0.75, 0.75, 0.75, 80.0)),
+            white, white]
+
+
+def splitmix64(seed, n):
+    """n 64-bit outputs of SplitMix64 started at `seed` (vectorised)."""
+    with np.errstate(over="ignore"):
+        i = np.arange(1, n + 1, dtype=np.uint64)
+        z = np.uint64(seed) + i * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform01(seed, n):
+    return ((splitmix64(seed, n) >> np.uint64(40)).astype(np.float64) * 2.0 ** -24).astype(F)
+
+
+def random_triangles(n_tris, seed):
+    """De-indexed triangle soup inside the Cornell box: centre ~U([-2.3,2.3]x[0.2,4.6]x[0.2,4.8]), two edge vectors
+    ~U([-s,s]^3), s = 2.5 N^(-1/3); per-vertex normals = flat normal of the front face (cross(B-A, C-A))."""
+    u = uniform01(seed, 9 * n_tris).reshape(n_tris, 9)
+    lo = np.array([-2.3, 0.2, 0.2], F); hi = np.array([2.3, 4.6, 4.8], F)
+    c = lo + u[:, 0:3] * (hi - lo)
+    s = F(2.5 * n_tris ** (-1.0 / 3.0))
+    e1 = (u[:, 3:6] * F(2.0) - F(1.0)) * s
+    e2 = (u[:, 6:9] * F(2.0) - F(1.0)) * s
+    A = c; B = (c + e1).astype(F); Cc = (c + e2).astype(F)
+    n = np.cross(e1, e2).astype(F)
+    ln = np.sqrt((n * n).sum(1, keepdims=True)).astype(F)
+    n = np.where(ln > 0, n / np.maximum(ln, F(1e-30)), np.array([0, 1, 0], F)).astype(F)
+    pos = np.stack([A, B, Cc], 1).reshape(-1, 3).astype(F)
+    nrm = np.repeat(n, 3, axis=0).astype(F)
+    idx = np.arange(3 * n_tris, dtype=np.int32).reshape(-1, 3)
+    matid = (1 + (np.arange(n_tris) % 3)).astype(np.int32)          # white, green, red
+    return dict(mode=MESH_CLOSEST, pos=pos, nrm=nrm, idx=idx, matid=matid)
+
+
+def rect_light(cx, mat, intensity=(20.0, 20.0, 20.0), y=4.98, half_x=0.25, cz=2.25, half_z=0.33):
+    bmin = (F(cx - half_x), F(y), F(cz - half_z)); bmax = (F(cx + half_x), F(y), F(cz + half_z))
+    area = F(F(bmax[0] - bmin[0]) * F(bmax[2] - bmin[2]))
+    return dict(shape=LIGHT_RECT, mat=mat, boxMin=[float(v) for v in bmin], boxMax=[float(v) for v in bmax],
+                normal=(0.0, -1.0, 0.0), intensity=intensity, surfaceArea=float(area))
+
+
+def sphere_light(cx, mat, cy=4.5, cz=2.25, radius=0.25, intensity=(10.0, 10.0, 10.0)):
+    area = float(F(4.0) * F(np.pi) * F(radius) * F(radius))          # scene.adb:122
+    return dict(shape=LIGHT_SPHERE, mat=mat, center=(cx, cy, cz), radius=radius, intensity=intensity, surfaceArea=area)
+
+
+def synthetic_scene(n_tris, config_id=3, rect_lights=False):
+    """C3 / C4: Cornell walls + n_tris random triangles + 3 area lights, light choice uniform per bounce (an extension:
+    the reference has a single light, scene.adb:45-48).
+
+    Default lights are three SphereLights (lights.adb:101-266), radius 0.25 at y = 4.5, x in {-1.5, 0, 1.5}.
+    SURVEY 8(d) suggested rect AreaLights at y = 4.98; with PT_MIS those overflow in the reference's own arithmetic:
+    for any surface point at or above the light plane (the whole ceiling) AreaLight.Sample returns
+    pdf = d^2 / (A * 1e-20) (lights.adb:42-45,72-74), its square is +inf in binary32 and the MIS weight
+    inf/(inf+x) is NaN (integrators.adb:277-279) -- the accumulated pixel never recovers.  The backend reproduces that
+    bit-for-bit (tests/test_gpu_parity.py::test_rect_light_mis_nan_pattern_matches), but a benchmark image made of NaNs
+    is useless, so the rect variant is kept for parity tests only (rect_lights=True)."""
+    mats = cornell_materials()
+    mats[4] = dict(type=MAT_LIGHT, light=0)
+    mats.append(dict(type=MAT_LIGHT, light=1))     # 11
+    mats.append(dict(type=MAT_LIGHT, light=2))     # 12
+    mesh = random_triangles(n_tris, 0xADA5EED0 + config_id)
+    if rect_lights:
+        lights = [rect_light(-1.5, 4), rect_light(0.0, 11), rect_light(1.5, 12)]
+        spheres = []
+    else:
+        lights = [sphere_light(-1.5, 4), sphere_light(0.0, 11), sphere_light(1.5, 12)]
+        spheres = [(l["center"], l["radius"], l["mat"]) for l in lights]
+    return SceneDesc(spheres=spheres, lights=lights, materials=mats, meshes=[mesh], cornell=CORNELL_BOX, cam_pos=REFERENCE_CAMERA)
+
+
+def mixed_scene(n_tris=20000, config_id=5, extra_spheres=8):
+    """C5: spheres (Phong, glass, extra glass/diffuse) + emissive sphere light + a triangle mesh inside the Cornell box."""
+    mats = cornell_materials()
+    area = float(F(4.0) * F(np.pi) * F(0.5) * F(0.5))
+    lights = [dict(shape=LIGHT_SPHERE, mat=4, center=(0.0, 4.5, 1.0), radius=0.5, intensity=(10.0, 10.0, 10.0), surfaceArea=area)]
+    spheres = [((-1.5, 1.0, 1.5), 1.0, 8), ((1.4, 1.0, 3.0), 1.0, 0), ((0.0, 4.5, 1.0), 0.5, 4)]
+    u = uniform01(0xADA5EED0 + 100 + config_id, 3 * extra_spheres).reshape(-1, 3)
+    for i in range(extra_spheres):
+        p = (float(-2.0 + 4.0 * u[i, 0]), float(2.4 + 1.6 * u[i, 1]), float(0.6 + 3.6 * u[i, 2]))
+        spheres.append((p, 0.4, (0, 1, 2, 3)[i % 4]))
+    mesh = random_triangles(n_tris, 0xADA5EED0 + config_id)
+    return SceneDesc(spheres=spheres, lights=lights, materials=mats, meshes=[mesh], cornell=CORNELL_BOX, cam_pos=REFERENCE_CAMERA)

@@ -1,0 +1,186 @@
+/*
+ * art_hip.h -- C ABI of libart_hip.so, the MI355X (gfx950) render backend for FROL256/ada-ray-tracer.
+ *
+ * Plain C types only (Interfaces.C.int / float / unsigned, System.Address on the Ada side).
+ * Two groups of entry points:
+ *
+ *  1. Frame-level calls (art_*): what Ray_Tracer.Render_Pass (ray_tracer.adb:240-293) forwards to
+ *     instead of waking its Path_Trace_Thread tasks -- the per-pixel DoPass loop
+ *     (ray_tracer-integrators.adb:25-71), PathTrace x3 (integrators.adb:82-301),
+ *     Scene.Find_Closest_Hit (scene.adb:56-86), Compute_Shadow (ray_tracer.adb:100-132), the accum
+ *     and the gamma/tonemap/pack resolve (ray_tracer.adb:281-291) all run on the GPU.
+ *
+ *  2. The legacy geometry-core seam (gcore_*): the six symbols scene_hydra_embree.adb:37-66 imports
+ *     and cpp/embree_connect.cpp:51-244 defines on top of Embree 3.7.  Same names and return types;
+ *     counts are element counts (the reference passes 'Size in bits, scene_hydra_embree.adb:259-262).
+ *
+ * Error convention: art_* return 0 on success, non-zero on failure, text via art_last_error();
+ * nothing in this library calls exit() (embree_connect.cpp:28-49 does).  gcore_* keep the reference's
+ * return types (0 / false on failure).  The library has NO CPU fallback: without a usable HIP device
+ * every call that needs one fails with a message.
+ *
+ * Threading: art_* are single-caller (Render_Pass is only called from the environment task,
+ * test.adb:50); gcore_closest_hit may be called concurrently (it is in the reference, from up to 28
+ * tasks) and is serialised internally.
+ */
+#ifndef ART_HIP_H
+#define ART_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- flattened scene description (host pointers, copied during art_upload_scene) ------------- */
+
+/* materials.ads:58-130 flattened: type tag + parameters */
+enum { ART_MAT_NULL = 0, ART_MAT_LIGHT = 1, ART_MAT_LAMBERT = 2, ART_MAT_MIRROR = 3, ART_MAT_GLASS = 4, ART_MAT_PHONG = 5 };
+typedef struct ArtMaterial {
+  int32_t type;
+  int32_t light;     /* LIGHT: index into lights (MaterialLight.lref) */
+  float   p[8];      /* LAMBERT kd[3] | MIRROR reflection[3] | GLASS reflection[3] transparency[3] ior | PHONG reflection[3] cosPower */
+} ArtMaterial;
+
+/* lights.ads:36-55 */
+enum { ART_LIGHT_RECT = 0, ART_LIGHT_SPHERE = 1 };
+typedef struct ArtLight {
+  int32_t shape;
+  int32_t mat;       /* material-table index of the MaterialLight referring to this light */
+  float boxMin[3], boxMax[3], normal[3];   /* AreaLight   */
+  float center[3], radius;                 /* SphereLight */
+  float intensity[3];
+  float surfaceArea;
+} ArtLight;
+
+/* geometry.ads:21-25 */
+typedef struct ArtSphere { float pos[3]; float r; int32_t mat; } ArtSphere;
+
+/* geometry.ads:94-101.  mode selects the search semantics:
+ *   ART_MESH_REFERENCE_BF : IntersectMeshBF verbatim (geometry.adb:266-323: bbox early-out, index-order
+ *                           scan with the (t, t+1e-6) window, matId forced to 2) -- for the reference's own
+ *                           8-triangle pyramid; O(N) per ray.
+ *   ART_MESH_CLOSEST      : true closest hit through the BVH (the semantics Embree provides at
+ *                           gcore_closest_hit), reference Moeller-Trumbore arithmetic, material_ids honoured. */
+enum { ART_MESH_REFERENCE_BF = 0, ART_MESH_CLOSEST = 1 };
+typedef struct ArtMesh {
+  int32_t mode;
+  int32_t nverts, ntris;
+  const float*   pos;     /* 3*nverts, world space (LoadMeshFromVSGF transforms positions only) */
+  const float*   nrm;     /* 3*nverts */
+  const float*   uv;      /* 2*nverts, may be NULL (treated as zeros, geometry.adb:565-566) */
+  const int32_t* idx;     /* 3*ntris */
+  const int32_t* matid;   /* ntris (ignored in REFERENCE_BF mode) */
+  float bbmin[3], bbmax[3];   /* used by REFERENCE_BF (geometry.adb:273) */
+} ArtMesh;
+
+typedef struct ArtSceneDesc {
+  int32_t n_spheres;   const ArtSphere*   spheres;
+  int32_t has_cornell;                              /* scene.ads:75-80 */
+  float   cb_min[3], cb_max[3];
+  int32_t cb_mat[6];
+  float   cb_nrm[6][3];
+  int32_t n_lights;    const ArtLight*    lights;   /* the reference has exactly one (scene.adb:45-48) */
+  int32_t n_materials; const ArtMaterial* materials;
+  int32_t n_meshes;    const ArtMesh*     meshes;   /* at most one per mode */
+  float   cam_pos[3];                               /* scene.ads:27-32 */
+  float   cam_matrix[16];                           /* row-major float4x4 */
+} ArtSceneDesc;
+
+/* ---- render control --------------------------------------------------------------------------- */
+
+enum { ART_RT_DEBUG = 0, ART_RT_WHITTED = 1, ART_PT_STUPID = 2, ART_PT_SHADOW = 3, ART_PT_MIS = 4 };  /* ray_tracer.ads:40 */
+enum { ART_LAYOUT_ADA_XY = 0,   /* AccumBuff(x,y) / ScreenBufferData(x,y): element (x,y) at x*height + y (ray_tracer.ads:35,54) */
+       ART_LAYOUT_ROW_MAJOR = 1 /* element (x,y) at y*width + x (Bitmap.Image.data, test.adb:65) */ };
+
+/* the mutable package variables Render_Pass reads (ray_tracer.ads:20-32), passed per call */
+typedef struct ArtPassParams {
+  int32_t  render_type;     /* g_rend_type */
+  int32_t  aa_on;           /* Anti_Aliasing_On */
+  int32_t  max_depth;       /* Max_Trace_Depth, 1..16 */
+  int32_t  vthreads;        /* Threads_Num: the pass adds vthreads * (aa_on ? 4 : 1) samples per pixel */
+  float    background[3];   /* Background_Color */
+  uint64_t seed;            /* keys the counter-based RNG (replaces Float_Random.Reset, ray_tracer.adb:147) */
+  int32_t  layout;          /* layout of the host buffers handed to this call */
+} ArtPassParams;
+
+typedef struct ArtStats {
+  uint64_t rays;            /* closest-hit queries issued (camera + bounce + shadow), cumulative since art_resize */
+  uint64_t samples;         /* camera samples, cumulative */
+  double   trace_ms;        /* GPU time inside the trace kernel, cumulative (HIP events) */
+  double   pass_ms;         /* GPU time of whole passes (all kernels), cumulative */
+  uint64_t trace_launches;
+  uint64_t box_tests, tri_tests, node_visits, leaf_visits, traced_rays;  /* only filled by art_trace_rays(stats) / art_enable_counters */
+} ArtStats;
+
+typedef struct ArtHit {          /* geometry.ads:57-67 flattened */
+  float   t;
+  int32_t is_hit;
+  int32_t prim_type;             /* Primitive'Pos: 0 plane, 1 sphere, 2 triangle, 3 quad; -1 miss */
+  int32_t prim_index;
+  int32_t mat_id;
+  int32_t mat;
+  float   normal[3];
+  float   u, v;                  /* triangle barycentrics (weight of C, weight of B; geometry.adb:245-246) */
+} ArtHit;
+
+typedef struct ArtBvhInfo { int32_t n_nodes, n_tris, max_stack, reserved; double build_ms; } ArtBvhInfo;
+
+int  art_init(int device_ordinal);                       /* -1: keep the current HIP device */
+int  art_set_stream(void* hip_stream);                   /* hipStream_t; NULL = default stream */
+int  art_upload_scene(const ArtSceneDesc* scene);        /* Scene.Init: flatten + BVH build + copy to HBM */
+int  art_resize(int32_t width, int32_t height);          /* Resize_Viewport (ray_tracer.adb:297-320): zero accum, spp := 0 */
+int  art_set_shard(int32_t rank, int32_t nranks, int32_t tile);   /* pixel tiles (tile x tile) dealt round-robin over ranks */
+
+/* One Render_Pass.  accum_host (float3 per pixel) and screen_host (u32 per pixel) may be NULL; when given
+ * they receive the cumulative accum buffer and the resolved LDR image in p->layout.  *spp_inout is g_spp. */
+int  art_render_pass(const ArtPassParams* p, float* accum_host, uint32_t* screen_host, int32_t* spp_inout);
+
+/* Debug_Ray_Tracing + resolve (ray_tracer.adb:208-261).  All pointers optional. */
+int  art_debug_hit_pass(const ArtPassParams* p, float* accum_host, uint32_t* screen_host,
+                        int32_t* prim_index, int32_t* mat_id, int32_t* prim_type);
+
+/* device-resident variants for the multi-GPU harness: accumulate into caller-owned HBM (row-major float3),
+ * e.g. a buffer that is then reduced over xGMI with RCCL. */
+int  art_bind_accum(void* device_accum_rowmajor);        /* NULL: back to the internal buffer */
+void* art_accum_device(void);
+int  art_download(float* accum_host, uint32_t* screen_host, int32_t layout, int32_t spp);
+int  art_synchronize(void);
+
+/* Scene.Find_Closest_Hit for a list of rays (host arrays of 3*n floats; tfar may be NULL = unbounded).
+ * kernel: 0 = cooperative 8-lane kernel, 1 = one-ray-per-lane kernel.  stats may be NULL. */
+int  art_trace_rays(const float* origins, const float* dirs, const float* tfar, int64_t n,
+                    ArtHit* out, int32_t kernel, ArtStats* stats);
+
+int  art_export_bvh(float* nodes, int64_t node_floats_cap, float* tris, int64_t tri_floats_cap, ArtBvhInfo* info);
+int  art_get_stats(ArtStats* out);
+int  art_set_option(const char* name, int64_t value);    /* "trace_kernel", "batch_paths", "blocks_per_cu", "count_tests" */
+const char* art_last_error(void);
+void art_shutdown(void);
+
+/* ---- legacy geometry-core seam: embree_connect.cpp:51-244 / scene_hydra_embree.adb:37-66 -------- */
+
+typedef struct HitCpp {          /* embree_connect.cpp:186-194, 36 bytes */
+  int32_t primIndex;
+  int32_t geomIndex;
+  int32_t instIndex;
+  float   t;
+  float   normal[3];             /* unnormalised geometric normal Ng = cross(B-A, C-A) */
+  float   texCoord[2];           /* barycentrics u, v */
+} HitCpp;
+
+void gcore_init_and_clear(void);                                                       /* :60-67  */
+void gcore_destroy(void);                                                              /* :51-58  */
+int  gcore_add_mesh_3f(const float* a_vertices3f, int a_vertexNum, const int* a_indices, int a_indicesNum);  /* :69-144: returns mesh id, copies the data */
+void gcore_instance_meshes(int a_geomId, const float* a_matrices16f, int a_matrixNum); /* :147-184: 3x4 row-major taken from each 16-float block */
+void gcore_commit_scene(void);                                                         /* :241-244: BVH build + upload */
+#ifdef __cplusplus
+bool gcore_closest_hit(const float a_rayPos[3], const float a_rayDir[3], float t_near, float t_far, HitCpp* pHit);  /* :196-238 */
+#else
+_Bool gcore_closest_hit(const float a_rayPos[3], const float a_rayDir[3], float t_near, float t_far, HitCpp* pHit);
+#endif
+
+#ifdef __cplusplus
+}
+#endif
+#endif

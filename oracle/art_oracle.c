@@ -583,6 +583,8 @@ static float mat_eval_pdf(const orc_material* m, f3 l, f3 v, f3 n) {
 /* geometry.adb                                                                             */
 /* ======================================================================================== */
 
+static inline int32_t f2i(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
+
 typedef struct { f3 origin, direction; int x, y; } ray_t;                            /* geometry.ads:15-19 */
 
 enum { PRIM_PLANE = 0, PRIM_SPHERE = 1, PRIM_TRIANGLE = 2, PRIM_QUAD = 3 };          /* geometry.ads:55 */
@@ -713,7 +715,17 @@ static hit_t intersect_mesh_bf(const ray_t* r, const orc_mesh* m, uint64_t* tri_
  * (embree_connect.cpp:196-238) with the reference's Moeller-Trumbore arithmetic (geometry.adb:231-263)
  * and window (0, 1e6) (geometry.adb:277-278).  Ties: lowest triangle index.  matId from material_ids.
  * Hit record for the shader uses the interpolated vertex normal exactly like geometry.adb:301.       */
+static void bvh_walk_one(const float* nodes, const float* tris, const ray_t* r, float tfar,
+                         lite_hit* best, int32_t* best_prim, uint64_t* counters /* box, tri, node, leaf */);
+
 static hit_t intersect_mesh_closest(const ray_t* r, const orc_mesh* m, uint64_t* tri_tests) {
+  if (m->bvh_nodes && m->bvh_tris) {
+    lite_hit bh; int32_t prim = -1; uint64_t c[4] = { 0, 0, 0, 0 };
+    bvh_walk_one(m->bvh_nodes, m->bvh_tris, r, ORC_INFINITY, &bh, &prim, c);
+    *tri_tests += c[1];
+    if (prim < 0) return null_hit();
+    return mesh_hit_record(m, bh, prim, m->matid[prim]);
+  }
   lite_hit best; best.is_hit = 0; best.tmin = 0.0f; best.tmax = 0.0f; best.u = 0.0f; best.v = 0.0f;
   int bestId = 0;
   float best_t = 1000000.0f;
@@ -1170,7 +1182,57 @@ void orc_build_cornell(orc_cornell_storage* st, const orc_mesh* pyramid, int use
 /* Tri  = 12 floats: A.xyz B.xyz C.xyz prim(int bits) pad pad.                               */
 /* ======================================================================================== */
 
-static inline int32_t f2i(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
+static void bvh_walk_one(const float* nodes, const float* tris, const ray_t* rp, float tfar,
+                         lite_hit* best, int32_t* best_prim_out, uint64_t* counters) {
+  const ray_t r = *rp;
+  float idx = 1.0f / r.direction.x, idy = 1.0f / r.direction.y, idz = 1.0f / r.direction.z;
+  float best_t = tfar;
+  int32_t best_prim = -1;
+  lite_hit bh; bh.is_hit = 0; bh.tmin = 0.0f; bh.tmax = 0.0f; bh.u = 0.0f; bh.v = 0.0f;
+  struct { int32_t ref, cnt; float tmin; } stack[192];
+  int sp = 0;
+  stack[sp].ref = 0; stack[sp].cnt = 0; stack[sp].tmin = 0.0f; sp++;
+  while (sp > 0) {
+    --sp;
+    int32_t ref = stack[sp].ref, c = stack[sp].cnt; float etmin = stack[sp].tmin;
+    if (etmin > best_t) continue;
+    if (c == 0) {
+      const float* nd = nodes + (size_t)ref * 64;
+      uint32_t key[8]; int32_t cref[8], ccnt[8]; float ctm[8]; int nh = 0;
+      counters[2]++;
+      for (int j = 0; j < 8; ++j) {
+        int32_t rj = f2i(nd[4 * j + 3]);
+        if (rj < 0) continue;
+        counters[0]++;
+        float t0x = (nd[4 * j + 0] - r.origin.x) * idx, t1x = (nd[32 + 4 * j + 0] - r.origin.x) * idx;
+        float t0y = (nd[4 * j + 1] - r.origin.y) * idy, t1y = (nd[32 + 4 * j + 1] - r.origin.y) * idy;
+        float t0z = (nd[4 * j + 2] - r.origin.z) * idz, t1z = (nd[32 + 4 * j + 2] - r.origin.z) * idz;
+        float tmn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+        float tmx = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best_t));
+        if (tmn <= tmx) {
+          uint32_t kb; memcpy(&kb, &tmn, 4);
+          key[nh] = (kb & ~7u) | (uint32_t)j; cref[nh] = rj; ccnt[nh] = f2i(nd[32 + 4 * j + 3]); ctm[nh] = tmn; nh++;
+        }
+      }
+      for (int a = 1; a < nh; ++a) {              /* ascending insertion sort by key */
+        uint32_t k = key[a]; int32_t rr = cref[a], cc = ccnt[a]; float tt = ctm[a]; int b = a - 1;
+        while (b >= 0 && key[b] > k) { key[b + 1] = key[b]; cref[b + 1] = cref[b]; ccnt[b + 1] = ccnt[b]; ctm[b + 1] = ctm[b]; --b; }
+        key[b + 1] = k; cref[b + 1] = rr; ccnt[b + 1] = cc; ctm[b + 1] = tt;
+      }
+      for (int a = nh - 1; a >= 0; --a) { stack[sp].ref = cref[a]; stack[sp].cnt = ccnt[a]; stack[sp].tmin = ctm[a]; sp++; }   /* far-to-near */
+    } else {
+      counters[3]++;
+      for (int j = 0; j < c; ++j) {
+        const float* tr = tris + (size_t)(ref + j) * 12;
+        counters[1]++;
+        lite_hit h = intersect_triangle(&r, ld3(tr), ld3(tr + 3), ld3(tr + 6), 0.0f, 1000000.0f);
+        int32_t prim = f2i(tr[9]);
+        if (h.is_hit && (h.tmin < best_t || (h.tmin == best_t && best_prim >= 0 && prim < best_prim))) { best_t = h.tmin; best_prim = prim; bh = h; }
+      }
+    }
+  }
+  *best = bh; *best_prim_out = best_prim;
+}
 
 void orc_bvh_walk(const float* nodes, int32_t n_nodes, const float* tris, int32_t n_tris,
                   const float* origins, const float* dirs, const float* tfar, int64_t n,
@@ -1180,54 +1242,12 @@ void orc_bvh_walk(const float* nodes, int32_t n_nodes, const float* tris, int32_
 #pragma omp parallel for schedule(dynamic, 256) reduction(+ : boxes, tritests, nvis, lvis)
   for (int64_t i = 0; i < n; ++i) {
     ray_t r; r.x = 0; r.y = 0; r.origin = ld3(origins + 3 * i); r.direction = ld3(dirs + 3 * i);
-    float idx = 1.0f / r.direction.x, idy = 1.0f / r.direction.y, idz = 1.0f / r.direction.z;
-    float best_t = tfar ? tfar[i] : 1000000.0f;
-    int32_t best_prim = -1;
-    struct { int32_t ref, cnt; float tmin; } stack[128];
-    int sp = 0;
-    stack[sp].ref = 0; stack[sp].cnt = 0; stack[sp].tmin = 0.0f; sp++;
-    while (sp > 0) {
-      --sp;
-      int32_t ref = stack[sp].ref, c = stack[sp].cnt; float etmin = stack[sp].tmin;
-      if (etmin > best_t) continue;
-      if (c == 0) {
-        const float* nd = nodes + (size_t)ref * 64;
-        uint32_t key[8]; int32_t cref[8], ccnt[8]; float ctm[8]; int nh = 0;
-        nvis++;
-        for (int j = 0; j < 8; ++j) {
-          int32_t rj = f2i(nd[4 * j + 3]);
-          if (rj < 0) continue;
-          boxes++;
-          float t0x = (nd[4 * j + 0] - r.origin.x) * idx, t1x = (nd[32 + 4 * j + 0] - r.origin.x) * idx;
-          float t0y = (nd[4 * j + 1] - r.origin.y) * idy, t1y = (nd[32 + 4 * j + 1] - r.origin.y) * idy;
-          float t0z = (nd[4 * j + 2] - r.origin.z) * idz, t1z = (nd[32 + 4 * j + 2] - r.origin.z) * idz;
-          float tmn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
-          float tmx = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best_t));
-          if (tmn <= tmx) {
-            uint32_t kb; memcpy(&kb, &tmn, 4);
-            key[nh] = (kb & ~7u) | (uint32_t)j; cref[nh] = rj; ccnt[nh] = f2i(nd[32 + 4 * j + 3]); ctm[nh] = tmn; nh++;
-          }
-        }
-        /* push far-to-near so the nearest child is popped first (order by key) */
-        for (int a = 1; a < nh; ++a) {              /* insertion sort ascending by key */
-          uint32_t k = key[a]; int32_t rr = cref[a], cc = ccnt[a]; float tt = ctm[a]; int b = a - 1;
-          while (b >= 0 && key[b] > k) { key[b + 1] = key[b]; cref[b + 1] = cref[b]; ccnt[b + 1] = ccnt[b]; ctm[b + 1] = ctm[b]; --b; }
-          key[b + 1] = k; cref[b + 1] = rr; ccnt[b + 1] = cc; ctm[b + 1] = tt;
-        }
-        for (int a = nh - 1; a >= 0; --a) { stack[sp].ref = cref[a]; stack[sp].cnt = ccnt[a]; stack[sp].tmin = ctm[a]; sp++; }
-      } else {
-        lvis++;
-        for (int j = 0; j < c; ++j) {
-          const float* tr = tris + (size_t)(ref + j) * 12;
-          tritests++;
-          lite_hit h = intersect_triangle(&r, ld3(tr), ld3(tr + 3), ld3(tr + 6), 0.0f, 1000000.0f);
-          int32_t prim = f2i(tr[9]);
-          if (h.is_hit && (h.tmin < best_t || (h.tmin == best_t && best_prim >= 0 && prim < best_prim))) { best_t = h.tmin; best_prim = prim; }
-        }
-      }
-    }
-    if (out_t) out_t[i] = best_t;
-    if (out_prim) out_prim[i] = best_prim;
+    lite_hit bh; int32_t prim; uint64_t c[4] = { 0, 0, 0, 0 };
+    const float tf = tfar ? tfar[i] : ORC_INFINITY;   /* the product's unbounded rays start at Float'Last */
+    bvh_walk_one(nodes, tris, &r, tf, &bh, &prim, c);
+    boxes += c[0]; tritests += c[1]; nvis += c[2]; lvis += c[3];
+    if (out_t) out_t[i] = (prim >= 0) ? bh.tmin : tf;
+    if (out_prim) out_prim[i] = prim;
   }
   if (cnt) { cnt->rays += (uint64_t)n; cnt->box_tests += boxes; cnt->tri_tests += tritests; cnt->node_visits += nvis; cnt->leaf_visits += lvis; }
 }

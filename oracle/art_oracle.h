@@ -75,6 +75,10 @@ typedef struct {
   const int32_t* idx;     /* 3*ntris  */
   const int32_t* matid;   /* ntris    */
   float bbmin[3], bbmax[3];
+  /* optional (ORC_MESH_CLOSEST only): the product's exported BVH8 (orc_bvh_walk layout).  When set, the closest-hit
+   * search walks it instead of scanning all triangles -- same result (tests), used for the timed CPU baseline. */
+  const float* bvh_nodes;
+  const float* bvh_tris;
 } orc_mesh;
 
 typedef struct {

@@ -1,0 +1,93 @@
+// host_sim.cpp -- TEST-ONLY harness (never linked into libart_hip.so, never shipped): compiles the
+// product's host+device per-slot functions (csrc/art_shade.h, art_isect.h, art_math.h) with g++ and
+// drives the same wavefront schedule on CPU arrays.  The build container has no GPU, so this is how
+// the device logic is checked against the oracle before a GPU run; the GPU parity tests (-m gpu) go
+// through the real C ABI.  It is not a fallback: the product has no CPU path.
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../ada-ray-tracer_amd/csrc/art_host_scene.h"
+#include "../../ada-ray-tracer_amd/csrc/art_shade.h"
+
+using namespace art;
+
+static std::string g_err;
+
+extern "C" const char* hs_last_error() { return g_err.c_str(); }
+
+extern "C" int hs_trace(const ArtSceneDesc* sd, const float* o, const float* d, const float* tfar, long long n,
+                        ArtHit* out, unsigned long long* stats4) {
+  HostScene hs; BvhBuildParams bp;
+  if (!flatten_scene(*sd, bp, hs, g_err)) return 1;
+  bind_host_pointers(hs);
+  BvhStats st = {0, 0, 0, 0};
+  for (long long i = 0; i < n; ++i) {
+    const f3 oo = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), dd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    const Cand c = closest_hit<true>(hs.hdr, oo, dd, tfar ? tfar[i] : kInfinity, &st);
+    ArtHit& h = out[i];
+    h.t = c.t; h.u = c.u; h.v = c.v;
+    if (c.key == KEY_MISS) { h.is_hit = 0; h.prim_type = -1; h.prim_index = -1; h.mat_id = -1; h.mat = -1; h.normal[0] = h.normal[1] = h.normal[2] = 0; continue; }
+    const Surface sf = surface_at(hs.hdr, oo, dd, c.t, c.key, c.u, c.v);
+    const uint32_t cls = c.key & ~KEY_INDEX_MASK;
+    h.is_hit = 1; h.prim_index = (int32_t)(c.key & KEY_INDEX_MASK); h.mat_id = sf.mat_id; h.mat = sf.mat;
+    h.prim_type = (cls == KEY_CORNELL) ? 0 : (cls == KEY_SPHERE) ? 1 : (cls == KEY_QUAD) ? 3 : 2;
+    h.normal[0] = sf.normal.x; h.normal[1] = sf.normal.y; h.normal[2] = sf.normal.z;
+  }
+  if (stats4) { stats4[0] = st.box_tests; stats4[1] = st.tri_tests; stats4[2] = st.node_visits; stats4[3] = st.leaf_visits; }
+  return 0;
+}
+
+extern "C" int hs_render(const ArtSceneDesc* sd, const ArtPassParams* p, int w, int h, int spp0, float* accum /*row-major*/,
+                         unsigned long long* rays_out) {
+  HostScene hs; BvhBuildParams bp;
+  if (!flatten_scene(*sd, bp, hs, g_err)) return 1;
+  bind_host_pointers(hs);
+  DevFrame F; F.width = w; F.height = h; F.render_type = p->render_type; F.aa_on = p->aa_on ? 1 : 0; F.max_depth = p->max_depth;
+  F.seed_lo = (uint32_t)p->seed; F.seed_hi = (uint32_t)(p->seed >> 32); std::memcpy(F.background, p->background, 12);
+  F.cam_z = -(float)w / safe_tan(kHalfPi / 2.0f);
+  const int per = p->aa_on ? 4 : 1, S = p->vthreads * per, npix = w * h, P = npix * S, D = p->max_depth;
+  std::vector<float> buf((size_t)(14 + 8 + 3 + 3 + 6 * D + 3 + 3) * P, 0.0f);
+  DevPaths q; std::memset(&q, 0, sizeof q);
+  q.P = P; q.npix = npix; q.pixmap = nullptr; q.sample_base = (uint32_t)spp0;
+  float* f = buf.data(); const size_t pp = (size_t)P;
+  auto take = [&](size_t k) { float* r = f; f += k; return r; };
+  q.ray_ox = take(2 * pp); q.ray_oy = take(2 * pp); q.ray_oz = take(2 * pp); q.ray_dx = take(2 * pp); q.ray_dy = take(2 * pp); q.ray_dz = take(2 * pp); q.ray_tfar = take(2 * pp);
+  q.hit_t = take(2 * pp); q.hit_key = (uint32_t*)take(2 * pp); q.hit_u = take(2 * pp); q.hit_v = take(2 * pp);
+  q.prev_pdf = take(pp); q.flags = (uint32_t*)take(pp); q.sh_min_t = take(pp); q.cand_r = take(pp); q.cand_g = take(pp); q.cand_b = take(pp);
+  q.e_r = take(D * pp); q.e_g = take(D * pp); q.e_b = take(D * pp); q.w_r = take(D * pp); q.w_g = take(D * pp); q.w_b = take(D * pp);
+  q.term_r = take(pp); q.term_g = take(pp); q.term_b = take(pp); q.rad_r = take(pp); q.rad_g = take(pp); q.rad_b = take(pp);
+  unsigned long long rays = 0;
+  auto trace = [&](int nr) {
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : rays)
+    for (int i = 0; i < nr; ++i) {
+      if (!(q.ray_tfar[i] >= 0.0f)) continue;
+      rays++;
+      const Cand c = closest_hit<false>(hs.hdr, mk3(q.ray_ox[i], q.ray_oy[i], q.ray_oz[i]), mk3(q.ray_dx[i], q.ray_dy[i], q.ray_dz[i]), q.ray_tfar[i], nullptr);
+      q.hit_t[i] = c.t; q.hit_key[i] = c.key; q.hit_u[i] = c.u; q.hit_v[i] = c.v;
+    }
+  };
+#pragma omp parallel for
+  for (int s = 0; s < P; ++s) raygen_slot(F, hs.hdr, q, s);
+  for (int b = 0; b < D; ++b) {
+    trace(b == 0 ? P : 2 * P);
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int s = 0; s < P; ++s) shade_slot(F, hs.hdr, q, s, b);
+  }
+  if (p->render_type != ART_PT_STUPID) trace(2 * P);
+#pragma omp parallel for
+  for (int s = 0; s < P; ++s) finish_slot(F, q, s, D - 1);
+#pragma omp parallel for
+  for (int pl = 0; pl < npix; ++pl) accumulate_pixel(F, q, pl, S, accum);
+  if (rays_out) *rays_out = rays;
+  return 0;
+}
+
+// BVH of the scene's CLOSEST mesh in the product's packet layout (what art_export_bvh returns on the GPU box)
+extern "C" int hs_bvh(const ArtSceneDesc* sd, float* nodes, long long node_cap, float* tris, long long tri_cap, int* info3) {
+  HostScene hs; BvhBuildParams bp;
+  if (!flatten_scene(*sd, bp, hs, g_err)) return 1;
+  info3[0] = hs.bvh.n_nodes; info3[1] = hs.bvh.n_tris; info3[2] = hs.bvh.max_stack;
+  if (nodes) { if (node_cap < (long long)hs.bvh.nodes.size()) return 2; std::memcpy(nodes, hs.bvh.nodes.data(), hs.bvh.nodes.size() * 4); }
+  if (tris) { if (tri_cap < (long long)hs.bvh.tris.size()) return 2; std::memcpy(tris, hs.bvh.tris.data(), hs.bvh.tris.size() * 4); }
+  return 0;
+}

@@ -1,0 +1,55 @@
+"""ctypes binding of tests/host_sim/libhost_sim.so (TEST-ONLY CPU build of the product's per-slot device functions)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def lib(art):
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "host_sim")])
+        L = C.CDLL(os.path.join(HERE, "host_sim", "libhost_sim.so"))
+        L.hs_last_error.restype = C.c_char_p
+        L.hs_render.argtypes = [C.POINTER(art.ArtSceneDesc), C.POINTER(art.ArtPassParams), C.c_int, C.c_int, C.c_int, art.f32p, C.POINTER(C.c_uint64)]
+        L.hs_trace.argtypes = [C.POINTER(art.ArtSceneDesc), art.f32p, art.f32p, art.f32p, C.c_longlong, C.POINTER(art.ArtHit), C.POINTER(C.c_uint64)]
+        _lib = L
+    return _lib
+
+
+def render(art, sd, params, w, h, spp0=0, accum=None):
+    if accum is None:
+        accum = np.zeros((h, w, 3), np.float32)
+    rays = C.c_uint64(0)
+    rc = lib(art).hs_render(C.byref(sd.desc), C.byref(params), w, h, spp0, accum.ctypes.data_as(art.f32p), C.byref(rays))
+    if rc:
+        raise RuntimeError(lib(art).hs_last_error().decode())
+    return accum, rays.value
+
+
+def trace(art, sd, origins, dirs, tfar=None):
+    o = np.ascontiguousarray(origins, np.float32); d = np.ascontiguousarray(dirs, np.float32)
+    n = o.shape[0]
+    out = (art.ArtHit * n)()
+    st = (C.c_uint64 * 4)()
+    tf = None if tfar is None else np.ascontiguousarray(tfar, np.float32).ctypes.data_as(art.f32p)
+    rc = lib(art).hs_trace(C.byref(sd.desc), o.ctypes.data_as(art.f32p), d.ctypes.data_as(art.f32p), tf, n, out, st)
+    if rc:
+        raise RuntimeError(lib(art).hs_last_error().decode())
+    return out, [int(v) for v in st]
+
+
+def bvh(art, sd):
+    L = lib(art)
+    info = (C.c_int * 3)()
+    L.hs_bvh.argtypes = [C.POINTER(art.ArtSceneDesc), art.f32p, C.c_longlong, art.f32p, C.c_longlong, C.POINTER(C.c_int)]
+    if L.hs_bvh(C.byref(sd.desc), None, 0, None, 0, info):
+        raise RuntimeError(L.hs_last_error().decode())
+    nodes = np.zeros(info[0] * 64, np.float32); tris = np.zeros(info[1] * 12, np.float32)
+    if L.hs_bvh(C.byref(sd.desc), nodes.ctypes.data_as(art.f32p), nodes.size, tris.ctypes.data_as(art.f32p), tris.size, info):
+        raise RuntimeError("hs_bvh failed")
+    return nodes, tris, dict(n_nodes=info[0], n_tris=info[1], max_stack=info[2])

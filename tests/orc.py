@@ -41,7 +41,8 @@ class Sphere(C.Structure):
 class Mesh(C.Structure):
     _fields_ = [("mode", C.c_int32), ("nverts", C.c_int32), ("ntris", C.c_int32),
                 ("pos", f32p), ("nrm", f32p), ("uv", f32p), ("idx", i32p), ("matid", i32p),
-                ("bbmin", C.c_float * 3), ("bbmax", C.c_float * 3)]
+                ("bbmin", C.c_float * 3), ("bbmax", C.c_float * 3),
+                ("bvh_nodes", f32p), ("bvh_tris", f32p)]
 
 
 class Scene(C.Structure):
