@@ -34,9 +34,9 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def build_scene(art, args):
     from ada_ray_tracer_amd import scenes
     if args.scene == "c4":
-        return scenes.synthetic_scene(args.tris, 4), "C4: synthetic %d triangles + 3 rect lights in the Cornell box" % args.tris
+        return scenes.synthetic_scene(args.tris, 4), "C4: synthetic %d triangles + 3 sphere lights in the Cornell box" % args.tris
     if args.scene == "c3":
-        return scenes.synthetic_scene(100000, 3), "C3: synthetic 100000 triangles + 3 rect lights in the Cornell box"
+        return scenes.synthetic_scene(100000, 3), "C3: synthetic 100000 triangles + 3 sphere lights in the Cornell box"
     if args.scene == "c5":
         return scenes.mixed_scene(20000, 5), "C5: spheres + 20000-triangle mesh, glass/diffuse/emissive"
     import conv
