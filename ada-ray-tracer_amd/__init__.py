@@ -17,7 +17,7 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "libart_hip.so")
+LIB_PATH = os.environ.get("ART_LIB", os.path.join(PKG_DIR, "libart_hip.so"))   # ART_LIB: A/B builds of the same source
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)

@@ -92,6 +92,8 @@ static int upload_scene_arrays(HostScene& hs) {
   s.bf_pos = (const float*)c.b_bf_pos.p; s.bf_nrm = (const float*)c.b_bf_nrm.p; s.bf_uv = (const float*)c.b_bf_uv.p; s.bf_idx = (const int32_t*)c.b_bf_idx.p;
   s.nodes = (const float*)c.b_nodes.p; s.tris = (const float*)c.b_tris.p;
   s.m_nrm = (const float*)c.b_m_nrm.p; s.m_uv = (const float*)c.b_m_uv.p; s.m_idx = (const int32_t*)c.b_m_idx.p; s.m_matid = (const int32_t*)c.b_m_matid.p;
+  if (!c.d_scene) HIP_TRY(hipMalloc(&c.d_scene, sizeof(DevScene)));
+  HIP_TRY(hipMemcpy(c.d_scene, &s, sizeof(DevScene), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -173,9 +175,10 @@ static int coop_grid() {
 
 static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
   Ctx& c = g_ctx;
-  a.n_rays = n_rays; a.stack_entries = c.stack_entries;
+  a.n_rays = n_rays; a.stack_entries = c.stack_entries; a.leaf_min = c.leaf_min;
   a.ray_ox = q.ray_ox; a.ray_oy = q.ray_oy; a.ray_oz = q.ray_oz; a.ray_dx = q.ray_dx; a.ray_dy = q.ray_dy; a.ray_dz = q.ray_dz; a.ray_tfar = q.ray_tfar;
   a.hit_t = q.hit_t; a.hit_key = q.hit_key; a.hit_u = q.hit_u; a.hit_v = q.hit_v;
+  a.nodes = c.scene.nodes; a.tris = c.scene.tris; a.n_tris = c.scene.n_tris;
   a.cursor = c.d_cursor; a.stats = c.d_counters + 3;
 }
 
@@ -190,7 +193,7 @@ static int trace(const DevPaths& q, int n_rays) {
     c.ev_pool.push_back(e0); c.ev_pool.push_back(e1);
   }
   HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used], c.stream));
-  launch_trace(c.stream, c.scene, a, c.trace_kernel, c.count_tests, coop_grid());
+  launch_trace(c.stream, c.d_scene, a, c.trace_kernel, c.count_tests, coop_grid());
   HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used + 1], c.stream));
   c.ev_used += 2;
   HIP_TRY(hipGetLastError());
@@ -416,6 +419,7 @@ void shutdown() {
                       &c.b_pixmap, &c.b_paths, &c.b_rays, &c.b_ids};
     for (DevBuf* b : bufs) b->release();
     if (c.d_cursor) (void)hipFree(c.d_cursor);
+    if (c.d_scene) (void)hipFree(c.d_scene);
     if (c.d_counters) (void)hipFree(c.d_counters);
     for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : c.pass_events) (void)hipEventDestroy(e);
@@ -507,8 +511,10 @@ int art_set_option(const char* name, int64_t value) {
   else if (n == "batch_paths") { if (value < 1024) return fail("batch_paths too small"); g_ctx.batch_paths = value; }
   else if (n == "blocks_per_cu") { g_ctx.opt_blocks_per_cu = (int)value; g_ctx.blocks_per_cu = 0; }
   else if (n == "count_tests") { g_ctx.count_tests = value != 0; }
+  else if (n == "leaf_min") { if (value < 1 || value > 8) return fail("leaf_min: 1..8"); g_ctx.leaf_min = (int)value; }
   else if (n == "bvh_max_leaf") { if (value < 1 || value > kMaxLeafTris) return fail("bvh_max_leaf: 1..8"); g_ctx.bvh_params.max_leaf = (int)value; }
   else if (n == "bvh_leaf_base_milli") { g_ctx.bvh_params.leaf_base = (float)value / 1000.0f; }
+  else if (n == "bvh_tri_cost_milli") { g_ctx.bvh_params.tri_cost = (float)value / 1000.0f; }
   else if (n == "bvh_node_cost_milli") { g_ctx.bvh_params.node_cost = (float)value / 1000.0f; }
   else return fail("unknown option " + n);
   return 0;

@@ -20,6 +20,7 @@ struct Ctx {
   bool scene_ready = false;
   HostScene host_scene;
   DevScene scene;
+  DevScene* d_scene = nullptr;                 // the same header in HBM (the trace kernels take it by pointer)
   BvhBuildParams bvh_params;
   DevBuf b_spheres, b_sphere_mat, b_lights, b_materials, b_bf_pos, b_bf_nrm, b_bf_uv, b_bf_idx, b_nodes, b_tris, b_m_nrm, b_m_uv, b_m_idx, b_m_matid;
   int stack_entries = 8;
@@ -37,6 +38,7 @@ struct Ctx {
   int64_t batch_paths = 8ll << 20;
   int opt_blocks_per_cu = 0, blocks_per_cu = 0;
   bool count_tests = false;
+  int leaf_min = 3;
   // timing
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   std::vector<hipEvent_t> pass_events;

@@ -10,10 +10,12 @@ enum { TRACE_COOP = 0, TRACE_SIMPLE = 1 };
 struct TraceArgs {
   int32_t n_rays;
   int32_t stack_entries;        // per-ray-group LDS stack depth (>= Bvh8::max_stack)
+  int32_t leaf_min;             // a wave runs its leaf phase once this many of its 8 ray groups wait on a leaf
   const float* ray_ox; const float* ray_oy; const float* ray_oz;
   const float* ray_dx; const float* ray_dy; const float* ray_dz;
   const float* ray_tfar;        // < 0: skip
   float* hit_t; uint32_t* hit_key; float* hit_u; float* hit_v;
+  const float* nodes; const float* tris; int32_t n_tris;   // BVH of the closest-hit mesh (hot-loop operands)
   int* cursor;                  // work cursor, zeroed before every launch
   unsigned long long* stats;    // [box, tri, node, leaf, rays] when counting
 };
@@ -28,7 +30,7 @@ void launch_to_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, in
 void launch_to_xmajor_u32(hipStream_t st, const uint32_t* src, uint32_t* dst, int w, int h);
 void launch_from_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, int h);
 size_t trace_coop_lds_bytes(int stack_entries);
-void launch_trace(hipStream_t st, const DevScene& S, const TraceArgs& A, int kernel, bool stats, int grid_blocks);
+void launch_trace(hipStream_t st, const DevScene* d_scene, const TraceArgs& A, int kernel, bool stats, int grid_blocks);
 int  trace_coop_blocks_per_cu(int stack_entries);
 
 }  // namespace art

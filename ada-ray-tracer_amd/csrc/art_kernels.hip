@@ -49,7 +49,7 @@ __device__ __forceinline__ int group_rank(int key) {
   return r;
 }
 
-// lexicographic (t, key) minimum across the group; every lane ends with the winner
+// lexicographic (t, key) minimum across the group; every lane ends with the winner (float compares: handles -0.0)
 __device__ __forceinline__ void group_min_tk(float& t, uint32_t& key) {
   {
     const float ot = dpp_f<DPP_XOR1>(t); const uint32_t ok = (uint32_t)dpp_i<DPP_XOR1>((int)key);
@@ -65,6 +65,19 @@ __device__ __forceinline__ void group_min_tk(float& t, uint32_t& key) {
   }
 }
 
+// the same minimum for packed keys (bits(t) << 32 | key), t > 0: one 64-bit compare per butterfly step, no branches
+__device__ __forceinline__ uint64_t pack_tk(uint32_t tbits, uint32_t key) { return ((uint64_t)tbits << 32) | key; }
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v) {
+  return pack_tk((uint32_t)dpp_i<CTRL>((int)(v >> 32)), (uint32_t)dpp_i<CTRL>((int)(uint32_t)v));
+}
+__device__ __forceinline__ uint64_t group_min_u64(uint64_t k) {
+  uint64_t o = dpp_u64<DPP_XOR1>(k); k = (o < k) ? o : k;
+  o = dpp_u64<DPP_XOR2>(k); k = (o < k) ? o : k;
+  o = dpp_u64<DPP_XOR3>(dpp_u64<DPP_HALF_MIRROR>(k)); k = (o < k) ? o : k;
+  return k;
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -75,22 +88,33 @@ __device__ __forceinline__ void wave_lds_sync() {
 // cooperative persistent trace kernel
 // ------------------------------------------------------------------------------------------------
 constexpr int kChunk = 64;   // rays fetched per atomic
+#ifndef ART_COOP_WAVES_PER_SIMD
+#define ART_COOP_WAVES_PER_SIMD 8   // <= 64 VGPRs: 8 waves per SIMD = 256 rays in flight per CU
+#endif
+#ifndef ART_COOP_LEAF_MIN
+#define ART_COOP_LEAF_MIN 3          // a wave runs its leaf phase once this many of its 8 ray groups wait on a leaf
+#endif
 
 template <bool STATS>
-__global__ __launch_bounds__(256) void k_trace_coop(const DevScene S, const TraceArgs A) {
+__global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(const DevScene* __restrict__ Sp, const TraceArgs A) {
   extern __shared__ uint2 lds_stack[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 7, g = lane >> 3;
   const int gbase = lane & ~7;
   uint2* const stk = lds_stack + (size_t)(wave * 8 + g) * (A.stack_entries + 1);
   const uint64_t leaders = 0x0101010101010101ull;
+  const float4* const nodes4 = reinterpret_cast<const float4*>(A.nodes);   // kernel arguments: global address space
+  const float4* const tris4 = reinterpret_cast<const float4*>(A.tris);
+  const bool have_mesh = A.n_tris > 0;
 
   int chunk_pos = 0, chunk_end = 0;   // wave-uniform
   bool exhausted = false;             // wave-uniform
-  bool has_ray = false;               // group-uniform
-  int sp = 0, ray = 0;                // group-uniform
+  bool has_ray = false;               // group-uniform from here on
+  int sp = 0, ray = 0;
   f3 o = mk3(0, 0, 0), d = o, inv = o;
-  Cand best = cand_init(0.0f);
+  float best_t = 0.0f; uint32_t best_key = KEY_MISS;
+  uint32_t pend = 0; bool pend_valid = false;        // popped entry waiting for its phase
+  uint32_t held_key = KEY_MISS; float held_u = 0.0f, held_v = 0.0f;   // lane-local: barycentrics of the hit this lane found
   uint64_t st_box = 0, st_tri = 0, st_node = 0, st_leaf = 0, st_rays = 0;
 
   for (;;) {
@@ -114,7 +138,8 @@ __global__ __launch_bounds__(256) void k_trace_coop(const DevScene S, const Trac
         ray = chunk_pos + my_rank;
         const float tfar = A.ray_tfar[ray];
         if (tfar >= 0.0f) {
-          // ---- new live ray: load, intersect the analytic primitives (one per lane), seed the stack
+          // ---- new live ray: load, intersect the analytic primitives (one per lane), start at the BVH root
+          const DevScene& S = *Sp;
           o = mk3(A.ray_ox[ray], A.ray_oy[ray], A.ray_oz[ray]);
           d = mk3(A.ray_dx[ray], A.ray_dy[ray], A.ray_dz[ray]);
           inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -126,8 +151,9 @@ __global__ __launch_bounds__(256) void k_trace_coop(const DevScene S, const Trac
             else { const int li = it - S.n_spheres - 1; if (S.lights[li].shape == LIGHT_RECT) isect_quad(o, d, S.lights[li], (uint32_t)li, c); }
           }
           group_min_tk(c.t, c.key);
-          best = c; best.u = 0.0f; best.v = 0.0f;
+          Cand best = c; best.u = 0.0f; best.v = 0.0f;
           if (best.key == KEY_MISS) best.t = tfar;
+          held_key = KEY_MISS; held_u = 0.0f; held_v = 0.0f;
           if (S.bf_ntris > 0) {   // reference brute-force mesh: lanes test 8 triangles, the window scan runs in index order
             float b0, b1;
             if (slab_reference(o, d, S.bf_bbmin, S.bf_bbmax, b0, b1)) {
@@ -146,77 +172,100 @@ __global__ __launch_bounds__(256) void k_trace_coop(const DevScene S, const Trac
                   if (pk && tk > wmin && tk < wmax) { any = true; tri_id = (uint32_t)(base + k); ht = tk; hu = uk; hv = vk; wmin = tk; wmax = tk + 1.0e-6f; }
                 }
               }
-              if (any) cand_take(best, ht, KEY_BFTRI | tri_id, hu, hv);
+              if (any) {
+                cand_take(best, ht, KEY_BFTRI | tri_id, hu, hv);
+                if (best.key == (KEY_BFTRI | tri_id)) { held_key = best.key; held_u = hu; held_v = hv; }
+              }
             }
           }
-          sp = 0;
-          if (S.n_tris > 0) { if (j == 0) stk[0] = make_uint2(0u, 0u); sp = 1; }
+          best_t = best.t; best_key = best.key;
+          sp = 0; pend = 0u; pend_valid = have_mesh;      // entry 0 = root node
           has_ray = true; need = false;
           if (STATS) st_rays += (j == 0);
         }
       }
       chunk_pos += min(avail, n_need);
-      wave_lds_sync();
     }
     if (__ballot(has_ray) == 0) break;
 
-    // ---------------- one traversal step per group
-    bool is_node = false, is_leaf = false;
-    int ref = 0, cnt = 0;
-    if (has_ray && sp > 0) {
-      --sp;
-      const uint2 e = stk[sp];
-      if (!(__builtin_bit_cast(float, e.y) > best.t)) {
-        ref = (int)e.x >> 4; cnt = (int)e.x & 15;
-        is_node = (cnt == 0); is_leaf = !is_node;
+    // The step loop below is written branch-free on purpose: on CDNA a divergent `if` costs three scalar
+    // instructions (save/restore exec + skip branch) and the scalar unit issues at half the vector rate, so the
+    // first version of this kernel was SALU-bound.  Inactive lanes compute on clamped operands and are masked by
+    // selects; LDS pushes of non-hit lanes go to the group's spare (padding) slot.
+    uint2* const trash = stk + A.stack_entries;
+
+    // ---------------- next stack entry: up to two pops per iteration, entries culled by the current hit are dropped
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const bool need_pop = has_ray && !pend_valid && sp > 0;
+      sp -= need_pop ? 1 : 0;
+      const uint2 e = need_pop ? stk[sp] : *trash;
+      const bool ok = need_pop && !(__builtin_bit_cast(float, e.y) > best_t);
+      pend = ok ? e.x : pend;
+      pend_valid = pend_valid || ok;
+    }
+    // ---------------- retire rays whose stack ran dry
+    const bool done = has_ray && !pend_valid && sp == 0;
+    if (__ballot(done) != 0) {
+      if (done) {
+        const uint32_t cls = best_key & ~KEY_INDEX_MASK;
+        const bool tri_hit = (best_key != KEY_MISS) && (cls == KEY_TRI || cls == KEY_BFTRI);
+        if (j == 0) { A.hit_t[ray] = best_t; A.hit_key[ray] = best_key; }
+        if (tri_hit ? (held_key == best_key && (cls == KEY_TRI || j == 0)) : (j == 0)) {
+          A.hit_u[ray] = tri_hit ? held_u : 0.0f; A.hit_v[ray] = tri_hit ? held_v : 0.0f;
+        }
+        has_ray = false;
       }
     }
-    if (is_node) {
-      const float4* nd = reinterpret_cast<const float4*>(S.nodes + (size_t)ref * kNodeFloats);
-      const float4 a = nd[j], b = nd[8 + j];
-      const int cref = __builtin_bit_cast(int, a.w), ccnt = __builtin_bit_cast(int, b.w);
-      const float t0x = (a.x - o.x) * inv.x, t1x = (b.x - o.x) * inv.x;
-      const float t0y = (a.y - o.y) * inv.y, t1y = (b.y - o.y) * inv.y;
-      const float t0z = (a.z - o.z) * inv.z, t1z = (b.z - o.z) * inv.z;
+    // ---------------- vote: one phase per iteration for the whole wave
+    const int cnt = (int)(pend & 15u), ref = (int)(pend >> 4);
+    const bool want_leaf = has_ray && pend_valid && cnt != 0;
+    const bool want_node = has_ray && pend_valid && cnt == 0;
+    const uint64_t leaf_mask = __ballot(want_leaf), node_mask = __ballot(want_node);
+    if ((leaf_mask | node_mask) == 0) continue;
+    const bool do_leaf = (__popcll(leaf_mask) >= 8 * A.leaf_min) || (node_mask == 0);
+    if (!do_leaf) {
+      // ---- node phase: lane j slab-tests child j; groups not taking part read the root node and discard the result
+      const float4* nd = nodes4 + (size_t)(want_node ? ref : 0) * (kNodeFloats / 4) + j;
+      const float4 r0 = nd[0], r1 = nd[8];
+      const int cref = __builtin_bit_cast(int, r0.w), ccnt = __builtin_bit_cast(int, r1.w);
+      const float t0x = (r0.x - o.x) * inv.x, t1x = (r1.x - o.x) * inv.x;
+      const float t0y = (r0.y - o.y) * inv.y, t1y = (r1.y - o.y) * inv.y;
+      const float t0z = (r0.z - o.z) * inv.z, t1z = (r1.z - o.z) * inv.z;
       const float tmn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
-      const float tmx = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best.t));
-      const bool hit = (cref >= 0) && (tmn <= tmx);
+      const float tmx = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best_t));
+      const bool hit = want_node && (cref >= 0) && (tmn <= tmx);
       const int key = hit ? (int)((__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j) : 0x7fffffff;
       const int rank = group_rank(key);
       const int nh = __popcll((__ballot(hit) >> gbase) & 0xffull);
-      if (hit) stk[sp + (nh - 1 - rank)] = make_uint2((uint32_t)((cref << 4) | ccnt), __builtin_bit_cast(uint32_t, tmn));
+      uint2* const dst = hit ? (stk + sp + (nh - 1 - rank)) : trash;
+      *dst = make_uint2((uint32_t)((cref << 4) | ccnt), __builtin_bit_cast(uint32_t, tmn));
       sp += nh;
-      if (STATS) { st_box += (cref >= 0); st_node += (j == 0); }
-    }
-    if (is_leaf) {
-      float t = kInfinity, u = 0.0f, v = 0.0f; uint32_t key = KEY_MISS;
-      if (j < cnt) {
-        const float4* tr = reinterpret_cast<const float4*>(S.tris + (size_t)(ref + j) * kTriFloats);
-        const float4 q0 = tr[0], q1 = tr[1], q2 = tr[2];
-        float tt, uu, vv;
-        if (tri_raw(o, d, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x), tt, uu, vv) && tt > 0.0f && tt < 1000000.0f) {
-          t = tt; u = uu; v = vv; key = KEY_TRI | (uint32_t)__builtin_bit_cast(int, q2.y);
-        }
-      }
-      float mt = t; uint32_t mk = key;
-      group_min_tk(mt, mk);
-      if (mk != KEY_MISS && cand_wins(mt, mk, best)) {
-        // fetch the winner's barycentrics: exactly one lane of the group holds (mt, mk)
-        const bool mine = (key == mk);
-        const int src = gbase + (__ffsll((unsigned long long)((__ballot(mine) >> gbase) & 0xffull)) - 1);
-        best.t = mt; best.key = mk; best.u = __shfl(u, src); best.v = __shfl(v, src);
-      }
-      if (STATS) { st_tri += (j < cnt); st_leaf += (j == 0); }
+      pend_valid = pend_valid && !want_node;
+      if (STATS) { st_box += (want_node && cref >= 0); st_node += (want_node && j == 0); }
+    } else {
+      // ---- leaf phase: lane j < cnt tests triangle j of the leaf; everybody else tests triangle 0 and is masked out
+      const bool tri_lane = want_leaf && (j < cnt);
+      const float4* tr = tris4 + (size_t)(tri_lane ? (ref + j) : 0) * (kTriFloats / 4);
+      const float4 q0 = tr[0], q1 = tr[1], q2 = tr[2];
+      float tt, uu, vv;
+      const bool pass = tri_raw(o, d, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x), tt, uu, vv);
+      const bool valid = tri_lane && pass && (tt > 0.0f) && (tt < 1000000.0f);
+      const uint32_t tb = valid ? __builtin_bit_cast(uint32_t, tt) : 0x7f7fffffu;
+      const uint32_t key = valid ? (KEY_TRI | (uint32_t)__builtin_bit_cast(int, q2.y)) : KEY_MISS;
+      const uint64_t win = group_min_u64(pack_tk(tb, key));
+      // cand_wins for t > 0:  (t, key) < (best_t, best_key), where an equal t never displaces the initial bound
+      const uint32_t bt = (best_t == 0.0f) ? 0u : __builtin_bit_cast(uint32_t, best_t);
+      const uint64_t cur = pack_tk(bt, best_key == KEY_MISS ? 0u : best_key);
+      const bool accept = want_leaf && ((uint32_t)win != KEY_MISS) && (win < cur);
+      best_t = accept ? __builtin_bit_cast(float, (uint32_t)(win >> 32)) : best_t;
+      best_key = accept ? (uint32_t)win : best_key;
+      const bool mine = accept && valid && (key == (uint32_t)win);
+      held_key = mine ? key : held_key; held_u = mine ? uu : held_u; held_v = mine ? vv : held_v;
+      pend_valid = pend_valid && !want_leaf;
+      if (STATS) { st_tri += tri_lane; st_leaf += (want_leaf && j == 0); }
     }
     wave_lds_sync();
-
-    // ---------------- retire finished rays
-    if (has_ray && sp == 0) {
-      if (j == 0) {
-        A.hit_t[ray] = best.t; A.hit_key[ray] = best.key; A.hit_u[ray] = best.u; A.hit_v[ray] = best.v;
-      }
-      has_ray = false;
-    }
   }
   if (STATS) {
     atomicAdd(&A.stats[0], (unsigned long long)st_box); atomicAdd(&A.stats[1], (unsigned long long)st_tri);
@@ -229,7 +278,8 @@ __global__ __launch_bounds__(256) void k_trace_coop(const DevScene S, const Trac
 // one ray per lane (cross-check / baseline)
 // ------------------------------------------------------------------------------------------------
 template <bool STATS>
-__global__ __launch_bounds__(256) void k_trace_simple(const DevScene S, const TraceArgs A) {
+__global__ __launch_bounds__(256) void k_trace_simple(const DevScene* __restrict__ Sp, const TraceArgs A) {
+  const DevScene& S = *Sp;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= A.n_rays) return;
   const float tfar = A.ray_tfar[i];
@@ -360,7 +410,7 @@ void launch_from_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, 
 
 size_t trace_coop_lds_bytes(int stack_entries) { return (size_t)4 * 8 * (stack_entries + 1) * sizeof(uint2); }
 
-void launch_trace(hipStream_t st, const DevScene& S, const TraceArgs& A, int kernel, bool stats, int grid_blocks) {
+void launch_trace(hipStream_t st, const DevScene* S, const TraceArgs& A, int kernel, bool stats, int grid_blocks) {
   if (kernel == TRACE_SIMPLE) {
     if (stats) hipLaunchKernelGGL(k_trace_simple<true>, dim3(blocks_for(A.n_rays)), dim3(256), 0, st, S, A);
     else hipLaunchKernelGGL(k_trace_simple<false>, dim3(blocks_for(A.n_rays)), dim3(256), 0, st, S, A);

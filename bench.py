@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--cpu-width", type=int, default=480)
     ap.add_argument("--cpu-height", type=int, default=270)
     ap.add_argument("--no-counters", action="store_true", help="skip the untimed B/T counting pass")
+    ap.add_argument("--opt", action="append", default=[], help="backend option name=value (art_set_option), e.g. bvh_leaf_base_milli=1000")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,6 +106,9 @@ def main():
     be = art.Backend(local_rank if world > 1 else 0)
     args._backend = be
     be.set_option("trace_kernel", art.TRACE_COOP if args.kernel == "coop" else art.TRACE_SIMPLE)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        be.set_option(k, int(v))
 
     t0 = time.time()
     sd, scene_name = build_scene(art, args)
@@ -171,12 +175,15 @@ def main():
             n = max(1, c1.traced_rays - c0.traced_rays)
             B = (c1.box_tests - c0.box_tests) / n
             T = (c1.tri_tests - c0.tri_tests) / n
+            NV = (c1.node_visits - c0.node_visits) / n
+            LV = (c1.leaf_visits - c0.leaf_visits) / n
             bytes_per_ray = 32.0 * B + 48.0 * T + 64.0
             achieved = rays * bytes_per_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
             roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                         "kernel": "k_trace_coop" if args.kernel == "coop" else "k_trace_simple",
                         "bytes_per_ray": round(bytes_per_ray, 1), "box_tests_per_ray": round(B, 2), "tri_tests_per_ray": round(T, 2),
+                        "node_visits_per_ray": round(NV, 2), "leaf_visits_per_ray": round(LV, 2),
                         "avg_launch_ms": round(trace_ms / max(1, launches), 4), "launches": int(launches),
                         "trace_Mrays_per_s": round(rays / (trace_ms * 1e-3) / 1e6, 2) if trace_ms > 0 else None}
         cpu = None
