@@ -69,9 +69,9 @@ int ensure_device() {
   HIP_TRY(hipGetDeviceProperties(&prop, c.device));
   c.num_cus = prop.multiProcessorCount;
   c.arch = prop.gcnArchName;
-  HIP_TRY(hipMalloc(&c.d_cursor, sizeof(int)));
-  HIP_TRY(hipMalloc(&c.d_counters, 8 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemset(c.d_counters, 0, 8 * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(&c.d_cursor, 2 * sizeof(int)));   // [0] work cursor, [1] live-ray queue length
+  HIP_TRY(hipMalloc(&c.d_counters, 16 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(c.d_counters, 0, 16 * sizeof(unsigned long long)));
   c.device_ready = true;
   return 0;
 }
@@ -104,6 +104,8 @@ int upload_scene(const ArtSceneDesc* d) {
   std::string err;
   HostScene hs;
   if (!flatten_scene(*d, c.bvh_params, hs, err)) return fail(err);
+  if ((uint64_t)hs.bvh.n_nodes * kNodeFloats * 4 >= (1ull << 32) || (uint64_t)hs.bvh.n_tris * kTriFloats * 4 >= (1ull << 32))
+    return fail("mesh too large: the trace kernel addresses nodes and triangles with 32-bit byte offsets (max ~89M triangles)");
   if (hs.bvh.max_stack > kStackEntries) return fail("BVH traversal stack bound " + std::to_string(hs.bvh.max_stack) + " exceeds " + std::to_string(kStackEntries));
   if (upload_scene_arrays(hs)) return 1;
   c.stack_entries = std::max(8, hs.bvh.max_stack);
@@ -142,7 +144,7 @@ int resize(int w, int h) {
   c.spp = 0;
   c.stats = ArtStats();
   c.camera_rays = 0;
-  HIP_TRY(hipMemsetAsync(c.d_counters, 0, 8 * sizeof(unsigned long long), c.stream));
+  HIP_TRY(hipMemsetAsync(c.d_counters, 0, 16 * sizeof(unsigned long long), c.stream));
   return build_shard();
 }
 
@@ -179,14 +181,19 @@ static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
   a.ray_ox = q.ray_ox; a.ray_oy = q.ray_oy; a.ray_oz = q.ray_oz; a.ray_dx = q.ray_dx; a.ray_dy = q.ray_dy; a.ray_dz = q.ray_dz; a.ray_tfar = q.ray_tfar;
   a.hit_t = q.hit_t; a.hit_key = q.hit_key; a.hit_u = q.hit_u; a.hit_v = q.hit_v;
   a.nodes = c.scene.nodes; a.tris = c.scene.tris; a.n_tris = c.scene.n_tris;
+  a.sh_min = (c.shadow_anyhit && q.sh_min_t && n_rays > q.P) ? q.sh_min_t : nullptr; a.shadow_begin = q.P;
   a.cursor = c.d_cursor; a.stats = c.d_counters + 3;
+  a.queue = (int*)c.b_queue.p; a.queue_count = c.d_cursor + 1;
 }
 
 // one trace launch, bracketed by HIP events on the launch stream
 static int trace(const DevPaths& q, int n_rays) {
   Ctx& c = g_ctx;
+  if (c.trace_kernel == TRACE_COOP && ensure(c.b_queue, (size_t)n_rays * sizeof(int))) return 1;
   TraceArgs a; fill_trace_args(a, q, n_rays);
-  if (c.trace_kernel == TRACE_COOP) HIP_TRY(hipMemsetAsync(c.d_cursor, 0, sizeof(int), c.stream));
+  if (c.trace_kernel == TRACE_COOP) {
+    HIP_TRY(hipMemsetAsync(c.d_cursor, 0, 2 * sizeof(int), c.stream));
+  }
   if (c.ev_pool.size() < c.ev_used + 2) {
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -209,8 +216,9 @@ static int collect_timing() {
     c.stats.trace_ms += ms; c.stats.trace_launches += 1;
   }
   c.ev_used = 0;
-  unsigned long long cnt[8];
+  unsigned long long cnt[16];
   HIP_TRY(hipMemcpy(cnt, c.d_counters, sizeof cnt, hipMemcpyDeviceToHost));
+  c.stats.node_phase_iters = cnt[8]; c.stats.leaf_phase_iters = cnt[9]; c.stats.wave_iters = cnt[10];
   c.stats.rays = c.camera_rays + cnt[0];
   c.stats.box_tests = cnt[3]; c.stats.tri_tests = cnt[4]; c.stats.node_visits = cnt[5]; c.stats.leaf_visits = cnt[6]; c.stats.traced_rays = cnt[7];
   return 0;
@@ -378,7 +386,7 @@ int trace_rays(const float* origins, const float* dirs, const float* tfar, int64
   float* d = (float*)c.b_rays.p;
   HIP_TRY(hipMemcpyAsync(d, soa.data(), 7 * N * 4, hipMemcpyHostToDevice, c.stream));
   HIP_TRY(hipMemsetAsync(d + 7 * N, 0xff, 4 * N * 4, c.stream));
-  HIP_TRY(hipMemsetAsync(c.d_counters + 3, 0, 5 * sizeof(unsigned long long), c.stream));
+  HIP_TRY(hipMemsetAsync(c.d_counters + 3, 0, 8 * sizeof(unsigned long long), c.stream));
   DevPaths q; std::memset(&q, 0, sizeof q);
   q.ray_ox = d; q.ray_oy = d + N; q.ray_oz = d + 2 * N; q.ray_dx = d + 3 * N; q.ray_dy = d + 4 * N; q.ray_dz = d + 5 * N; q.ray_tfar = d + 6 * N;
   q.hit_t = d + 7 * N; q.hit_key = (uint32_t*)(d + 8 * N); q.hit_u = d + 9 * N; q.hit_v = d + 10 * N;
@@ -416,7 +424,7 @@ void shutdown() {
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c.b_spheres, &c.b_sphere_mat, &c.b_lights, &c.b_materials, &c.b_bf_pos, &c.b_bf_nrm, &c.b_bf_uv, &c.b_bf_idx,
                       &c.b_nodes, &c.b_tris, &c.b_m_nrm, &c.b_m_uv, &c.b_m_idx, &c.b_m_matid, &c.b_accum, &c.b_screen, &c.b_stage,
-                      &c.b_pixmap, &c.b_paths, &c.b_rays, &c.b_ids};
+                      &c.b_pixmap, &c.b_paths, &c.b_rays, &c.b_ids, &c.b_queue};
     for (DevBuf* b : bufs) b->release();
     if (c.d_cursor) (void)hipFree(c.d_cursor);
     if (c.d_scene) (void)hipFree(c.d_scene);
@@ -511,6 +519,7 @@ int art_set_option(const char* name, int64_t value) {
   else if (n == "batch_paths") { if (value < 1024) return fail("batch_paths too small"); g_ctx.batch_paths = value; }
   else if (n == "blocks_per_cu") { g_ctx.opt_blocks_per_cu = (int)value; g_ctx.blocks_per_cu = 0; }
   else if (n == "count_tests") { g_ctx.count_tests = value != 0; }
+  else if (n == "shadow_anyhit") { g_ctx.shadow_anyhit = value != 0; }
   else if (n == "leaf_min") { if (value < 1 || value > 8) return fail("leaf_min: 1..8"); g_ctx.leaf_min = (int)value; }
   else if (n == "bvh_max_leaf") { if (value < 1 || value > kMaxLeafTris) return fail("bvh_max_leaf: 1..8"); g_ctx.bvh_params.max_leaf = (int)value; }
   else if (n == "bvh_leaf_base_milli") { g_ctx.bvh_params.leaf_base = (float)value / 1000.0f; }

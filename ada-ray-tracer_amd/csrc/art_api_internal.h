@@ -27,7 +27,7 @@ struct Ctx {
   // frame
   int width = 0, height = 0, spp = 0;
   int rank = 0, nranks = 1, tile = 32, npix_local = 0;
-  DevBuf b_accum, b_screen, b_stage, b_pixmap, b_paths, b_rays, b_ids;
+  DevBuf b_accum, b_screen, b_stage, b_pixmap, b_paths, b_rays, b_ids, b_queue;
   float* ext_accum = nullptr;
   // work distribution / counters
   int* d_cursor = nullptr;
@@ -38,7 +38,8 @@ struct Ctx {
   int64_t batch_paths = 8ll << 20;
   int opt_blocks_per_cu = 0, blocks_per_cu = 0;
   bool count_tests = false;
-  int leaf_min = 3;
+  int leaf_min = 4;
+  bool shadow_anyhit = true;   // shadow rays use the visibility rule instead of a full closest-hit search (same decision)
   // timing
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   std::vector<hipEvent_t> pass_events;

@@ -129,8 +129,24 @@ ART_HD void tri_leaf_test(const float* tr, f3 o, f3 d, Cand& best) {
     cand_take(best, t, KEY_TRI | (uint32_t)__builtin_bit_cast(int32_t, tr[9]), u, v);
 }
 
+ART_HD float next_up_pos(float x) { return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) + 1u); }   // x >= 0, finite
+
+// Visibility rule for shadow rays (shm >= 0): Compute_Shadow only asks whether the closest hit lies in (shm, tfar)
+// (ray_tracer.adb:122, shm = 10*eps).  The first hit found beyond shm ("far") already bounds the closest hit from
+// above, so from then on only hits with t <= shm can change the answer: the search bound collapses to shm, and the
+// first hit found there ("near") ends the ray.  `rep` is the hit reported when no near hit exists.
+struct ShadowState { float shm; bool far; Cand rep; };
+
+// returns true when the ray is finished
+ART_HD bool shadow_rule(ShadowState& sh, Cand& best) {
+  if (sh.shm < 0.0f || best.key == KEY_MISS) return false;
+  if (best.t <= sh.shm) return true;                       // near hit: not in shadow, done
+  if (!sh.far) { sh.far = true; sh.rep = best; best = cand_init(next_up_pos(sh.shm)); }
+  return false;
+}
+
 template <bool STATS>
-ART_HD void bvh_closest(const DevScene& s, f3 o, f3 d, Cand& best, BvhStats* st) {
+ART_HD void bvh_closest(const DevScene& s, f3 o, f3 d, Cand& best, BvhStats* st, ShadowState& sh) {
   if (s.n_tris <= 0) return;
   const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   int32_t stk_ref[kStackEntries]; float stk_t[kStackEntries];
@@ -166,7 +182,8 @@ ART_HD void bvh_closest(const DevScene& s, f3 o, f3 d, Cand& best, BvhStats* st)
       for (int a = nh - 1; a >= 0; --a) { stk_ref[sp] = ent[a]; stk_t[sp] = tm[a]; ++sp; }
     } else {
       if (STATS) { st->leaf_visits++; st->tri_tests += (uint64_t)cnt; }
-      for (int j = 0; j < cnt; ++j) tri_leaf_test(s.tris + (size_t)(ref + j) * kTriFloats, o, d, best);
+      for (int j = 0; j < cnt; ++j) tri_leaf_test(s.tris + (size_t)(ref + j) * kTriFloats, o, d, best);   // the leaf is one unit
+      if (shadow_rule(sh, best)) return;
     }
   }
 }
@@ -174,15 +191,17 @@ ART_HD void bvh_closest(const DevScene& s, f3 o, f3 d, Cand& best, BvhStats* st)
 // Scene.Find_Closest_Hit (scene.adb:56-86) for one ray; tfar clips the search (shadow rays only need
 // hits below maxDist - epsilon2, ray_tracer.adb:119-122; camera/bounce rays pass kInfinity).
 template <bool STATS>
-ART_HD Cand closest_hit(const DevScene& s, f3 o, f3 d, float tfar, BvhStats* st) {
+ART_HD Cand closest_hit(const DevScene& s, f3 o, f3 d, float tfar, BvhStats* st, float shm = -1.0f) {
   Cand best = cand_init(tfar);
   for (int i = 0; i < s.n_spheres; ++i) isect_sphere(o, d, s.spheres[i], (uint32_t)i, best);
   if (s.has_cornell) isect_cornell(o, d, s, best);
   for (int i = 0; i < s.n_lights; ++i)
     if (s.lights[i].shape == LIGHT_RECT) isect_quad(o, d, s.lights[i], (uint32_t)i, best);
   isect_bf_mesh(o, d, s, best);
-  bvh_closest<STATS>(s, o, d, best, st);
-  return best;
+  ShadowState sh; sh.shm = shm; sh.far = false; sh.rep = best;
+  if (shadow_rule(sh, best)) return best;
+  bvh_closest<STATS>(s, o, d, best, st, sh);
+  return (best.key != KEY_MISS || !sh.far) ? best : sh.rep;
 }
 
 }  // namespace art

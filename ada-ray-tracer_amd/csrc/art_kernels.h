@@ -14,9 +14,13 @@ struct TraceArgs {
   const float* ray_ox; const float* ray_oy; const float* ray_oz;
   const float* ray_dx; const float* ray_dy; const float* ray_dz;
   const float* ray_tfar;        // < 0: skip
+  // shadow rays (index >= shadow_begin) only feed Compute_Shadow's test  10*eps < t_closest < tfar  (ray_tracer.adb:122):
+  // sh_min[i - shadow_begin] = 10*eps.  nullptr: every ray is a closest-hit query.
+  const float* sh_min; int32_t shadow_begin;
   float* hit_t; uint32_t* hit_key; float* hit_u; float* hit_v;
   const float* nodes; const float* tris; int32_t n_tris;   // BVH of the closest-hit mesh (hot-loop operands)
   int* cursor;                  // work cursor, zeroed before every launch
+  int* queue; int* queue_count; // live-ray queue filled by k_analytic (indices into the ray arrays), count zeroed before every launch
   unsigned long long* stats;    // [box, tri, node, leaf, rays] when counting
 };
 

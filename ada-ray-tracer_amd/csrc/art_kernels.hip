@@ -78,6 +78,9 @@ __device__ __forceinline__ uint64_t group_min_u64(uint64_t k) {
   return k;
 }
 
+// hip's __ballot() round-trips the predicate through a VGPR (v_cndmask + v_cmp); the builtin keeps it a lane mask
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -103,9 +106,11 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
   const int gbase = lane & ~7;
   uint2* const stk = lds_stack + (size_t)(wave * 8 + g) * (A.stack_entries + 1);
   const uint64_t leaders = 0x0101010101010101ull;
-  const float4* const nodes4 = reinterpret_cast<const float4*>(A.nodes);   // kernel arguments: global address space
-  const float4* const tris4 = reinterpret_cast<const float4*>(A.tris);
-  const bool have_mesh = A.n_tris > 0;
+  // kernel-argument bases stay in SGPRs; per-lane addressing is a 32-bit byte offset (scalar base + vector offset loads).
+  // art_upload_scene guarantees n_nodes * 256 and n_tris * 48 fit in 32 bits.
+  const char* const nodes_b = reinterpret_cast<const char*>(A.nodes);
+  const char* const tris_b = reinterpret_cast<const char*>(A.tris);
+  const int n_queue = *A.queue_count;
 
   int chunk_pos = 0, chunk_end = 0;   // wave-uniform
   bool exhausted = false;             // wave-uniform
@@ -115,78 +120,45 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
   float best_t = 0.0f; uint32_t best_key = KEY_MISS;
   uint32_t pend = 0; bool pend_valid = false;        // popped entry waiting for its phase
   uint32_t held_key = KEY_MISS; float held_u = 0.0f, held_v = 0.0f;   // lane-local: barycentrics of the hit this lane found
-  uint64_t st_box = 0, st_tri = 0, st_node = 0, st_leaf = 0, st_rays = 0;
+  float shm = -1.0f; bool far_found = false;          // shadow-ray visibility rule (art_isect.h shadow_rule)
+  uint64_t st_box = 0, st_tri = 0, st_node = 0, st_leaf = 0, st_it_node = 0, st_it_leaf = 0, st_it_all = 0;
 
   for (;;) {
-    // ---------------- refill idle groups from the wave's chunk
+    if (STATS) st_it_all += (lane == 0);
+    // ---------------- refill idle groups from the wave's chunk of the live-ray queue
     bool need = !has_ray;
     while (!exhausted) {
-      const uint64_t need_mask = __ballot(need) & leaders;
+      const uint64_t need_mask = ballot64(need) & leaders;
       if (need_mask == 0) break;
       if (chunk_pos == chunk_end) {
         int base = 0;
         if (lane == 0) base = atomicAdd(A.cursor, kChunk);
         base = __builtin_amdgcn_readfirstlane(base);
-        chunk_pos = base; chunk_end = min(base + kChunk, A.n_rays);
-        if (chunk_pos >= A.n_rays) { exhausted = true; chunk_pos = chunk_end = 0; break; }
+        chunk_pos = base; chunk_end = min(base + kChunk, n_queue);
+        if (chunk_pos >= n_queue) { exhausted = true; chunk_pos = chunk_end = 0; break; }
       }
       const int avail = chunk_end - chunk_pos;
       const int n_need = __popcll(need_mask);
       const int my_rank = __popcll(need_mask & ((1ull << gbase) - 1ull));
       const bool got = need && (my_rank < avail);
       if (got) {
-        ray = chunk_pos + my_rank;
-        const float tfar = A.ray_tfar[ray];
-        if (tfar >= 0.0f) {
-          // ---- new live ray: load, intersect the analytic primitives (one per lane), start at the BVH root
-          const DevScene& S = *Sp;
-          o = mk3(A.ray_ox[ray], A.ray_oy[ray], A.ray_oz[ray]);
-          d = mk3(A.ray_dx[ray], A.ray_dy[ray], A.ray_dz[ray]);
-          inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-          Cand c = cand_init(tfar);
-          const int n_items = S.n_spheres + 1 + S.n_lights;
-          for (int it = j; it < n_items; it += 8) {
-            if (it < S.n_spheres) isect_sphere(o, d, S.spheres[it], (uint32_t)it, c);
-            else if (it == S.n_spheres) { if (S.has_cornell) isect_cornell(o, d, S, c); }
-            else { const int li = it - S.n_spheres - 1; if (S.lights[li].shape == LIGHT_RECT) isect_quad(o, d, S.lights[li], (uint32_t)li, c); }
-          }
-          group_min_tk(c.t, c.key);
-          Cand best = c; best.u = 0.0f; best.v = 0.0f;
-          if (best.key == KEY_MISS) best.t = tfar;
-          held_key = KEY_MISS; held_u = 0.0f; held_v = 0.0f;
-          if (S.bf_ntris > 0) {   // reference brute-force mesh: lanes test 8 triangles, the window scan runs in index order
-            float b0, b1;
-            if (slab_reference(o, d, S.bf_bbmin, S.bf_bbmax, b0, b1)) {
-              float wmin = 0.0f, wmax = 1000000.0f, ht = 0.0f, hu = 0.0f, hv = 0.0f; bool any = false; uint32_t tri_id = 0;
-              for (int base = 0; base < S.bf_ntris; base += 8) {
-                const int i = base + j;
-                float tt = 0.0f, uu = 0.0f, vv = 0.0f; bool pass = false;
-                if (i < S.bf_ntris) {
-                  const int32_t* ix = S.bf_idx + 3 * i;
-                  pass = tri_raw(o, d, ld3(S.bf_pos + 3 * ix[0]), ld3(S.bf_pos + 3 * ix[1]), ld3(S.bf_pos + 3 * ix[2]), tt, uu, vv);
-                }
-                for (int k = 0; k < 8; ++k) {
-                  const float tk = __shfl(tt, gbase + k);
-                  const int pk = __shfl((int)pass, gbase + k);
-                  const float uk = __shfl(uu, gbase + k), vk = __shfl(vv, gbase + k);
-                  if (pk && tk > wmin && tk < wmax) { any = true; tri_id = (uint32_t)(base + k); ht = tk; hu = uk; hv = vk; wmin = tk; wmax = tk + 1.0e-6f; }
-                }
-              }
-              if (any) {
-                cand_take(best, ht, KEY_BFTRI | tri_id, hu, hv);
-                if (best.key == (KEY_BFTRI | tri_id)) { held_key = best.key; held_u = hu; held_v = hv; }
-              }
-            }
-          }
-          best_t = best.t; best_key = best.key;
-          sp = 0; pend = 0u; pend_valid = have_mesh;      // entry 0 = root node
-          has_ray = true; need = false;
-          if (STATS) st_rays += (j == 0);
-        }
+        // the analytic primitives were intersected by k_analytic: (hit_t, hit_key) is the starting bound
+        ray = A.queue[chunk_pos + my_rank];
+        o = mk3(A.ray_ox[ray], A.ray_oy[ray], A.ray_oz[ray]);
+        d = mk3(A.ray_dx[ray], A.ray_dy[ray], A.ray_dz[ray]);
+        inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        best_t = A.hit_t[ray]; best_key = A.hit_key[ray];
+        shm = (A.sh_min != nullptr && ray >= A.shadow_begin) ? A.sh_min[ray - A.shadow_begin] : -1.0f;
+        far_found = (shm >= 0.0f) && (best_key != KEY_MISS);     // a queued shadow ray with a hit has a far hit (near ones are not queued)
+        best_t = far_found ? next_up_pos(shm) : best_t;
+        best_key = far_found ? KEY_MISS : best_key;
+        held_key = KEY_MISS;
+        sp = 0; pend = 0u; pend_valid = true;                     // entry 0 = root node
+        has_ray = true; need = false;
       }
       chunk_pos += min(avail, n_need);
     }
-    if (__ballot(has_ray) == 0) break;
+    if (ballot64(has_ray) == 0) break;
 
     // The step loop below is written branch-free on purpose: on CDNA a divergent `if` costs three scalar
     // instructions (save/restore exec + skip branch) and the scalar unit issues at half the vector rate, so the
@@ -206,14 +178,12 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
     }
     // ---------------- retire rays whose stack ran dry
     const bool done = has_ray && !pend_valid && sp == 0;
-    if (__ballot(done) != 0) {
+    if (ballot64(done) != 0) {
       if (done) {
-        const uint32_t cls = best_key & ~KEY_INDEX_MASK;
-        const bool tri_hit = (best_key != KEY_MISS) && (cls == KEY_TRI || cls == KEY_BFTRI);
-        if (j == 0) { A.hit_t[ray] = best_t; A.hit_key[ray] = best_key; }
-        if (tri_hit ? (held_key == best_key && (cls == KEY_TRI || j == 0)) : (j == 0)) {
-          A.hit_u[ray] = tri_hit ? held_u : 0.0f; A.hit_v[ray] = tri_hit ? held_v : 0.0f;
-        }
+        const bool keep_far = far_found && best_key == KEY_MISS;      // shadow ray whose far hit is already stored
+        if (j == 0 && !keep_far) { A.hit_t[ray] = best_t; A.hit_key[ray] = best_key; }
+        // barycentrics: only a BVH triangle found by this kernel needs storing (analytic / brute-force hits were stored by k_analytic)
+        if (shm < 0.0f && best_key != KEY_MISS && held_key == best_key) { A.hit_u[ray] = held_u; A.hit_v[ray] = held_v; }
         has_ray = false;
       }
     }
@@ -221,13 +191,14 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
     const int cnt = (int)(pend & 15u), ref = (int)(pend >> 4);
     const bool want_leaf = has_ray && pend_valid && cnt != 0;
     const bool want_node = has_ray && pend_valid && cnt == 0;
-    const uint64_t leaf_mask = __ballot(want_leaf), node_mask = __ballot(want_node);
+    const uint64_t leaf_mask = ballot64(want_leaf), node_mask = ballot64(want_node);
     if ((leaf_mask | node_mask) == 0) continue;
     const bool do_leaf = (__popcll(leaf_mask) >= 8 * A.leaf_min) || (node_mask == 0);
     if (!do_leaf) {
       // ---- node phase: lane j slab-tests child j; groups not taking part read the root node and discard the result
-      const float4* nd = nodes4 + (size_t)(want_node ? ref : 0) * (kNodeFloats / 4) + j;
-      const float4 r0 = nd[0], r1 = nd[8];
+      const uint32_t noff = (uint32_t)(want_node ? ref : 0) * (uint32_t)(kNodeFloats * 4) + (uint32_t)j * 16u;
+      const float4 r0 = *reinterpret_cast<const float4*>(nodes_b + noff);
+      const float4 r1 = *reinterpret_cast<const float4*>(nodes_b + noff + 128u);
       const int cref = __builtin_bit_cast(int, r0.w), ccnt = __builtin_bit_cast(int, r1.w);
       const float t0x = (r0.x - o.x) * inv.x, t1x = (r1.x - o.x) * inv.x;
       const float t0y = (r0.y - o.y) * inv.y, t1y = (r1.y - o.y) * inv.y;
@@ -237,17 +208,19 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       const bool hit = want_node && (cref >= 0) && (tmn <= tmx);
       const int key = hit ? (int)((__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j) : 0x7fffffff;
       const int rank = group_rank(key);
-      const int nh = __popcll((__ballot(hit) >> gbase) & 0xffull);
+      const int nh = __popcll((ballot64(hit) >> gbase) & 0xffull);
       uint2* const dst = hit ? (stk + sp + (nh - 1 - rank)) : trash;
       *dst = make_uint2((uint32_t)((cref << 4) | ccnt), __builtin_bit_cast(uint32_t, tmn));
       sp += nh;
       pend_valid = pend_valid && !want_node;
-      if (STATS) { st_box += (want_node && cref >= 0); st_node += (want_node && j == 0); }
+      if (STATS) { st_box += (want_node && cref >= 0); st_node += (want_node && j == 0); st_it_node += (lane == 0); }
     } else {
       // ---- leaf phase: lane j < cnt tests triangle j of the leaf; everybody else tests triangle 0 and is masked out
       const bool tri_lane = want_leaf && (j < cnt);
-      const float4* tr = tris4 + (size_t)(tri_lane ? (ref + j) : 0) * (kTriFloats / 4);
-      const float4 q0 = tr[0], q1 = tr[1], q2 = tr[2];
+      const uint32_t toff = (uint32_t)(tri_lane ? (ref + j) : 0) * (uint32_t)(kTriFloats * 4);
+      const float4 q0 = *reinterpret_cast<const float4*>(tris_b + toff);
+      const float4 q1 = *reinterpret_cast<const float4*>(tris_b + toff + 16u);
+      const float4 q2 = *reinterpret_cast<const float4*>(tris_b + toff + 32u);
       float tt, uu, vv;
       const bool pass = tri_raw(o, d, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x), tt, uu, vv);
       const bool valid = tri_lane && pass && (tt > 0.0f) && (tt < 1000000.0f);
@@ -258,19 +231,70 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       const uint32_t bt = (best_t == 0.0f) ? 0u : __builtin_bit_cast(uint32_t, best_t);
       const uint64_t cur = pack_tk(bt, best_key == KEY_MISS ? 0u : best_key);
       const bool accept = want_leaf && ((uint32_t)win != KEY_MISS) && (win < cur);
-      best_t = accept ? __builtin_bit_cast(float, (uint32_t)(win >> 32)) : best_t;
+      const float win_t = __builtin_bit_cast(float, (uint32_t)(win >> 32));
+      best_t = accept ? win_t : best_t;
       best_key = accept ? (uint32_t)win : best_key;
+      const bool sh_hit = accept && (shm >= 0.0f);
+      if (ballot64(sh_hit) != 0) {                         // shadow_rule, group-uniform
+        const bool near = sh_hit && (win_t <= shm);
+        const bool far = sh_hit && !near;                  // first far hit (afterwards the bound is <= shm)
+        if (far && j == 0) { A.hit_t[ray] = win_t; A.hit_key[ray] = (uint32_t)win; }
+        far_found = far_found || far;
+        best_t = far ? next_up_pos(shm) : best_t;
+        best_key = far ? KEY_MISS : best_key;
+        sp = near ? 0 : sp;                                // near hit: nothing left to learn
+      }
       const bool mine = accept && valid && (key == (uint32_t)win);
       held_key = mine ? key : held_key; held_u = mine ? uu : held_u; held_v = mine ? vv : held_v;
       pend_valid = pend_valid && !want_leaf;
-      if (STATS) { st_tri += tri_lane; st_leaf += (want_leaf && j == 0); }
+      if (STATS) { st_tri += tri_lane; st_leaf += (want_leaf && j == 0); st_it_leaf += (lane == 0); }
     }
     wave_lds_sync();
   }
   if (STATS) {
     atomicAdd(&A.stats[0], (unsigned long long)st_box); atomicAdd(&A.stats[1], (unsigned long long)st_tri);
     atomicAdd(&A.stats[2], (unsigned long long)st_node); atomicAdd(&A.stats[3], (unsigned long long)st_leaf);
-    atomicAdd(&A.stats[4], (unsigned long long)st_rays);
+    if (lane == 0) { atomicAdd(&A.stats[5], (unsigned long long)st_it_node); atomicAdd(&A.stats[6], (unsigned long long)st_it_leaf); atomicAdd(&A.stats[7], (unsigned long long)st_it_all); }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_analytic: one ray per lane.  Intersects the analytic primitives and the reference brute-force mesh
+// (scene.adb:62-69 candidates 1-4), stores the result as the starting bound of the BVH search and appends
+// the rays that still need the BVH to the live-ray queue (dead rays and decided shadow rays drop out here).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_analytic(const DevScene* __restrict__ Sp, const TraceArgs A) {
+  const DevScene& S = *Sp;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool queue_it = false;
+  if (i < A.n_rays) {
+    const float tfar = A.ray_tfar[i];
+    if (tfar >= 0.0f) {
+      const f3 o = mk3(A.ray_ox[i], A.ray_oy[i], A.ray_oz[i]), d = mk3(A.ray_dx[i], A.ray_dy[i], A.ray_dz[i]);
+      Cand best = cand_init(tfar);
+      for (int k = 0; k < S.n_spheres; ++k) isect_sphere(o, d, S.spheres[k], (uint32_t)k, best);
+      if (S.has_cornell) isect_cornell(o, d, S, best);
+      for (int k = 0; k < S.n_lights; ++k)
+        if (S.lights[k].shape == LIGHT_RECT) isect_quad(o, d, S.lights[k], (uint32_t)k, best);
+      isect_bf_mesh(o, d, S, best);
+      A.hit_t[i] = best.t; A.hit_key[i] = best.key; A.hit_u[i] = best.u; A.hit_v[i] = best.v;
+      const float shm = (A.sh_min != nullptr && i >= A.shadow_begin) ? A.sh_min[i - A.shadow_begin] : -1.0f;
+      const bool near_done = (shm >= 0.0f) && (best.key != KEY_MISS) && (best.t <= shm);   // shadow_rule: decided
+      queue_it = (A.n_tris > 0) && !near_done;
+    }
+  }
+  // wave-aggregated append
+  const uint64_t m = __ballot(queue_it);
+  if (m != 0) {
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == (__ffsll((unsigned long long)m) - 1)) base = atomicAdd(A.queue_count, (int)__popcll(m));
+    base = __shfl(base, __ffsll((unsigned long long)m) - 1);
+    if (queue_it) A.queue[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = i;
+  }
+  if (A.stats != nullptr) {
+    const uint64_t live = __ballot(i < A.n_rays && A.ray_tfar[min(i, A.n_rays - 1)] >= 0.0f);
+    if ((threadIdx.x & 63) == 0 && live) atomicAdd(&A.stats[4], (unsigned long long)__popcll(live));
   }
 }
 
@@ -285,7 +309,8 @@ __global__ __launch_bounds__(256) void k_trace_simple(const DevScene* __restrict
   const float tfar = A.ray_tfar[i];
   if (!(tfar >= 0.0f)) return;
   BvhStats st = {0, 0, 0, 0};
-  const Cand c = closest_hit<STATS>(S, mk3(A.ray_ox[i], A.ray_oy[i], A.ray_oz[i]), mk3(A.ray_dx[i], A.ray_dy[i], A.ray_dz[i]), tfar, &st);
+  const float shm = (A.sh_min != nullptr && i >= A.shadow_begin) ? A.sh_min[i - A.shadow_begin] : -1.0f;
+  const Cand c = closest_hit<STATS>(S, mk3(A.ray_ox[i], A.ray_oy[i], A.ray_oz[i]), mk3(A.ray_dx[i], A.ray_dy[i], A.ray_dz[i]), tfar, &st, shm);
   A.hit_t[i] = c.t; A.hit_key[i] = c.key; A.hit_u[i] = c.u; A.hit_v[i] = c.v;
   if (STATS) {
     atomicAdd(&A.stats[0], (unsigned long long)st.box_tests); atomicAdd(&A.stats[1], (unsigned long long)st.tri_tests);
@@ -416,6 +441,10 @@ void launch_trace(hipStream_t st, const DevScene* S, const TraceArgs& A, int ker
     else hipLaunchKernelGGL(k_trace_simple<false>, dim3(blocks_for(A.n_rays)), dim3(256), 0, st, S, A);
     return;
   }
+  TraceArgs B = A;
+  if (!stats) B.stats = nullptr;
+  hipLaunchKernelGGL(k_analytic, dim3(blocks_for(A.n_rays)), dim3(256), 0, st, S, B);
+  if (A.n_tris <= 0) return;                       // no BVH mesh: the analytic pass is the whole search
   const size_t lds = trace_coop_lds_bytes(A.stack_entries);
   if (stats) hipLaunchKernelGGL(k_trace_coop<true>, dim3(grid_blocks), dim3(256), lds, st, S, A);
   else hipLaunchKernelGGL(k_trace_coop<false>, dim3(grid_blocks), dim3(256), lds, st, S, A);

@@ -177,13 +177,18 @@ def main():
             T = (c1.tri_tests - c0.tri_tests) / n
             NV = (c1.node_visits - c0.node_visits) / n
             LV = (c1.leaf_visits - c0.leaf_visits) / n
+            itn = max(1, c1.node_phase_iters - c0.node_phase_iters); itl = max(1, c1.leaf_phase_iters - c0.leaf_phase_iters)
+            occ = {"groups_per_node_phase": round((c1.node_visits - c0.node_visits) / itn, 2),
+                   "groups_per_leaf_phase": round((c1.leaf_visits - c0.leaf_visits) / itl, 2),
+                   "tris_per_leaf_visit": round((c1.tri_tests - c0.tri_tests) / max(1, c1.leaf_visits - c0.leaf_visits), 2),
+                   "node_phase_iters": int(itn), "leaf_phase_iters": int(itl), "wave_iters": int(c1.wave_iters - c0.wave_iters)}
             bytes_per_ray = 32.0 * B + 48.0 * T + 64.0
             achieved = rays * bytes_per_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
             roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                         "kernel": "k_trace_coop" if args.kernel == "coop" else "k_trace_simple",
                         "bytes_per_ray": round(bytes_per_ray, 1), "box_tests_per_ray": round(B, 2), "tri_tests_per_ray": round(T, 2),
-                        "node_visits_per_ray": round(NV, 2), "leaf_visits_per_ray": round(LV, 2),
+                        "node_visits_per_ray": round(NV, 2), "leaf_visits_per_ray": round(LV, 2), "wave_occupancy": occ,
                         "avg_launch_ms": round(trace_ms / max(1, launches), 4), "launches": int(launches),
                         "trace_Mrays_per_s": round(rays / (trace_ms * 1e-3) / 1e6, 2) if trace_ms > 0 else None}
         cpu = None

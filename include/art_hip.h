@@ -110,7 +110,8 @@ typedef struct ArtStats {
   double   trace_ms;        /* GPU time inside the trace kernel, cumulative (HIP events) */
   double   pass_ms;         /* GPU time of whole passes (all kernels), cumulative */
   uint64_t trace_launches;
-  uint64_t box_tests, tri_tests, node_visits, leaf_visits, traced_rays;  /* only filled by art_trace_rays(stats) / art_enable_counters */
+  uint64_t box_tests, tri_tests, node_visits, leaf_visits, traced_rays;  /* only filled by art_trace_rays(stats) / option count_tests */
+  uint64_t node_phase_iters, leaf_phase_iters, wave_iters;               /* cooperative kernel: wave-level loop counters (count_tests) */
 } ArtStats;
 
 typedef struct ArtHit {          /* geometry.ads:57-67 flattened */

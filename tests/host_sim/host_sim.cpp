@@ -62,7 +62,8 @@ extern "C" int hs_render(const ArtSceneDesc* sd, const ArtPassParams* p, int w, 
     for (int i = 0; i < nr; ++i) {
       if (!(q.ray_tfar[i] >= 0.0f)) continue;
       rays++;
-      const Cand c = closest_hit<false>(hs.hdr, mk3(q.ray_ox[i], q.ray_oy[i], q.ray_oz[i]), mk3(q.ray_dx[i], q.ray_dy[i], q.ray_dz[i]), q.ray_tfar[i], nullptr);
+      const float shm = (i >= P) ? q.sh_min_t[i - P] : -1.0f;
+      const Cand c = closest_hit<false>(hs.hdr, mk3(q.ray_ox[i], q.ray_oy[i], q.ray_oz[i]), mk3(q.ray_dx[i], q.ray_dy[i], q.ray_dz[i]), q.ray_tfar[i], nullptr, shm);
       q.hit_t[i] = c.t; q.hit_key[i] = c.key; q.hit_u[i] = c.u; q.hit_v[i] = c.v;
     }
   };
