@@ -1,0 +1,108 @@
+--  art_hip.ads -- thin Ada binding of libart_hip.so (include/art_hip.h), the MI355X render backend.
+--  NOTE: written against the reference sources without an Ada toolchain in the build image (no GNAT):
+--  syntax-reviewed only.  The same calling sequence is exercised by host/test_main.cpp (C++ mirror).
+--
+--  Record layouts are Convention C and match include/art_hip.h field for field.
+with Interfaces;   use Interfaces;
+with Interfaces.C; use Interfaces.C;
+with System;
+with Interfaces.C.Strings;
+
+package Art_Hip is
+
+  type Float3_C is array (0 .. 2) of aliased C_float;   pragma Convention (C, Float3_C);
+  type Float8_C is array (0 .. 7) of aliased C_float;   pragma Convention (C, Float8_C);
+  type Float16_C is array (0 .. 15) of aliased C_float; pragma Convention (C, Float16_C);
+  type Int6_C is array (0 .. 5) of aliased int;         pragma Convention (C, Int6_C);
+  type Normals6_C is array (0 .. 5) of Float3_C;        pragma Convention (C, Normals6_C);
+
+  ART_MAT_NULL    : constant := 0;  ART_MAT_LIGHT  : constant := 1;  ART_MAT_LAMBERT : constant := 2;
+  ART_MAT_MIRROR  : constant := 3;  ART_MAT_GLASS  : constant := 4;  ART_MAT_PHONG   : constant := 5;
+  ART_LIGHT_RECT  : constant := 0;  ART_LIGHT_SPHERE : constant := 1;
+  ART_MESH_REFERENCE_BF : constant := 0;  ART_MESH_CLOSEST : constant := 1;
+  ART_LAYOUT_ADA_XY : constant := 0;      ART_LAYOUT_ROW_MAJOR : constant := 1;
+
+  type Art_Material is record          --  materials.ads:58-130 flattened
+    kind  : int;
+    light : int;
+    p     : Float8_C;
+  end record;
+  pragma Convention (C, Art_Material);
+
+  type Art_Light is record             --  lights.ads:36-55
+    shape       : int;
+    mat         : int;
+    boxMin, boxMax, normal : Float3_C;
+    center      : Float3_C;
+    radius      : C_float;
+    intensity   : Float3_C;
+    surfaceArea : C_float;
+  end record;
+  pragma Convention (C, Art_Light);
+
+  type Art_Sphere is record            --  geometry.ads:21-25
+    pos : Float3_C;
+    r   : C_float;
+    mat : int;
+  end record;
+  pragma Convention (C, Art_Sphere);
+
+  type Art_Mesh is record              --  geometry.ads:94-101
+    mode   : int;
+    nverts : int;
+    ntris  : int;
+    pos, nrm, uv : System.Address;     --  Float3_Array / Float2_Array storage ('Address of element 0)
+    idx, matid   : System.Address;     --  Triangle_Array (3 ints each) / MaterialsId_Array
+    bbmin, bbmax : Float3_C;
+  end record;
+  pragma Convention (C, Art_Mesh);
+
+  type Art_Scene_Desc is record
+    n_spheres   : int;  spheres   : System.Address;
+    has_cornell : int;
+    cb_min, cb_max : Float3_C;
+    cb_mat      : Int6_C;
+    cb_nrm      : Normals6_C;
+    n_lights    : int;  lights    : System.Address;
+    n_materials : int;  materials : System.Address;
+    n_meshes    : int;  meshes    : System.Address;
+    cam_pos     : Float3_C;
+    cam_matrix  : Float16_C;
+  end record;
+  pragma Convention (C, Art_Scene_Desc);
+
+  type Art_Pass_Params is record       --  the package variables Render_Pass reads, ray_tracer.ads:20-32
+    render_type : int;                 --  Render_Type'Pos (g_rend_type)
+    aa_on       : int;
+    max_depth   : int;
+    vthreads    : int;                 --  Threads_Num
+    background  : Float3_C;
+    seed        : Unsigned_64;
+    layout      : int;
+  end record;
+  pragma Convention (C, Art_Pass_Params);
+
+  function art_init (device_ordinal : int) return int;
+  pragma Import (C, art_init, "art_init");
+
+  function art_upload_scene (scene : access constant Art_Scene_Desc) return int;
+  pragma Import (C, art_upload_scene, "art_upload_scene");
+
+  function art_resize (width, height : int) return int;
+  pragma Import (C, art_resize, "art_resize");
+
+  function art_render_pass (p : access constant Art_Pass_Params; accum_host : System.Address;
+                            screen_host : System.Address; spp_inout : access int) return int;
+  pragma Import (C, art_render_pass, "art_render_pass");
+
+  function art_debug_hit_pass (p : access constant Art_Pass_Params; accum_host, screen_host : System.Address;
+                               prim_index, mat_id, prim_type : System.Address) return int;
+  pragma Import (C, art_debug_hit_pass, "art_debug_hit_pass");
+
+  function art_last_error return Interfaces.C.Strings.chars_ptr;
+  pragma Import (C, art_last_error, "art_last_error");
+
+  procedure art_shutdown;
+  pragma Import (C, art_shutdown, "art_shutdown");
+
+end Art_Hip;

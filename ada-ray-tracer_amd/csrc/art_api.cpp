@@ -118,16 +118,7 @@ int upload_scene(const ArtSceneDesc* d) {
 // ------------------------------------------------------------------------------------------------
 static int build_shard() {
   Ctx& c = g_ctx;
-  const int W = c.width, H = c.height, T = c.tile;
-  std::vector<uint32_t> pm;
-  pm.reserve((size_t)W * H / std::max(1, c.nranks) + 1024);
-  const int tx = (W + T - 1) / T, ty = (H + T - 1) / T;
-  for (int by = 0; by < ty; ++by)
-    for (int bx = 0; bx < tx; ++bx) {
-      if ((by * tx + bx) % c.nranks != c.rank) continue;
-      for (int y = by * T; y < std::min(H, (by + 1) * T); ++y)
-        for (int x = bx * T; x < std::min(W, (bx + 1) * T); ++x) pm.push_back((uint32_t)(y * W + x));
-    }
+  const std::vector<uint32_t> pm = build_pixmap(c.width, c.height, c.rank, c.nranks, c.tile);
   c.npix_local = (int)pm.size();
   return upload(c.b_pixmap, pm);
 }

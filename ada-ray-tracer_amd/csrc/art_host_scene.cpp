@@ -89,6 +89,19 @@ bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& o
   return true;
 }
 
+std::vector<uint32_t> build_pixmap(int W, int H, int rank, int nranks, int T) {
+  std::vector<uint32_t> pm;
+  pm.reserve((size_t)W * H / (size_t)(nranks > 0 ? nranks : 1) + 1024);
+  const int tx = (W + T - 1) / T, ty = (H + T - 1) / T;
+  for (int by = 0; by < ty; ++by)
+    for (int bx = 0; bx < tx; ++bx) {
+      if ((by * tx + bx) % nranks != rank) continue;
+      for (int y = by * T; y < (H < (by + 1) * T ? H : (by + 1) * T); ++y)
+        for (int x = bx * T; x < (W < (bx + 1) * T ? W : (bx + 1) * T); ++x) pm.push_back((uint32_t)(y * W + x));
+    }
+  return pm;
+}
+
 void bind_host_pointers(HostScene& hs) {
   DevScene& h = hs.hdr;
   h.spheres = hs.spheres.data(); h.sphere_mat = hs.sphere_mat.data();

@@ -26,6 +26,10 @@ struct HostScene {
 
 bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& out, std::string& err);
 
+// pixel ownership for multi-GPU sharding: tile x tile pixel tiles dealt round-robin, tile_id % nranks == rank.
+// Returns the global pixel indices (y*W + x) owned by `rank`, in tile order.
+std::vector<uint32_t> build_pixmap(int W, int H, int rank, int nranks, int tile);
+
 // points hdr's pointer members at the host vectors (host simulation / CPU-side checks)
 void bind_host_pointers(HostScene& hs);
 

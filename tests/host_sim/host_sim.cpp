@@ -37,6 +37,9 @@ extern "C" int hs_trace(const ArtSceneDesc* sd, const float* o, const float* d, 
   return 0;
 }
 
+static int g_rank = 0, g_nranks = 1, g_tile = 32;
+extern "C" void hs_set_shard(int rank, int nranks, int tile) { g_rank = rank; g_nranks = nranks; g_tile = tile; }
+
 extern "C" int hs_render(const ArtSceneDesc* sd, const ArtPassParams* p, int w, int h, int spp0, float* accum /*row-major*/,
                          unsigned long long* rays_out) {
   HostScene hs; BvhBuildParams bp;
@@ -45,10 +48,11 @@ extern "C" int hs_render(const ArtSceneDesc* sd, const ArtPassParams* p, int w, 
   DevFrame F; F.width = w; F.height = h; F.render_type = p->render_type; F.aa_on = p->aa_on ? 1 : 0; F.max_depth = p->max_depth;
   F.seed_lo = (uint32_t)p->seed; F.seed_hi = (uint32_t)(p->seed >> 32); std::memcpy(F.background, p->background, 12);
   F.cam_z = -(float)w / safe_tan(kHalfPi / 2.0f);
-  const int per = p->aa_on ? 4 : 1, S = p->vthreads * per, npix = w * h, P = npix * S, D = p->max_depth;
+  const std::vector<uint32_t> pixmap = build_pixmap(w, h, g_rank, g_nranks, g_tile);   // the product's shard map
+  const int per = p->aa_on ? 4 : 1, S = p->vthreads * per, npix = (int)pixmap.size(), P = npix * S, D = p->max_depth;
   std::vector<float> buf((size_t)(14 + 8 + 3 + 3 + 6 * D + 3 + 3) * P, 0.0f);
   DevPaths q; std::memset(&q, 0, sizeof q);
-  q.P = P; q.npix = npix; q.pixmap = nullptr; q.sample_base = (uint32_t)spp0;
+  q.P = P; q.npix = npix; q.pixmap = pixmap.data(); q.sample_base = (uint32_t)spp0;
   float* f = buf.data(); const size_t pp = (size_t)P;
   auto take = [&](size_t k) { float* r = f; f += k; return r; };
   q.ray_ox = take(2 * pp); q.ray_oy = take(2 * pp); q.ray_oz = take(2 * pp); q.ray_dx = take(2 * pp); q.ray_dy = take(2 * pp); q.ray_dz = take(2 * pp); q.ray_tfar = take(2 * pp);

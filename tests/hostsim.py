@@ -21,6 +21,10 @@ def lib(art):
     return _lib
 
 
+def set_shard(art, rank, nranks, tile=32):
+    lib(art).hs_set_shard(rank, nranks, tile)
+
+
 def render(art, sd, params, w, h, spp0=0, accum=None):
     if accum is None:
         accum = np.zeros((h, w, 3), np.float32)

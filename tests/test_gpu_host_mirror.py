@@ -1,0 +1,43 @@
+"""GPU: the C++ replay of test.adb (host/test_main.cpp) writes the BMP the oracle predicts; bench.py keeps its contract."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_test_adb_replay_writes_identical_bmp(art, tmp_path):
+    exe = os.path.join(art.PKG_DIR, "art_test")
+    out = str(tmp_path / "ART_render.bmp")
+    # width height passes Threads_Num render_type(PT_MIS) aa
+    r = subprocess.run([exe, orc.PYRAMID_VSGF, out, "96", "64", "2", "3", "4", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "spp =  24" in r.stdout.replace("spp = 24", "spp =  24")
+    cs = orc.CornellScene()
+    acc, spp, _ = orc.render(cs.scene, orc.make_params(96, 64, orc.PT_MIS, True, 8, 3, seed=1), passes=2)
+    assert open(out, "rb").read() == orc.bmp_bytes(orc.resolve(acc, spp))
+    r = subprocess.run([exe, orc.PYRAMID_VSGF, out, "64", "64", "5", "28", "0", "1"], capture_output=True, text=True, timeout=300)   # RT_DEBUG finishes after one pass
+    assert r.returncode == 0 and r.stdout.count("pass ") == 1
+    oacc, _, _, _ = orc.debug_pass(cs.scene, orc.make_params(64, 64, orc.RT_DEBUG, False))
+    assert open(out, "rb").read() == orc.bmp_bytes(orc.resolve(oacc, 1))
+
+
+def test_bench_contract(art):
+    r = subprocess.run([sys.executable, os.path.join(art.ROOT, "bench.py"), "--scene", "c3", "--width", "256", "--height", "144", "--steps", "1",
+                        "--warmup", "1", "--vthreads", "1", "--cpu-seconds", "1", "--cpu-width", "64", "--cpu-height", "36"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in line
+    assert line["metric"] == "Mrays/s" and line["value"] > 0 and line["vs_baseline"] is None and "workload" in line["config"]
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
