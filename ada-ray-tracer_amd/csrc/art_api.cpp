@@ -168,12 +168,12 @@ static int coop_grid() {
 
 static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
   Ctx& c = g_ctx;
-  a.n_rays = n_rays; a.stack_entries = c.stack_entries; a.leaf_min = c.leaf_min;
+  a.n_rays = n_rays; a.stack_entries = c.stack_entries; a.node_min = c.node_min; a.chunk = c.ray_chunk;
   a.ray_ox = q.ray_ox; a.ray_oy = q.ray_oy; a.ray_oz = q.ray_oz; a.ray_dx = q.ray_dx; a.ray_dy = q.ray_dy; a.ray_dz = q.ray_dz; a.ray_tfar = q.ray_tfar;
   a.hit_t = q.hit_t; a.hit_key = q.hit_key; a.hit_u = q.hit_u; a.hit_v = q.hit_v;
   a.nodes = c.scene.nodes; a.tris = c.scene.tris; a.n_tris = c.scene.n_tris;
   a.sh_min = (c.shadow_anyhit && q.sh_min_t && n_rays > q.P) ? q.sh_min_t : nullptr; a.shadow_begin = q.P;
-  a.cursor = c.d_cursor; a.stats = c.d_counters + 3;
+  a.cursor = c.d_cursor; a.stats = c.d_counters + 3; a.live_rays = c.d_counters;
   a.queue = (int*)c.b_queue.p; a.queue_count = c.d_cursor + 1;
 }
 
@@ -190,6 +190,7 @@ static int trace(const DevPaths& q, int n_rays) {
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     c.ev_pool.push_back(e0); c.ev_pool.push_back(e1);
   }
+  if (c.trace_kernel == TRACE_COOP) launch_analytic(c.stream, c.d_scene, a, c.count_tests);   // outside the trace-kernel event pair
   HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used], c.stream));
   launch_trace(c.stream, c.d_scene, a, c.trace_kernel, c.count_tests, coop_grid());
   HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used + 1], c.stream));
@@ -210,7 +211,7 @@ static int collect_timing() {
   unsigned long long cnt[16];
   HIP_TRY(hipMemcpy(cnt, c.d_counters, sizeof cnt, hipMemcpyDeviceToHost));
   c.stats.node_phase_iters = cnt[8]; c.stats.leaf_phase_iters = cnt[9]; c.stats.wave_iters = cnt[10];
-  c.stats.rays = c.camera_rays + cnt[0];
+  c.stats.rays = cnt[0];
   c.stats.box_tests = cnt[3]; c.stats.tri_tests = cnt[4]; c.stats.node_visits = cnt[5]; c.stats.leaf_visits = cnt[6]; c.stats.traced_rays = cnt[7];
   return 0;
 }
@@ -267,7 +268,7 @@ int render_pass_device(const ArtPassParams* p, int32_t* spp_inout) {
         c.camera_rays += (uint64_t)q.P;
         for (int b = 0; b < p->max_depth; ++b) {
           if (trace(q, b == 0 ? q.P : 2 * q.P)) return 1;
-          launch_shade(c.stream, F, c.scene, q, b, c.d_counters);
+          launch_shade(c.stream, F, c.scene, q, b);
         }
         if (p->render_type != ART_PT_STUPID) { if (trace(q, 2 * q.P)) return 1; }
         launch_finish(c.stream, F, q, p->max_depth - 1);
@@ -507,11 +508,12 @@ int art_set_option(const char* name, int64_t value) {
   if (!name) return fail("null option");
   const std::string n(name);
   if (n == "trace_kernel") { if (value != TRACE_COOP && value != TRACE_SIMPLE) return fail("trace_kernel: 0 (cooperative) or 1 (simple)"); g_ctx.trace_kernel = (int)value; }
-  else if (n == "batch_paths") { if (value < 1024) return fail("batch_paths too small"); g_ctx.batch_paths = value; }
+  else if (n == "batch_paths") { if (value < 1024 || value > (1ll << 30)) return fail("batch_paths: 1024..2^30"); g_ctx.batch_paths = value; }
   else if (n == "blocks_per_cu") { g_ctx.opt_blocks_per_cu = (int)value; g_ctx.blocks_per_cu = 0; }
   else if (n == "count_tests") { g_ctx.count_tests = value != 0; }
   else if (n == "shadow_anyhit") { g_ctx.shadow_anyhit = value != 0; }
-  else if (n == "leaf_min") { if (value < 1 || value > 8) return fail("leaf_min: 1..8"); g_ctx.leaf_min = (int)value; }
+  else if (n == "ray_chunk") { if (value < 8 || value > 4096) return fail("ray_chunk: 8..4096"); g_ctx.ray_chunk = (int)value; }
+  else if (n == "node_min") { if (value < 1 || value > 8) return fail("node_min: 1..8"); g_ctx.node_min = (int)value; }
   else if (n == "bvh_max_leaf") { if (value < 1 || value > kMaxLeafTris) return fail("bvh_max_leaf: 1..8"); g_ctx.bvh_params.max_leaf = (int)value; }
   else if (n == "bvh_leaf_base_milli") { g_ctx.bvh_params.leaf_base = (float)value / 1000.0f; }
   else if (n == "bvh_tri_cost_milli") { g_ctx.bvh_params.tri_cost = (float)value / 1000.0f; }

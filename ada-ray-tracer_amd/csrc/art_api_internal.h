@@ -35,10 +35,11 @@ struct Ctx {
   uint64_t camera_rays = 0;
   // options
   int trace_kernel = TRACE_COOP;
-  int64_t batch_paths = 8ll << 20;
+  int64_t batch_paths = 32ll << 20;   // path slots per batch (328 B each at depth 8 -> 11 GB of the 288 GB HBM): big batches keep late bounces wide
   int opt_blocks_per_cu = 0, blocks_per_cu = 0;
   bool count_tests = false;
-  int leaf_min = 4;
+  int node_min = 4;
+  int ray_chunk = 32;
   bool shadow_anyhit = true;   // shadow rays use the visibility rule instead of a full closest-hit search (same decision)
   // timing
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;

@@ -9,6 +9,8 @@
 
 namespace art {
 
+ART_HD f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
 struct Cand { float t; uint32_t key; float u, v; };
 
 ART_HD Cand cand_init(float tfar) { Cand c; c.t = tfar; c.key = KEY_MISS; c.u = 0.0f; c.v = 0.0f; return c; }
@@ -88,8 +90,6 @@ ART_HD bool tri_raw(f3 o, f3 d, f3 A, f3 B, f3 C, float& t, float& u, float& v) 
   return (v > 0.0f) && (u > 0.0f) && (u + v < 1.0f);
 }
 
-ART_HD f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
-
 // IntersectMeshBF with its (tmin, tmax) window semantics: triangles in index order, the window
 // collapses to (t, t+1e-6) after every accepted hit ("first hit wins").  One candidate results.
 ART_HD void isect_bf_mesh(f3 o, f3 d, const DevScene& s, Cand& best) {
@@ -115,12 +115,29 @@ ART_HD void isect_bf_mesh(f3 o, f3 d, const DevScene& s, Cand& best) {
 // key = (bits(tmin) & ~7) | slot, push far-to-near; leaf: test its triangles in storage order.
 struct BvhStats { uint64_t box_tests, tri_tests, node_visits, leaf_visits; };
 
-ART_HD void slab_fast(const float* nd, int j, f3 o, f3 inv, float tbest, float& tmn, float& tmx) {
-  const float t0x = (nd[4 * j + 0] - o.x) * inv.x, t1x = (nd[32 + 4 * j + 0] - o.x) * inv.x;
-  const float t0y = (nd[4 * j + 1] - o.y) * inv.y, t1y = (nd[32 + 4 * j + 1] - o.y) * inv.y;
-  const float t0z = (nd[4 * j + 2] - o.z) * inv.z, t1z = (nd[32 + 4 * j + 2] - o.z) * inv.z;
+// Slab test of the BVH (this backend's own arithmetic, not reference code; the oracle's walker mirrors it for the
+// B/T counters).  Per ray: inv = 1/d with |d| < 1e-30 replaced by +-1e-30 (so inv is finite and an axis-parallel ray
+// behaves like the limit of a slightly tilted one), noi = -(o * inv).  Per box plane: t = fma(plane, inv, noi) -- one
+// fused op per plane, 6 per box.  The interval is clipped to [0, tbest].
+ART_HD void slab_setup(f3 o, f3 d, f3& inv, f3& noi) {
+  const float tiny = 1.0e-30f;
+  const float dx = (fabsf(d.x) < tiny) ? copysignf(tiny, d.x) : d.x;
+  const float dy = (fabsf(d.y) < tiny) ? copysignf(tiny, d.y) : d.y;
+  const float dz = (fabsf(d.z) < tiny) ? copysignf(tiny, d.z) : d.z;
+  inv = mk3(1.0f / dx, 1.0f / dy, 1.0f / dz);
+  noi = mk3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+}
+
+ART_HD void slab_interval(f3 lo, f3 hi, f3 inv, f3 noi, float tbest, float& tmn, float& tmx) {
+  const float t0x = __builtin_fmaf(lo.x, inv.x, noi.x), t1x = __builtin_fmaf(hi.x, inv.x, noi.x);
+  const float t0y = __builtin_fmaf(lo.y, inv.y, noi.y), t1y = __builtin_fmaf(hi.y, inv.y, noi.y);
+  const float t0z = __builtin_fmaf(lo.z, inv.z, noi.z), t1z = __builtin_fmaf(hi.z, inv.z, noi.z);
   tmn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
   tmx = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tbest));
+}
+
+ART_HD void slab_fast(const float* nd, int j, f3 inv, f3 noi, float tbest, float& tmn, float& tmx) {
+  slab_interval(ld3(nd + 4 * j), ld3(nd + 32 + 4 * j), inv, noi, tbest, tmn, tmx);
 }
 
 ART_HD void tri_leaf_test(const float* tr, f3 o, f3 d, Cand& best) {
@@ -148,7 +165,8 @@ ART_HD bool shadow_rule(ShadowState& sh, Cand& best) {
 template <bool STATS>
 ART_HD void bvh_closest(const DevScene& s, f3 o, f3 d, Cand& best, BvhStats* st, ShadowState& sh) {
   if (s.n_tris <= 0) return;
-  const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  f3 inv, noi;
+  slab_setup(o, d, inv, noi);
   int32_t stk_ref[kStackEntries]; float stk_t[kStackEntries];
   int sp = 0;
   stk_ref[sp] = 0; stk_t[sp] = 0.0f; ++sp;        // entry = (ref << 4) | count
@@ -166,7 +184,7 @@ ART_HD void bvh_closest(const DevScene& s, f3 o, f3 d, Cand& best, BvhStats* st,
         if (rj < 0) continue;
         if (STATS) st->box_tests++;
         float tmn, tmx;
-        slab_fast(nd, j, o, inv, best.t, tmn, tmx);
+        slab_fast(nd, j, inv, noi, best.t, tmn, tmx);
         if (tmn <= tmx) {
           key[nh] = (__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j;
           ent[nh] = (rj << 4) | __builtin_bit_cast(int32_t, nd[32 + 4 * j + 3]);

@@ -10,7 +10,7 @@ enum { TRACE_COOP = 0, TRACE_SIMPLE = 1 };
 struct TraceArgs {
   int32_t n_rays;
   int32_t stack_entries;        // per-ray-group LDS stack depth (>= Bvh8::max_stack)
-  int32_t leaf_min;             // a wave runs its leaf phase once this many of its 8 ray groups wait on a leaf
+  int32_t node_min;             // a wave keeps expanding nodes while at least this many of its 8 ray groups have one
   const float* ray_ox; const float* ray_oy; const float* ray_oz;
   const float* ray_dx; const float* ray_dy; const float* ray_dz;
   const float* ray_tfar;        // < 0: skip
@@ -19,13 +19,15 @@ struct TraceArgs {
   const float* sh_min; int32_t shadow_begin;
   float* hit_t; uint32_t* hit_key; float* hit_u; float* hit_v;
   const float* nodes; const float* tris; int32_t n_tris;   // BVH of the closest-hit mesh (hot-loop operands)
+  int32_t chunk;                // rays a wave claims per atomic on the cursor
   int* cursor;                  // work cursor, zeroed before every launch
   int* queue; int* queue_count; // live-ray queue filled by k_analytic (indices into the ray arrays), count zeroed before every launch
   unsigned long long* stats;    // [box, tri, node, leaf, rays] when counting
+  unsigned long long* live_rays;   // += closest-hit queries actually issued by this launch (Mrays/s numerator)
 };
 
 void launch_raygen(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q);
-void launch_shade(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q, int bounce, unsigned long long* ray_counter);
+void launch_shade(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q, int bounce);
 void launch_finish(hipStream_t st, const DevFrame& F, const DevPaths& Q, int last_level);
 void launch_accumulate(hipStream_t st, const DevFrame& F, const DevPaths& Q, int samples_in_batch, float* accum);
 void launch_resolve(hipStream_t st, const float* accum, int n_pixels, float norm_c, uint32_t* screen);
@@ -35,6 +37,7 @@ void launch_to_xmajor_u32(hipStream_t st, const uint32_t* src, uint32_t* dst, in
 void launch_from_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, int h);
 size_t trace_coop_lds_bytes(int stack_entries);
 void launch_trace(hipStream_t st, const DevScene* d_scene, const TraceArgs& A, int kernel, bool stats, int grid_blocks);
+void launch_analytic(hipStream_t st, const DevScene* d_scene, const TraceArgs& A, bool stats);
 int  trace_coop_blocks_per_cu(int stack_entries);
 
 }  // namespace art

@@ -35,7 +35,8 @@ constexpr int DPP_HALF_MIRROR = 0x141;  // lane i <- lane 7-i  (= xor 7 inside a
 __device__ __forceinline__ int xor4_i(int v) { return dpp_i<DPP_XOR3>(dpp_i<DPP_HALF_MIRROR>(v)); }
 __device__ __forceinline__ float xor4_f(float v) { return dpp_f<DPP_XOR3>(dpp_f<DPP_HALF_MIRROR>(v)); }
 
-// number of lanes in my 8-lane group whose key is smaller than mine (keys are < 2^31)
+// number of lanes in my 8-lane group whose key is smaller than mine (keys are < 2^31).  (A hand-scheduled
+// v_sub_co_u32_dpp / v_addc chain has fewer instructions but measured 4 % slower: its carry chain serialises.)
 __device__ __forceinline__ int group_rank(int key) {
   const int m = dpp_i<DPP_HALF_MIRROR>(key);
   int r = 0;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
   bool exhausted = false;             // wave-uniform
   bool has_ray = false;               // group-uniform from here on
   int sp = 0, ray = 0;
-  f3 o = mk3(0, 0, 0), d = o, inv = o;
+  f3 o = mk3(0, 0, 0), d = o, inv = o, noi = o;
   float best_t = 0.0f; uint32_t best_key = KEY_MISS;
   uint32_t pend = 0; bool pend_valid = false;        // popped entry waiting for its phase
   uint32_t held_key = KEY_MISS; float held_u = 0.0f, held_v = 0.0f;   // lane-local: barycentrics of the hit this lane found
@@ -132,9 +133,9 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       if (need_mask == 0) break;
       if (chunk_pos == chunk_end) {
         int base = 0;
-        if (lane == 0) base = atomicAdd(A.cursor, kChunk);
+        if (lane == 0) base = atomicAdd(A.cursor, A.chunk);
         base = __builtin_amdgcn_readfirstlane(base);
-        chunk_pos = base; chunk_end = min(base + kChunk, n_queue);
+        chunk_pos = base; chunk_end = min(base + A.chunk, n_queue);
         if (chunk_pos >= n_queue) { exhausted = true; chunk_pos = chunk_end = 0; break; }
       }
       const int avail = chunk_end - chunk_pos;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         ray = A.queue[chunk_pos + my_rank];
         o = mk3(A.ray_ox[ray], A.ray_oy[ray], A.ray_oz[ray]);
         d = mk3(A.ray_dx[ray], A.ray_dy[ray], A.ray_dz[ray]);
-        inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        slab_setup(o, d, inv, noi);
         best_t = A.hit_t[ray]; best_key = A.hit_key[ray];
         shm = (A.sh_min != nullptr && ray >= A.shadow_begin) ? A.sh_min[ray - A.shadow_begin] : -1.0f;
         far_found = (shm >= 0.0f) && (best_key != KEY_MISS);     // a queued shadow ray with a hit has a far hit (near ones are not queued)
@@ -160,22 +161,57 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
     }
     if (ballot64(has_ray) == 0) break;
 
-    // The step loop below is written branch-free on purpose: on CDNA a divergent `if` costs three scalar
-    // instructions (save/restore exec + skip branch) and the scalar unit issues at half the vector rate, so the
-    // first version of this kernel was SALU-bound.  Inactive lanes compute on clamped operands and are masked by
-    // selects; LDS pushes of non-hit lanes go to the group's spare (padding) slot.
+    // The step code below is written branch-free on purpose: on CDNA a divergent `if` costs three scalar
+    // instructions (save/restore exec + skip branch) and the first version of this kernel was SALU-bound.  Inactive
+    // lanes compute on clamped operands and are masked by selects; LDS pushes of non-hit lanes go to the group's
+    // spare (padding) slot.  The kernel is now VALU-issue-bound, so bookkeeping (retire / refill / leaf vote) is kept
+    // out of the inner node loop.
     uint2* const trash = stk + A.stack_entries;
 
-    // ---------------- next stack entry: up to two pops per iteration, entries culled by the current hit are dropped
-#pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-      const bool need_pop = has_ray && !pend_valid && sp > 0;
-      sp -= need_pop ? 1 : 0;
-      const uint2 e = need_pop ? stk[sp] : *trash;
-      const bool ok = need_pop && !(__builtin_bit_cast(float, e.y) > best_t);
-      pend = ok ? e.x : pend;
-      pend_valid = pend_valid || ok;
+    // ---------------- inner loop: pop + node phase, as long as enough of the wave's groups have a node to expand
+    bool want_leaf = false;
+    for (;;) {
+      // next stack entry: the two top entries are read together (one LDS wait); entries culled by the current hit are dropped
+      {
+        const bool need = has_ray && !pend_valid;
+        const uint2 e1 = stk[max(sp - 1, 0)], e2 = stk[max(sp - 2, 0)];
+        const bool v1 = need && sp > 0;
+        const bool ok1 = v1 && !(__builtin_bit_cast(float, e1.y) > best_t);
+        const bool v2 = v1 && !ok1 && sp > 1;
+        const bool ok2 = v2 && !(__builtin_bit_cast(float, e2.y) > best_t);
+        pend = ok1 ? e1.x : (ok2 ? e2.x : pend);
+        pend_valid = pend_valid || ok1 || ok2;
+        sp -= (v1 ? 1 : 0) + (v2 ? 1 : 0);
+      }
+      const int cnt = (int)(pend & 15u);
+      const bool active = has_ray && pend_valid;
+      want_leaf = active && cnt != 0;
+      const bool want_node = active && cnt == 0;
+      const uint64_t node_mask = ballot64(want_node);
+      // leave when fewer than node_min groups still expand nodes (the others wait on a leaf, are finished, or idle)
+      if (__popcll(node_mask) < 8 * A.node_min) {
+        if (node_mask == 0 || ballot64(want_leaf || (has_ray && !active && sp == 0)) != 0 || !exhausted) break;
+      }
+      // ---- node phase: lane j slab-tests child j; groups not taking part read the root node and discard the result
+      const int ref = (int)(pend >> 4);
+      const uint32_t noff = (uint32_t)(want_node ? ref : 0) * (uint32_t)(kNodeFloats * 4) + (uint32_t)j * 16u;
+      const float4 r0 = *reinterpret_cast<const float4*>(nodes_b + noff);
+      const float4 r1 = *reinterpret_cast<const float4*>(nodes_b + noff + 128u);
+      const int cref = __builtin_bit_cast(int, r0.w), ccnt = __builtin_bit_cast(int, r1.w);
+      float tmn, tmx;
+      slab_interval(mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), inv, noi, best_t, tmn, tmx);
+      const bool hit = want_node && (cref >= 0) && (tmn <= tmx);
+      const int key = hit ? (int)((__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j) : 0x7fffffff;
+      const int rank = group_rank(key);
+      const int nh = __popcll((ballot64(hit) >> gbase) & 0xffull);
+      uint2* const dst = hit ? (stk + sp + (nh - 1 - rank)) : trash;
+      *dst = make_uint2((uint32_t)((cref << 4) | ccnt), __builtin_bit_cast(uint32_t, tmn));
+      sp += nh;
+      pend_valid = pend_valid && !want_node;
+      if (STATS) { st_box += (want_node && cref >= 0); st_node += (want_node && j == 0); st_it_node += (lane == 0); }
+      wave_lds_sync();
     }
+
     // ---------------- retire rays whose stack ran dry
     const bool done = has_ray && !pend_valid && sp == 0;
     if (ballot64(done) != 0) {
@@ -187,35 +223,10 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         has_ray = false;
       }
     }
-    // ---------------- vote: one phase per iteration for the whole wave
-    const int cnt = (int)(pend & 15u), ref = (int)(pend >> 4);
-    const bool want_leaf = has_ray && pend_valid && cnt != 0;
-    const bool want_node = has_ray && pend_valid && cnt == 0;
-    const uint64_t leaf_mask = ballot64(want_leaf), node_mask = ballot64(want_node);
-    if ((leaf_mask | node_mask) == 0) continue;
-    const bool do_leaf = (__popcll(leaf_mask) >= 8 * A.leaf_min) || (node_mask == 0);
-    if (!do_leaf) {
-      // ---- node phase: lane j slab-tests child j; groups not taking part read the root node and discard the result
-      const uint32_t noff = (uint32_t)(want_node ? ref : 0) * (uint32_t)(kNodeFloats * 4) + (uint32_t)j * 16u;
-      const float4 r0 = *reinterpret_cast<const float4*>(nodes_b + noff);
-      const float4 r1 = *reinterpret_cast<const float4*>(nodes_b + noff + 128u);
-      const int cref = __builtin_bit_cast(int, r0.w), ccnt = __builtin_bit_cast(int, r1.w);
-      const float t0x = (r0.x - o.x) * inv.x, t1x = (r1.x - o.x) * inv.x;
-      const float t0y = (r0.y - o.y) * inv.y, t1y = (r1.y - o.y) * inv.y;
-      const float t0z = (r0.z - o.z) * inv.z, t1z = (r1.z - o.z) * inv.z;
-      const float tmn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
-      const float tmx = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best_t));
-      const bool hit = want_node && (cref >= 0) && (tmn <= tmx);
-      const int key = hit ? (int)((__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j) : 0x7fffffff;
-      const int rank = group_rank(key);
-      const int nh = __popcll((ballot64(hit) >> gbase) & 0xffull);
-      uint2* const dst = hit ? (stk + sp + (nh - 1 - rank)) : trash;
-      *dst = make_uint2((uint32_t)((cref << 4) | ccnt), __builtin_bit_cast(uint32_t, tmn));
-      sp += nh;
-      pend_valid = pend_valid && !want_node;
-      if (STATS) { st_box += (want_node && cref >= 0); st_node += (want_node && j == 0); st_it_node += (lane == 0); }
-    } else {
-      // ---- leaf phase: lane j < cnt tests triangle j of the leaf; everybody else tests triangle 0 and is masked out
+
+    // ---------------- leaf phase for every group holding a leaf: lane j < cnt tests triangle j; others test triangle 0, masked
+    if (ballot64(want_leaf) != 0) {
+      const int cnt = (int)(pend & 15u), ref = (int)(pend >> 4);
       const bool tri_lane = want_leaf && (j < cnt);
       const uint32_t toff = (uint32_t)(tri_lane ? (ref + j) : 0) * (uint32_t)(kTriFloats * 4);
       const float4 q0 = *reinterpret_cast<const float4*>(tris_b + toff);
@@ -249,7 +260,6 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       pend_valid = pend_valid && !want_leaf;
       if (STATS) { st_tri += tri_lane; st_leaf += (want_leaf && j == 0); st_it_leaf += (lane == 0); }
     }
-    wave_lds_sync();
   }
   if (STATS) {
     atomicAdd(&A.stats[0], (unsigned long long)st_box); atomicAdd(&A.stats[1], (unsigned long long)st_tri);
@@ -263,39 +273,72 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
 // (scene.adb:62-69 candidates 1-4), stores the result as the starting bound of the BVH search and appends
 // the rays that still need the BVH to the live-ray queue (dead rays and decided shadow rays drop out here).
 // ------------------------------------------------------------------------------------------------
+constexpr int kAnalyticChunk = 4096;   // rays per workgroup: ONE global atomic per chunk for the queue (a single hot word
+                                       // serves only ~88 atomics/us on this chip, so per-wave atomics were the bottleneck)
+
 __global__ __launch_bounds__(256) void k_analytic(const DevScene* __restrict__ Sp, const TraceArgs A) {
+  __shared__ int s_idx[kAnalyticChunk];
+  __shared__ int s_count, s_live, s_base;
   const DevScene& S = *Sp;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool queue_it = false;
-  if (i < A.n_rays) {
-    const float tfar = A.ray_tfar[i];
-    if (tfar >= 0.0f) {
-      const f3 o = mk3(A.ray_ox[i], A.ray_oy[i], A.ray_oz[i]), d = mk3(A.ray_dx[i], A.ray_dy[i], A.ray_dz[i]);
-      Cand best = cand_init(tfar);
-      for (int k = 0; k < S.n_spheres; ++k) isect_sphere(o, d, S.spheres[k], (uint32_t)k, best);
-      if (S.has_cornell) isect_cornell(o, d, S, best);
-      for (int k = 0; k < S.n_lights; ++k)
-        if (S.lights[k].shape == LIGHT_RECT) isect_quad(o, d, S.lights[k], (uint32_t)k, best);
-      isect_bf_mesh(o, d, S, best);
-      A.hit_t[i] = best.t; A.hit_key[i] = best.key; A.hit_u[i] = best.u; A.hit_v[i] = best.v;
-      const float shm = (A.sh_min != nullptr && i >= A.shadow_begin) ? A.sh_min[i - A.shadow_begin] : -1.0f;
-      const bool near_done = (shm >= 0.0f) && (best.key != KEY_MISS) && (best.t <= shm);   // shadow_rule: decided
-      queue_it = (A.n_tris > 0) && !near_done;
+  if (threadIdx.x == 0) { s_count = 0; s_live = 0; }
+  __syncthreads();
+  const int chunk0 = blockIdx.x * kAnalyticChunk;
+  for (int k0 = 0; k0 < kAnalyticChunk; k0 += 256) {
+    const int i = chunk0 + k0 + threadIdx.x;
+    bool queue_it = false, live = false;
+    if (i < A.n_rays) {
+      const float tfar = A.ray_tfar[i];
+      if (tfar >= 0.0f) {
+        live = true;
+        const f3 o = mk3(A.ray_ox[i], A.ray_oy[i], A.ray_oz[i]), d = mk3(A.ray_dx[i], A.ray_dy[i], A.ray_dz[i]);
+        Cand best = cand_init(tfar);
+        for (int k = 0; k < S.n_spheres; ++k) isect_sphere(o, d, S.spheres[k], (uint32_t)k, best);
+        if (S.has_cornell) isect_cornell(o, d, S, best);
+        for (int k = 0; k < S.n_lights; ++k)
+          if (S.lights[k].shape == LIGHT_RECT) isect_quad(o, d, S.lights[k], (uint32_t)k, best);
+        isect_bf_mesh(o, d, S, best);
+        A.hit_t[i] = best.t; A.hit_key[i] = best.key; A.hit_u[i] = best.u; A.hit_v[i] = best.v;
+        const float shm = (A.sh_min != nullptr && i >= A.shadow_begin) ? A.sh_min[i - A.shadow_begin] : -1.0f;
+        const bool near_done = (shm >= 0.0f) && (best.key != KEY_MISS) && (best.t <= shm);   // shadow_rule: decided
+        queue_it = (A.n_tris > 0) && !near_done;
+      }
     }
-  }
-  // wave-aggregated append
-  const uint64_t m = __ballot(queue_it);
-  if (m != 0) {
+    // wave-aggregated append into the workgroup's LDS list
+    const uint64_t m = __builtin_amdgcn_ballot_w64(queue_it);
+    const uint64_t lv = __builtin_amdgcn_ballot_w64(live);
     const int lane = threadIdx.x & 63;
     int base = 0;
-    if (lane == (__ffsll((unsigned long long)m) - 1)) base = atomicAdd(A.queue_count, (int)__popcll(m));
-    base = __shfl(base, __ffsll((unsigned long long)m) - 1);
-    if (queue_it) A.queue[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = i;
+    if (lane == 0) {
+      if (m) base = atomicAdd(&s_count, (int)__popcll(m));
+      if (lv) atomicAdd(&s_live, (int)__popcll(lv));
+    }
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (queue_it) s_idx[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = i;
   }
-  if (A.stats != nullptr) {
-    const uint64_t live = __ballot(i < A.n_rays && A.ray_tfar[min(i, A.n_rays - 1)] >= 0.0f);
-    if ((threadIdx.x & 63) == 0 && live) atomicAdd(&A.stats[4], (unsigned long long)__popcll(live));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s_base = s_count ? atomicAdd(A.queue_count, s_count) : 0;
+    if (s_live) atomicAdd(A.live_rays, (unsigned long long)s_live);
+    if (A.stats != nullptr && s_live) atomicAdd(&A.stats[4], (unsigned long long)s_live);
   }
+  __syncthreads();
+  for (int k = threadIdx.x; k < s_count; k += 256) A.queue[s_base + k] = s_idx[k];
+}
+
+// rays of a launch that bypasses k_analytic (one-ray-per-lane kernel): count the live ones, one atomic per workgroup chunk
+__global__ __launch_bounds__(256) void k_count_live(const TraceArgs A) {
+  __shared__ int s_live;
+  if (threadIdx.x == 0) s_live = 0;
+  __syncthreads();
+  int n = 0;
+  for (int k0 = 0; k0 < kAnalyticChunk; k0 += 256) {
+    const int i = blockIdx.x * kAnalyticChunk + k0 + threadIdx.x;
+    n += (i < A.n_rays && A.ray_tfar[i] >= 0.0f) ? 1 : 0;
+  }
+  for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(&s_live, n);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_live) atomicAdd(A.live_rays, (unsigned long long)s_live);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -327,16 +370,9 @@ __global__ __launch_bounds__(256) void k_raygen(const DevFrame F, const DevScene
   if (slot < Q.P) raygen_slot(F, S, Q, slot);
 }
 
-__global__ __launch_bounds__(256) void k_shade(const DevFrame F, const DevScene S, const DevPaths Q, int bounce, unsigned long long* ray_counter) {
+__global__ __launch_bounds__(256) void k_shade(const DevFrame F, const DevScene S, const DevPaths Q, int bounce) {
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned int live = 0;
-  if (slot < Q.P) {
-    shade_slot(F, S, Q, slot, bounce);
-    live = (Q.ray_tfar[slot] >= 0.0f) + (Q.ray_tfar[(size_t)Q.P + slot] >= 0.0f);
-  }
-  // rays issued for the next trace launch (Mrays/s numerator), one atomic per wave
-  for (int off = 32; off > 0; off >>= 1) live += __shfl_down(live, off);
-  if ((threadIdx.x & 63) == 0 && live) atomicAdd(ray_counter, (unsigned long long)live);
+  if (slot < Q.P) shade_slot(F, S, Q, slot, bounce);
 }
 
 __global__ __launch_bounds__(256) void k_finish(const DevFrame F, const DevPaths Q, int last_level) {
@@ -408,8 +444,8 @@ static inline int blocks_for(int n) { return (n + 255) / 256; }
 void launch_raygen(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q) {
   hipLaunchKernelGGL(k_raygen, dim3(blocks_for(Q.P)), dim3(256), 0, st, F, S, Q);
 }
-void launch_shade(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q, int bounce, unsigned long long* ray_counter) {
-  hipLaunchKernelGGL(k_shade, dim3(blocks_for(Q.P)), dim3(256), 0, st, F, S, Q, bounce, ray_counter);
+void launch_shade(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q, int bounce) {
+  hipLaunchKernelGGL(k_shade, dim3(blocks_for(Q.P)), dim3(256), 0, st, F, S, Q, bounce);
 }
 void launch_finish(hipStream_t st, const DevFrame& F, const DevPaths& Q, int last_level) {
   hipLaunchKernelGGL(k_finish, dim3(blocks_for(Q.P)), dim3(256), 0, st, F, Q, last_level);
@@ -435,16 +471,20 @@ void launch_from_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, 
 
 size_t trace_coop_lds_bytes(int stack_entries) { return (size_t)4 * 8 * (stack_entries + 1) * sizeof(uint2); }
 
+void launch_analytic(hipStream_t st, const DevScene* S, const TraceArgs& A, bool stats) {
+  TraceArgs B = A;
+  if (!stats) B.stats = nullptr;
+  hipLaunchKernelGGL(k_analytic, dim3((A.n_rays + kAnalyticChunk - 1) / kAnalyticChunk), dim3(256), 0, st, S, B);
+}
+
 void launch_trace(hipStream_t st, const DevScene* S, const TraceArgs& A, int kernel, bool stats, int grid_blocks) {
   if (kernel == TRACE_SIMPLE) {
+    hipLaunchKernelGGL(k_count_live, dim3((A.n_rays + kAnalyticChunk - 1) / kAnalyticChunk), dim3(256), 0, st, A);
     if (stats) hipLaunchKernelGGL(k_trace_simple<true>, dim3(blocks_for(A.n_rays)), dim3(256), 0, st, S, A);
     else hipLaunchKernelGGL(k_trace_simple<false>, dim3(blocks_for(A.n_rays)), dim3(256), 0, st, S, A);
     return;
   }
-  TraceArgs B = A;
-  if (!stats) B.stats = nullptr;
-  hipLaunchKernelGGL(k_analytic, dim3(blocks_for(A.n_rays)), dim3(256), 0, st, S, B);
-  if (A.n_tris <= 0) return;                       // no BVH mesh: the analytic pass is the whole search
+  if (A.n_tris <= 0) return;                       // no BVH mesh: the analytic pass (launch_analytic) is the whole search
   const size_t lds = trace_coop_lds_bytes(A.stack_entries);
   if (stats) hipLaunchKernelGGL(k_trace_coop<true>, dim3(grid_blocks), dim3(256), lds, st, S, A);
   else hipLaunchKernelGGL(k_trace_coop<false>, dim3(grid_blocks), dim3(256), lds, st, S, A);

@@ -944,10 +944,13 @@ void orc_render_pass(const orc_scene* scn, const orc_params* prm, float* accum, 
 #ifdef _OPENMP
   if (prm->nthreads > 0) omp_set_num_threads(prm->nthreads);
 #endif
+  const int64_t npx = (int64_t)W * H, nblk = (npx + 63) / 64;
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, tris)
-  for (int y = 0; y < H; ++y) {
+  for (int64_t blk = 0; blk < nblk; ++blk) {
     local_counters lc = { 0, 0 };
-    for (int x = 0; x < W; ++x) {
+    const int64_t p1 = (blk + 1) * 64 < npx ? (blk + 1) * 64 : npx;
+    for (int64_t pi = blk * 64; pi < p1; ++pi) {
+      const int x = (int)(pi % W), y = (int)(pi / W);
       float* a = accum + 3 * ((size_t)y * W + x);
       for (int t = 0; t < prm->vthreads; ++t) {
         f3 color;
@@ -1185,7 +1188,13 @@ void orc_build_cornell(orc_cornell_storage* st, const orc_mesh* pyramid, int use
 static void bvh_walk_one(const float* nodes, const float* tris, const ray_t* rp, float tfar,
                          lite_hit* best, int32_t* best_prim_out, uint64_t* counters) {
   const ray_t r = *rp;
-  float idx = 1.0f / r.direction.x, idy = 1.0f / r.direction.y, idz = 1.0f / r.direction.z;
+  /* the product's slab arithmetic (csrc/art_isect.h slab_setup / slab_interval): finite inverse, one fma per plane */
+  const float tiny = 1.0e-30f;
+  float ddx = (fabsf(r.direction.x) < tiny) ? copysignf(tiny, r.direction.x) : r.direction.x;
+  float ddy = (fabsf(r.direction.y) < tiny) ? copysignf(tiny, r.direction.y) : r.direction.y;
+  float ddz = (fabsf(r.direction.z) < tiny) ? copysignf(tiny, r.direction.z) : r.direction.z;
+  float idx = 1.0f / ddx, idy = 1.0f / ddy, idz = 1.0f / ddz;
+  float nox = -(r.origin.x * idx), noy = -(r.origin.y * idy), noz = -(r.origin.z * idz);
   float best_t = tfar;
   int32_t best_prim = -1;
   lite_hit bh; bh.is_hit = 0; bh.tmin = 0.0f; bh.tmax = 0.0f; bh.u = 0.0f; bh.v = 0.0f;
@@ -1204,9 +1213,9 @@ static void bvh_walk_one(const float* nodes, const float* tris, const ray_t* rp,
         int32_t rj = f2i(nd[4 * j + 3]);
         if (rj < 0) continue;
         counters[0]++;
-        float t0x = (nd[4 * j + 0] - r.origin.x) * idx, t1x = (nd[32 + 4 * j + 0] - r.origin.x) * idx;
-        float t0y = (nd[4 * j + 1] - r.origin.y) * idy, t1y = (nd[32 + 4 * j + 1] - r.origin.y) * idy;
-        float t0z = (nd[4 * j + 2] - r.origin.z) * idz, t1z = (nd[32 + 4 * j + 2] - r.origin.z) * idz;
+        float t0x = fmaf(nd[4 * j + 0], idx, nox), t1x = fmaf(nd[32 + 4 * j + 0], idx, nox);
+        float t0y = fmaf(nd[4 * j + 1], idy, noy), t1y = fmaf(nd[32 + 4 * j + 1], idy, noy);
+        float t0z = fmaf(nd[4 * j + 2], idz, noz), t1z = fmaf(nd[32 + 4 * j + 2], idz, noz);
         float tmn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
         float tmx = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best_t));
         if (tmn <= tmx) {

@@ -70,7 +70,7 @@ def test_small_batches_do_not_change_the_image(art, backend, cornell):
         p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=9)
         accum, _, spp = backend.render_pass(p, 0)
     finally:
-        backend.set_option("batch_paths", 8 << 20)
+        backend.set_option("batch_paths", 32 << 20)
     ref, _, _ = orc.render(cs.scene, orc.make_params(64, 48, orc.PT_MIS, True, 8, 2, seed=9))
     assert_radiance_equal(accum, ref, spp)
 
