@@ -45,6 +45,21 @@ def build_scene(art, args):
     return conv.desc_from_oracle(art, cs), "C2: internal Cornell scene with data/pyramid2.vsgf"
 
 
+def measured_traffic(args, W, H):
+    """HBM-side traffic of the trace kernel in GB/s from the committed rocprofv3 PMC passes (profiles/collect.sh ->
+    profiles/summarize.py): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch / launch time.  The factor 2 on FETCH_SIZE is the
+    gfx950 correction, calibrated on this kernel's own access pattern (profiles/calib_fetch.hip: 17.15 GB reported for
+    34.36 GB of known 128-byte segment gathers).  Only valid for the profiled workload (default C4); null otherwise."""
+    if args.scene != "c4" or args.tris != 1000000 or (W, H) != (1920, 1080) or args.kernel != "coop":
+        return None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r1_final", "pmc_summary.json")))
+        k = [x for x in d if "k_trace_coop" in x][0]
+        return round(d[k]["traffic_GBps_fetch_x2"], 1)
+    except Exception:
+        return None
+
+
 def cpu_baseline(art, sd, args):
     """CPU oracle (kind "port": the reference is Ada and cannot be built or shipped) on a bounded sample of the same
     workload: same scene, same camera, reduced frame (ray distribution preserved), PT_MIS depth 8, all host threads.
@@ -97,13 +112,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("ART_BENCH_FORCE_DIST"))     # FORCE: rehearse the torch/RCCL path with one rank
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl")
     art = ge.load_package()
-    be = art.Backend(local_rank if world > 1 else 0)
+    be = art.Backend(local_rank if use_dist else 0)
     args._backend = be
     be.set_option("trace_kernel", art.TRACE_COOP if args.kernel == "coop" else art.TRACE_SIMPLE)
     for kv in args.opt:
@@ -120,7 +136,7 @@ def main():
 
     W, H = args.width, args.height
     accum_t = None
-    if world > 1:
+    if use_dist:
         accum_t = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
         be.bind_accum(accum_t.data_ptr())
         be.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -133,7 +149,7 @@ def main():
 
     def sync():
         be.synchronize()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
 
@@ -142,7 +158,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         spp = be.render_pass_device(prm, spp)
-    if world > 1:
+    if use_dist:
         be.synchronize()
         dist.reduce(accum_t, dst=0, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
@@ -153,7 +169,7 @@ def main():
     samples = s1.samples - s0.samples
     trace_ms = s1.trace_ms - s0.trace_ms
     launches = s1.trace_launches - s0.trace_launches
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -185,14 +201,14 @@ def main():
             bytes_per_ray = 32.0 * B + 48.0 * T + 64.0
             achieved = rays * bytes_per_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
             roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(args, W, H),
                         "kernel": "k_trace_coop" if args.kernel == "coop" else "k_trace_simple",
                         "bytes_per_ray": round(bytes_per_ray, 1), "box_tests_per_ray": round(B, 2), "tri_tests_per_ray": round(T, 2),
                         "node_visits_per_ray": round(NV, 2), "leaf_visits_per_ray": round(LV, 2), "wave_occupancy": occ,
                         "avg_launch_ms": round(trace_ms / max(1, launches), 4), "launches": int(launches),
                         "trace_Mrays_per_s": round(rays / (trace_ms * 1e-3) / 1e6, 2) if trace_ms > 0 else None}
         cpu = None
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:          # timed on rank 0 at N = 1 only
             cpu = cpu_baseline(art, sd, args)
         value = total_rays / elapsed / 1e6
         line = {
@@ -207,7 +223,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     be.shutdown()

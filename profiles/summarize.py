@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof_final (raw rocprofv3 csv, scratch) into the committed summaries under profiles/<tag>/:
+kernel_stats.csv (rocprofv3 --kernel-trace --stats) and pmc_summary.json (per-kernel counter sums, per-launch HBM traffic
+of the trace kernel).  usage: python profiles/summarize.py r1_final"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof_final")
+
+
+def main(tag):
+    dst = os.path.join(ROOT, "profiles", tag)
+    os.makedirs(dst, exist_ok=True)
+    shutil.copyfile(glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, "kernel_stats.csv"))
+    out = {}
+    for name in ("fetch", "write", "sq", "tcc"):
+        rows = list(csv.DictReader(open(glob.glob(os.path.join(SRC, name, "*", "*_counter_collection.csv"))[0])))
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        disp = collections.defaultdict(dict)
+        for r in rows:
+            k = r["Kernel_Name"].split("(")[0]
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            disp[k][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        for k, v in agg.items():
+            o = out.setdefault(k, {})
+            o.update(v)
+            o["dispatches_" + name] = len(disp[k]); o["total_ns_" + name] = sum(disp[k].values())
+    for k, o in out.items():
+        if "k_trace_coop" in k and "FETCH_SIZE" in o:
+            n = o["dispatches_fetch"]
+            fetch_b = o["FETCH_SIZE"] * 1024.0 / n; write_b = o["WRITE_SIZE"] * 1024.0 / o["dispatches_write"]
+            o["hbm_bytes_per_launch_raw"] = fetch_b + write_b                       # FETCH_SIZE/WRITE_SIZE are in KiB
+            o["hbm_bytes_per_launch_fetch_x2"] = 2.0 * fetch_b + write_b            # gfx950: FETCH_SIZE may count 128-B requests as 64 B
+            o["avg_launch_ms_fetch_pass"] = o["total_ns_fetch"] / n / 1e6
+            o["traffic_GBps_raw"] = o["hbm_bytes_per_launch_raw"] / (o["total_ns_fetch"] / n) 
+            o["traffic_GBps_fetch_x2"] = o["hbm_bytes_per_launch_fetch_x2"] / (o["total_ns_fetch"] / n)
+            if "GRBM_GUI_ACTIVE" in o:
+                o["effective_clock_GHz"] = o["GRBM_GUI_ACTIVE"] / 8.0 / o["total_ns_sq"]
+            if "TCC_HIT_sum" in o:
+                o["l2_hit_rate"] = o["TCC_HIT_sum"] / (o["TCC_HIT_sum"] + o["TCC_MISS_sum"])
+    json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    b = os.path.join(SRC, "bench_under_rocprof.json")
+    if os.path.exists(b):
+        shutil.copyfile(b, os.path.join(dst, "bench_under_rocprof.json"))
+    print("wrote", dst)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r1_final")

@@ -213,6 +213,28 @@ def test_mixed_scene_bit_exact(art, backend):
     assert_radiance_equal(accum, ref, spp)
 
 
+@pytest.mark.parametrize("config", ["c3", "c4", "c5"])
+def test_baseline_scenes_at_full_triangle_count(art, backend, config):
+    """BASELINE configs C3 (100k triangles), C4 (1M) and C5 (mixed 20k) at their real scene size, reduced frame: the oracle's
+    mesh search walks the exported BVH (proven equal to its brute-force scan in test_host_sim_parity / the <=20k cases above),
+    everything else is the oracle's own recursion.  Radiance bit-exact, ray counts equal."""
+    from ada_ray_tracer_amd import scenes
+    sd = {"c3": lambda: scenes.synthetic_scene(100000, 3), "c4": lambda: scenes.synthetic_scene(1000000, 4),
+          "c5": lambda: scenes.mixed_scene(20000, 5)}[config]()
+    backend.upload_scene(sd)
+    osc = conv.OracleScene(sd)
+    nodes, tris, _ = backend.export_bvh()
+    osc.attach_bvh(nodes, tris)
+    W, H = (96, 54)
+    backend.resize(W, H)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=1)
+    accum, _, spp = backend.render_pass(p, 0)
+    ref, rspp, cnt = orc.render(osc.scene, orc.make_params(W, H, orc.PT_MIS, True, 8, 2, seed=1))
+    assert spp == rspp == 8
+    assert_radiance_equal(accum, ref, spp)
+    assert backend.stats().rays == cnt.rays and np.isfinite(ref).all()
+
+
 def test_pixel_tile_shards_sum_to_the_full_frame(art, backend, cornell):
     """8(e): interleaved pixel tiles, one owner per pixel -> the sum over ranks is bit-identical to 1 GPU."""
     cs, sd = cornell
