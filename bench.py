@@ -60,6 +60,26 @@ def measured_traffic(args, W, H):
         return None
 
 
+def host_cpu_share():
+    """CPUs this job may actually use: min(affinity mask, cgroup quota).  A 1-GPU box exposes 256 logical CPUs but caps the
+    job at a share of them; timing an oversubscribed OpenMP team would misreport both the rate and the core count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0]); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(art, sd, args):
     """CPU oracle (kind "port": the reference is Ada and cannot be built or shipped) on a bounded sample of the same
     workload: same scene, same camera, reduced frame (ray distribution preserved), PT_MIS depth 8, all host threads.
@@ -72,8 +92,9 @@ def cpu_baseline(art, sd, args):
     if sd.desc.n_meshes and sd.desc.meshes[0].mode == art.MESH_CLOSEST:
         nodes, tris, _ = be.export_bvh()
         osc.attach_bvh(nodes, tris)
-    prm = orc.make_params(w, h, orc.PT_MIS, True, 8, 1, seed=1)
-    orc.render(osc.scene, orc.make_params(32, 18, orc.PT_MIS, True, 8, 1, seed=1))      # warm threads / caches
+    cores = args.cpu_threads if args.cpu_threads > 0 else host_cpu_share()
+    prm = orc.make_params(w, h, orc.PT_MIS, True, 8, 1, seed=1, nthreads=cores)
+    orc.render(osc.scene, orc.make_params(32, 18, orc.PT_MIS, True, 8, 1, seed=1, nthreads=cores))      # warm threads / caches
     t0 = time.time()
     passes = 0
     cnt_total = 0
@@ -84,7 +105,7 @@ def cpu_baseline(art, sd, args):
         if time.time() - t0 > args.cpu_seconds or passes >= 64:
             break
     dt = time.time() - t0
-    return {"value": round(cnt_total / dt / 1e6, 4), "unit": "Mrays/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": round(cnt_total / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": "same scene+camera at %dx%d, %d passes x 4 spp, PT_MIS depth 8, BVH closest-hit, %.1f s" % (w, h, passes, dt)}
 
 
@@ -101,6 +122,7 @@ def main():
     ap.add_argument("--kernel", default="coop", choices=["coop", "simple"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the cpu_baseline leg (0 = the job's CPU share)")
     ap.add_argument("--cpu-width", type=int, default=480)
     ap.add_argument("--cpu-height", type=int, default=270)
     ap.add_argument("--no-counters", action="store_true", help="skip the untimed B/T counting pass")

@@ -28,6 +28,29 @@ def test_test_adb_replay_writes_identical_bmp(art, tmp_path):
     assert open(out, "rb").read() == orc.bmp_bytes(orc.resolve(oacc, 1))
 
 
+def test_python_mirror_of_ray_tracer_package(art, backend):
+    """test.adb:32-69 through the Python mirror of package Ray_Tracer: Ada (x,y) buffers, screen copy, SaveBMP."""
+    import conv
+    cs = orc.CornellScene()
+    rt = art.RayTracer(backend, conv.desc_from_oracle(art, cs))
+    rt.Threads_Num = 2
+    rt.Init_Render(art.PT_MIS)
+    rt.Resize_Viewport(72, 48)
+    for _ in range(2):
+        rt.Render_Pass()
+    assert rt.GetSPP() == 16 and not rt.Finished()
+    assert rt.screen_buffer.shape == (72, 48) and rt.g_accBuff.shape == (72, 48, 3)
+    image = np.zeros((48, 72), np.uint32)
+    for y in range(48):
+        for x in range(72):
+            image[y, x] = rt.screen_buffer[x, y]                       # test.adb:63-67
+    acc, spp, _ = orc.render(cs.scene, orc.make_params(72, 48, orc.PT_MIS, True, 8, 2, seed=1), passes=2)
+    assert art.save_bmp(None, image) == orc.bmp_bytes(orc.resolve(acc, spp))
+    rt.Init_Render(art.RT_DEBUG)
+    rt.Render_Pass()
+    assert rt.Finished()
+
+
 def test_bench_contract(art):
     r = subprocess.run([sys.executable, os.path.join(art.ROOT, "bench.py"), "--scene", "c3", "--width", "256", "--height", "144", "--steps", "1",
                         "--warmup", "1", "--vthreads", "1", "--cpu-seconds", "1", "--cpu-width", "64", "--cpu-height", "36"],
