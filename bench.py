@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- Mrays/s of the render loop on MI355X (BASELINE.json metric), one JSON line on stdout.
 
-Workload (N=1 and N>1): BASELINE config C4 -- synthetic 1M random triangles + 3 rect lights inside the Cornell
+Workload (N=1 and N>1): BASELINE config C4 -- synthetic 1M random triangles + 3 sphere lights inside the Cornell
 box (SURVEY 8d generator, seed 0xADA5EED0+4), 1920x1080, PT_MIS, Max_Trace_Depth 8, 2x2 AA.  One "step" is one
-Render_Pass of `--vthreads` x 4 samples per pixel (default 16 spp); the full 256-spp render of C4 is 16 such steps.
+Render_Pass of `--vthreads` x 4 samples per pixel (default 64 spp); the full 256-spp render of C4 is the default 4 steps.
 Rays = closest-hit queries actually issued (camera + bounce + shadow).  Scene upload and BVH build are
 outside the timed region and reported separately in `config`.
 
@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--tris", type=int, default=1000000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--vthreads", type=int, default=4, help="Threads_Num of the pass: spp per step = 4 * vthreads")
+    ap.add_argument("--vthreads", type=int, default=16, help="Threads_Num of the pass: spp per step = 4 * vthreads (default 64: 4 steps = the 256-spp C4 render)")
     ap.add_argument("--kernel", default="coop", choices=["coop", "simple"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--cpu-width", type=int, default=480)
     ap.add_argument("--cpu-height", type=int, default=270)
     ap.add_argument("--no-counters", action="store_true", help="skip the untimed B/T counting pass")
+    ap.add_argument("--simulate-shard", default="", help="R/N: render only rank R's pixel tiles of an N-GPU job on this one GPU (scaling rehearsal)")
     ap.add_argument("--opt", action="append", default=[], help="backend option name=value (art_set_option), e.g. bvh_leaf_base_milli=1000")
     args = ap.parse_args()
 
@@ -162,7 +163,11 @@ def main():
         accum_t = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
         be.bind_accum(accum_t.data_ptr())
         be.set_stream(torch.cuda.current_stream().cuda_stream)
-    be.set_shard(rank, world, 32)
+    if args.simulate_shard:
+        r_, n_ = [int(v) for v in args.simulate_shard.split("/")]
+        be.set_shard(r_, n_, 32)
+    else:
+        be.set_shard(rank, world, 32)
     be.resize(W, H)
     prm = art.Backend.pass_params(art.PT_MIS, True, 8, args.vthreads, seed=1)
     spp = 0
