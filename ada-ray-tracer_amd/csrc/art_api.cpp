@@ -100,10 +100,10 @@ static int upload_scene_arrays(HostScene& hs) {
 int upload_scene(const ArtSceneDesc* d) {
   Ctx& c = g_ctx;
   if (!d) return fail("art_upload_scene: null scene");
-  if (ensure_device()) return 1;
   std::string err;
   HostScene hs;
-  if (!flatten_scene(*d, c.bvh_params, hs, err)) return fail(err);
+  if (!flatten_scene(*d, c.bvh_params, hs, err)) return fail(err);      // validation + BVH build need no GPU
+  if (ensure_device()) return 1;
   if ((uint64_t)hs.bvh.n_nodes * kNodeFloats * 4 >= (1ull << 32) || (uint64_t)hs.bvh.n_tris * kTriFloats * 4 >= (1ull << 32))
     return fail("mesh too large: the trace kernel addresses nodes and triangles with 32-bit byte offsets (max ~89M triangles)");
   if (hs.bvh.max_stack > kStackEntries) return fail("BVH traversal stack bound " + std::to_string(hs.bvh.max_stack) + " exceeds " + std::to_string(kStackEntries));

@@ -57,6 +57,8 @@ bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& o
     if (m.ntris >= (1 << 27)) { err = "scene: mesh too large (max 2^27-1 triangles)"; return false; }
     for (int64_t i = 0; i < 3 * (int64_t)m.ntris; ++i)
       if (m.idx[i] < 0 || m.idx[i] >= m.nverts) { err = "scene: triangle index out of range"; return false; }
+    for (int64_t i = 0; i < (int64_t)m.nverts; ++i)
+      if (!finite3(m.pos + 3 * i) || !finite3(m.nrm + 3 * i)) { err = "scene: non-finite mesh vertex"; return false; }
     if (m.mode == ART_MESH_REFERENCE_BF) {
       if (have_bf) { err = "scene: at most one REFERENCE_BF mesh"; return false; }
       have_bf = true;

@@ -66,16 +66,13 @@ __device__ __forceinline__ void group_min_tk(float& t, uint32_t& key) {
   }
 }
 
-// the same minimum for packed keys (bits(t) << 32 | key), t > 0: one 64-bit compare per butterfly step, no branches
 __device__ __forceinline__ uint64_t pack_tk(uint32_t tbits, uint32_t key) { return ((uint64_t)tbits << 32) | key; }
-template <int CTRL>
-__device__ __forceinline__ uint64_t dpp_u64(uint64_t v) {
-  return pack_tk((uint32_t)dpp_i<CTRL>((int)(v >> 32)), (uint32_t)dpp_i<CTRL>((int)(uint32_t)v));
-}
-__device__ __forceinline__ uint64_t group_min_u64(uint64_t k) {
-  uint64_t o = dpp_u64<DPP_XOR1>(k); k = (o < k) ? o : k;
-  o = dpp_u64<DPP_XOR2>(k); k = (o < k) ? o : k;
-  o = dpp_u64<DPP_XOR3>(dpp_u64<DPP_HALF_MIRROR>(k)); k = (o < k) ? o : k;
+
+// 32-bit unsigned minimum across the 8-lane group (every lane gets it); min ops take the DPP operand directly
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t k) {
+  k = min(k, (uint32_t)dpp_i<DPP_XOR1>((int)k));
+  k = min(k, (uint32_t)dpp_i<DPP_XOR2>((int)k));
+  k = min(k, (uint32_t)xor4_i((int)k));
   return k;
 }
 
@@ -91,7 +88,6 @@ __device__ __forceinline__ void wave_lds_sync() {
 // ------------------------------------------------------------------------------------------------
 // cooperative persistent trace kernel
 // ------------------------------------------------------------------------------------------------
-constexpr int kChunk = 64;   // rays fetched per atomic
 #ifndef ART_COOP_WAVES_PER_SIMD
 #define ART_COOP_WAVES_PER_SIMD 8   // <= 64 VGPRs: 8 waves per SIMD = 256 rays in flight per CU
 #endif
@@ -237,7 +233,10 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       const bool valid = tri_lane && pass && (tt > 0.0f) && (tt < 1000000.0f);
       const uint32_t tb = valid ? __builtin_bit_cast(uint32_t, tt) : 0x7f7fffffu;
       const uint32_t key = valid ? (KEY_TRI | (uint32_t)__builtin_bit_cast(int, q2.y)) : KEY_MISS;
-      const uint64_t win = group_min_u64(pack_tk(tb, key));
+      // lexicographic (t, key) minimum as two 32-bit reductions: smallest t, then smallest key among the lanes holding it
+      const uint32_t win_tb = group_min_u32(tb);
+      const uint32_t win_key = group_min_u32(tb == win_tb ? key : 0xffffffffu);
+      const uint64_t win = pack_tk(win_tb, win_key);
       // cand_wins for t > 0:  (t, key) < (best_t, best_key), where an equal t never displaces the initial bound
       const uint32_t bt = (best_t == 0.0f) ? 0u : __builtin_bit_cast(uint32_t, best_t);
       const uint64_t cur = pack_tk(bt, best_key == KEY_MISS ? 0u : best_key);

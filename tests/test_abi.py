@@ -57,3 +57,34 @@ def test_host_mirror_scene_init_equals_oracle(art):
         assert mats[i, 0] == s.materials[i].type and list(mats[i, 2:10]) == list(s.materials[i].p)
     assert np.array_equal(pos[:17].view(np.uint32), a["pos"].view(np.uint32))       # RotationMatrix(-Pi/6) etc. bit for bit
     assert np.array_equal(bbox[:3], a["bbmin"]) and np.array_equal(bbox[3:], a["bbmax"])
+
+
+def test_scene_validation_errors_are_reported_without_a_gpu(art):
+    """art_upload_scene validates the description before it touches the device: every malformed scene is refused with a message."""
+    from ada_ray_tracer_amd import scenes
+    L = art.load_library()
+
+    def err_of(sd):
+        rc = L.art_upload_scene(C.byref(sd.desc))
+        assert rc != 0
+        return L.art_last_error().decode()
+
+    mats = scenes.cornell_materials()
+    light = [scenes.sphere_light(0.0, 4)]
+    assert "no light" in err_of(art.SceneDesc([], [], mats, [], None))
+    assert "sphere.mat out of range" in err_of(art.SceneDesc([((0, 0, 0), 1.0, 99)], light, mats, [], None))
+    bad_light_mat = [dict(type=art.MAT_LIGHT, light=3)]
+    assert "missing light" in err_of(art.SceneDesc([], light, bad_light_mat, [], None))
+    tri = dict(mode=art.MESH_CLOSEST, pos=[[0, 0, 0], [1, 0, 0], [0, 1, 0]], nrm=[[0, 0, 1]] * 3, idx=[[0, 1, 7]], matid=[1])
+    assert "index out of range" in err_of(art.SceneDesc([], light, mats, [tri], None))
+    tri["idx"] = [[0, 1, 2]]; tri["matid"] = [55]
+    assert "material id out of range" in err_of(art.SceneDesc([], light, mats, [tri], None))
+    tri["matid"] = [1]; tri["pos"] = [[0, 0, 0], [float("nan"), 0, 0], [0, 1, 0]]
+    assert "non-finite" in err_of(art.SceneDesc([], light, mats, [tri], None))
+    tri["pos"] = [[0, 0, 0], [1, 0, 0], [0, 1, 0]]
+    two = [dict(tri), dict(tri)]
+    assert "at most one CLOSEST mesh" in err_of(art.SceneDesc([], light, mats, two, None))
+    assert "Cornell box material" in err_of(art.SceneDesc([], light, mats, [], dict(min=(0, 0, 0), max=(1, 1, 1), mat=(2, 3, 1, 1, 80, 1), nrm=scenes.CORNELL_BOX["nrm"])))
+    p = art.Backend.pass_params()
+    assert L.art_render_pass(C.byref(p), None, None, None) != 0 and "no scene" in L.art_last_error().decode()
+    assert L.art_set_option(b"no_such_option", 1) != 0 and L.art_set_shard(3, 2, 32) != 0

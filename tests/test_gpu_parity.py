@@ -305,3 +305,35 @@ def test_gcore_seam(art, backend):
     assert hit.primIndex == 1 and abs(hit.t - 5.0) < 1e-6
     assert not L.gcore_closest_hit(pos3, dirn2, 0.0, 4.0, C.byref(hit))   # beyond t_far
     L.gcore_destroy()
+
+
+def test_gcore_closest_hit_is_thread_safe(art, backend):
+    """The reference calls gcore_closest_hit concurrently from up to 28 tasks (scene_hydra_embree.adb:426-446)."""
+    import threading
+    L = backend.lib
+    rng = np.random.default_rng(3)
+    verts = (rng.random((300, 3)) * 4 - 2).astype(np.float32)
+    idx = rng.integers(0, 300, 600).astype(np.int32)
+    L.gcore_init_and_clear()
+    mid = L.gcore_add_mesh_3f(verts.ctypes.data_as(art.f32p), 300, idx.ctypes.data_as(art.i32p), 600)
+    m = np.eye(4, dtype=np.float32)
+    L.gcore_instance_meshes(mid, m.ctypes.data_as(art.f32p), 1)
+    L.gcore_commit_scene()
+    n = 64
+    o = (rng.random((n, 3)) * 2 - 1).astype(np.float32); o[:, 2] = 6.0
+    d = np.tile(np.array([0, 0, -1], np.float32), (n, 1))
+
+    def query(i):
+        h = art.HitCpp(); h.primIndex = -1
+        ok = L.gcore_closest_hit(o[i].ctypes.data_as(art.f32p), d[i].ctypes.data_as(art.f32p), 0.0, 100000.0, C.byref(h))
+        return (bool(ok), h.primIndex, h.t) if ok else (False, -1, 0.0)
+    serial = [query(i) for i in range(n)]
+    out = [None] * n
+
+    def worker(k):
+        for i in range(k, n, 8):
+            out[i] = query(i)
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert out == serial and any(s[0] for s in serial)
+    L.gcore_destroy()
