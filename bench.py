@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--cpu-width", type=int, default=480)
     ap.add_argument("--cpu-height", type=int, default=270)
     ap.add_argument("--no-counters", action="store_true", help="skip the untimed B/T counting pass")
+    ap.add_argument("--host-buffers", action="store_true", help="hand AccumBuff/screen_buffer over in host memory every pass (Ada layout), i.e. include PCIe")
     ap.add_argument("--simulate-shard", default="", help="R/N: render only rank R's pixel tiles of an N-GPU job on this one GPU (scaling rehearsal)")
     ap.add_argument("--opt", action="append", default=[], help="backend option name=value (art_set_option), e.g. bvh_leaf_base_milli=1000")
     args = ap.parse_args()
@@ -184,7 +185,11 @@ def main():
     s0 = be.stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        spp = be.render_pass_device(prm, spp)
+        if args.host_buffers:
+            prm.layout = art.LAYOUT_ADA_XY
+            _, _, spp = be.render_pass(prm, spp, True, True)
+        else:
+            spp = be.render_pass_device(prm, spp)
     if use_dist:
         be.synchronize()
         dist.reduce(accum_t, dst=0, op=dist.ReduceOp.SUM)
