@@ -508,7 +508,7 @@ int art_set_option(const char* name, int64_t value) {
   if (!name) return fail("null option");
   const std::string n(name);
   if (n == "trace_kernel") { if (value != TRACE_COOP && value != TRACE_SIMPLE) return fail("trace_kernel: 0 (cooperative) or 1 (simple)"); g_ctx.trace_kernel = (int)value; }
-  else if (n == "batch_paths") { if (value < 1024 || value > (1ll << 30)) return fail("batch_paths: 1024..2^30"); g_ctx.batch_paths = value; }
+  else if (n == "batch_paths") { if (value < 1024 || value > (1ll << 29)) return fail("batch_paths: 1024..2^29 (ray indices are 32-bit: 2 rays per path slot)"); g_ctx.batch_paths = value; }
   else if (n == "blocks_per_cu") { g_ctx.opt_blocks_per_cu = (int)value; g_ctx.blocks_per_cu = 0; }
   else if (n == "count_tests") { g_ctx.count_tests = value != 0; }
   else if (n == "shadow_anyhit") { g_ctx.shadow_anyhit = value != 0; }

@@ -48,6 +48,30 @@ def test_cornell_render_pass_bit_exact(art, backend, cornell, rt, aa):
     assert backend.stats().rays == cnt.rays
 
 
+def _tilted_camera_scene(art):
+    """Internal scene seen through a rotated + translated camera matrix (cam.matrix * dir adds the translation column,
+    vector_math.adb:137-144, before the normalize of integrators.adb:46)."""
+    cs = orc.CornellScene()
+    c, s = np.float32(np.cos(0.2)), np.float32(np.sin(0.2))
+    m = np.array([[c, 0, s, 0.05], [0, 1, 0, -0.02], [-s, 0, c, 0.01], [0, 0, 0, 1]], np.float32)
+    cs.scene.cam_matrix = (C.c_float * 16)(*[float(v) for v in m.ravel()])
+    cs.scene.cam_pos = (C.c_float * 3)(0.4, 2.4, 11.0)
+    return cs, conv.desc_from_oracle(art, cs)
+
+
+@pytest.mark.parametrize("depth,aa,bg,seed", [(3, True, (0.1, 0.2, 0.3), 1 << 40 | 5), (12, False, (0.0, 0.05, 0.0), 77), (1, True, (0.0, 0.0, 0.0), 3)])
+def test_camera_matrix_background_depth_and_wide_seed(art, backend, depth, aa, bg, seed):
+    cs, sd = _tilted_camera_scene(art)
+    backend.upload_scene(sd)
+    backend.resize(72, 56)
+    p = art.Backend.pass_params(art.PT_MIS, aa, depth, 2, seed=seed, background=bg)
+    accum, _, spp = backend.render_pass(p, 0)
+    ref, rspp, cnt = orc.render(cs.scene, orc.make_params(72, 56, orc.PT_MIS, aa, depth, 2, seed=seed, background=bg))
+    assert spp == rspp
+    assert_radiance_equal(accum, ref, spp)
+    assert backend.stats().rays == cnt.rays
+
+
 def test_two_passes_accumulate_like_reference(art, backend, cornell):
     cs, sd = cornell
     backend.upload_scene(sd)

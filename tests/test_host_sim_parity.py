@@ -37,6 +37,22 @@ def test_max_trace_depth(art, cornell, depth):
     assert np.array_equal(bits(acc), bits(ref)) and rays == cnt.rays
 
 
+def test_camera_matrix_background_and_wide_seed(art):
+    import ctypes as C
+    cs = orc.CornellScene()
+    c, s = np.float32(np.cos(0.2)), np.float32(np.sin(0.2))
+    m = np.array([[c, 0, s, 0.05], [0, 1, 0, -0.02], [-s, 0, c, 0.01], [0, 0, 0, 1]], np.float32)
+    cs.scene.cam_matrix = (C.c_float * 16)(*[float(v) for v in m.ravel()])
+    cs.scene.cam_pos = (C.c_float * 3)(0.4, 2.4, 11.0)
+    sd = conv.desc_from_oracle(art, cs)
+    seed = (1 << 40) | 5
+    p = art.Backend.pass_params(art.PT_MIS, True, 4, 2, seed=seed, background=(0.1, 0.2, 0.3))
+    acc, rays = hostsim.render(art, sd, p, 40, 32)
+    ref, _, cnt = orc.render(cs.scene, orc.make_params(40, 32, orc.PT_MIS, True, 4, 2, seed=seed, background=(0.1, 0.2, 0.3)))
+    assert np.array_equal(bits(acc), bits(ref)) and rays == cnt.rays
+    assert (ref[0, 0] >= np.float32(0.2 * 0.99)).all()        # Background_Color is added once per virtual thread (integrators.adb:42)
+
+
 def test_second_pass_continues_sample_indices(art, cornell):
     cs, sd = cornell
     p = art.Backend.pass_params(art.PT_MIS, True, 8, 1, seed=2)
