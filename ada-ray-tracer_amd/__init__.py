@@ -289,6 +289,11 @@ class Backend:
         _check(self.lib.art_trace_rays(_fp(o), _fp(d), _fp(tf), n, out, kernel, C.byref(st) if want_stats else None))
         return (out, st) if want_stats else out
 
+    def bvh_info(self):
+        info = ArtBvhInfo()
+        _check(self.lib.art_export_bvh(None, 0, None, 0, C.byref(info)))
+        return info
+
     def export_bvh(self):
         info = ArtBvhInfo()
         _check(self.lib.art_export_bvh(None, 0, None, 0, C.byref(info)))

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "art_api_internal.h"
+#include "art_lbvh.h"
 
 namespace art {
 
@@ -81,8 +82,8 @@ static int upload_scene_arrays(HostScene& hs) {
   Ctx& c = g_ctx;
   if (upload(c.b_spheres, hs.spheres) || upload(c.b_sphere_mat, hs.sphere_mat) || upload(c.b_lights, hs.lights) ||
       upload(c.b_materials, hs.materials) || upload(c.b_bf_pos, hs.bf_pos) || upload(c.b_bf_nrm, hs.bf_nrm) ||
-      upload(c.b_bf_uv, hs.bf_uv) || upload(c.b_bf_idx, hs.bf_idx) || upload(c.b_nodes, hs.bvh.nodes) ||
-      upload(c.b_tris, hs.bvh.tris) || upload(c.b_m_nrm, hs.m_nrm) || upload(c.b_m_uv, hs.m_uv) ||
+      upload(c.b_bf_uv, hs.bf_uv) || upload(c.b_bf_idx, hs.bf_idx) || (!hs.gpu_built && upload(c.b_nodes, hs.bvh.nodes)) ||
+      (!hs.gpu_built && upload(c.b_tris, hs.bvh.tris)) || upload(c.b_m_nrm, hs.m_nrm) || upload(c.b_m_uv, hs.m_uv) ||
       upload(c.b_m_idx, hs.m_idx) || upload(c.b_m_matid, hs.m_matid))
     return 1;
   DevScene& s = c.scene;
@@ -104,6 +105,21 @@ int upload_scene(const ArtSceneDesc* d) {
   HostScene hs;
   if (!flatten_scene(*d, c.bvh_params, hs, err)) return fail(err);      // validation + BVH build need no GPU
   if (ensure_device()) return 1;
+  if (!hs.deferred_tri9.empty()) {            // option bvh_builder = 1: LBVH built in HBM
+    DevBuf tri9;
+    if (upload(tri9, hs.deferred_tri9)) return 1;
+    GpuBvh g;
+    const bool ok = build_bvh8_gpu((const float*)tri9.p, (int)(hs.deferred_tri9.size() / 9), c.bvh_params, c.stream, g, err);
+    tri9.release();
+    if (!ok) { if (g.nodes) (void)hipFree(g.nodes); if (g.tris) (void)hipFree(g.tris); return fail("GPU BVH build: " + err); }
+    c.b_nodes.release(); c.b_tris.release();
+    c.b_nodes.p = g.nodes; c.b_nodes.bytes = (size_t)g.n_nodes * kNodeFloats * 4;
+    c.b_tris.p = g.tris; c.b_tris.bytes = (size_t)g.n_tris * kTriFloats * 4;
+    hs.bvh.n_nodes = g.n_nodes; hs.bvh.n_tris = g.n_tris; hs.bvh.max_stack = g.max_stack;
+    hs.hdr.n_nodes = g.n_nodes; hs.hdr.n_tris = g.n_tris;
+    hs.bvh_build_ms = g.build_ms; hs.gpu_built = true;
+    std::vector<float>().swap(hs.deferred_tri9);
+  }
   if ((uint64_t)hs.bvh.n_nodes * kNodeFloats * 4 >= (1ull << 32) || (uint64_t)hs.bvh.n_tris * kTriFloats * 4 >= (1ull << 32))
     return fail("mesh too large: the trace kernel addresses nodes and triangles with 32-bit byte offsets (max ~89M triangles)");
   if (hs.bvh.max_stack > kStackEntries) return fail("BVH traversal stack bound " + std::to_string(hs.bvh.max_stack) + " exceeds " + std::to_string(kStackEntries));
@@ -488,7 +504,12 @@ int art_trace_rays(const float* origins, const float* dirs, const float* tfar, i
 int art_export_bvh(float* nodes, int64_t node_cap, float* tris, int64_t tri_cap, ArtBvhInfo* info) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_ctx.scene_ready) return fail("no scene uploaded");
-  const Bvh8& b = g_ctx.host_scene.bvh;
+  Bvh8& b = g_ctx.host_scene.bvh;
+  if (g_ctx.host_scene.gpu_built && b.nodes.empty() && (nodes || tris)) {     // the GPU-built tree is fetched on first request
+    b.nodes.resize((size_t)b.n_nodes * kNodeFloats); b.tris.resize((size_t)b.n_tris * kTriFloats);
+    HIP_TRY(hipMemcpy(b.nodes.data(), g_ctx.b_nodes.p, b.nodes.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(b.tris.data(), g_ctx.b_tris.p, b.tris.size() * 4, hipMemcpyDeviceToHost));
+  }
   if (info) { info->n_nodes = b.n_nodes; info->n_tris = b.n_tris; info->max_stack = b.max_stack; info->reserved = 0; info->build_ms = g_ctx.host_scene.bvh_build_ms; }
   if (nodes) { if (node_cap < (int64_t)b.nodes.size()) return fail("art_export_bvh: node buffer too small"); std::memcpy(nodes, b.nodes.data(), b.nodes.size() * 4); }
   if (tris) { if (tri_cap < (int64_t)b.tris.size()) return fail("art_export_bvh: triangle buffer too small"); std::memcpy(tris, b.tris.data(), b.tris.size() * 4); }
@@ -515,6 +536,7 @@ int art_set_option(const char* name, int64_t value) {
   else if (n == "ray_chunk") { if (value < 8 || value > 4096) return fail("ray_chunk: 8..4096"); g_ctx.ray_chunk = (int)value; }
   else if (n == "node_min") { if (value < 1 || value > 8) return fail("node_min: 1..8"); g_ctx.node_min = (int)value; }
   else if (n == "bvh_max_leaf") { if (value < 1 || value > kMaxLeafTris) return fail("bvh_max_leaf: 1..8"); g_ctx.bvh_params.max_leaf = (int)value; }
+  else if (n == "bvh_builder") { if (value < 0 || value > 1) return fail("bvh_builder: 0 host SAH, 1 GPU LBVH"); g_ctx.bvh_params.builder = (int)value; }
   else if (n == "bvh_leaf_base_milli") { g_ctx.bvh_params.leaf_base = (float)value / 1000.0f; }
   else if (n == "bvh_tri_cost_milli") { g_ctx.bvh_params.tri_cost = (float)value / 1000.0f; }
   else if (n == "bvh_node_cost_milli") { g_ctx.bvh_params.node_cost = (float)value / 1000.0f; }

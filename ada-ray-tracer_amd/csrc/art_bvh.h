@@ -18,6 +18,7 @@ struct BvhBuildParams {
   int   parallel_depth = 3;      // top levels built by std::async tasks
   float inflate_rel = 8.0e-6f;   // conservative padding of child boxes (relative to |coordinate|)
   float inflate_abs = 1.0e-6f;
+  int   builder = 0;             // 0: binned SAH on the host (art_bvh.cpp); 1: LBVH on the GPU (art_lbvh.hip), needs >= 2 triangles
   float leaf_cost(int n) const { return leaf_base + tri_cost * (float)n; }
 };
 

@@ -20,6 +20,8 @@ struct HostScene {
   std::vector<float> m_nrm, m_uv; std::vector<int32_t> m_idx, m_matid;
   std::vector<float> m_pos;   // kept for gcore-style geometric normals / export
   Bvh8 bvh;
+  std::vector<float> deferred_tri9;   // builder == 1: triangle corners for the GPU build (bvh stays empty until then)
+  bool gpu_built = false;             // nodes / tris live only in HBM (art_export_bvh copies them back on demand)
   double bvh_build_ms = 0.0;
   DevScene hdr;               // scalar part; pointer members are filled by the owner (host or device addresses)
 };

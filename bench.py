@@ -156,7 +156,7 @@ def main():
     t0 = time.time()
     be.upload_scene(sd)
     t_upload = time.time() - t0
-    info = be.export_bvh()[2]
+    info = be.bvh_info()
 
     W, H = args.width, args.height
     accum_t = None
@@ -250,7 +250,7 @@ def main():
             "config": {"workload": "%s, %dx%d, PT_MIS depth 8, 2x2 AA, %d spp per step" % (scene_name, W, H, 4 * args.vthreads),
                        "spp_per_step": 4 * args.vthreads, "rays_per_sample": round(total_rays / max(1.0, total_samples), 3),
                        "Msamples_per_s": round(total_samples / elapsed / 1e6, 3), "parallelism": "pixel-tiles x%d" % world,
-                       "bvh_nodes": info.n_nodes, "bvh_build_ms": round(info.build_ms, 1), "scene_gen_s": round(t_gen, 2),
+                       "bvh_nodes": info.n_nodes, "bvh_build_ms": round(info.build_ms, 1), "bvh_max_stack": info.max_stack, "scene_gen_s": round(t_gen, 2),
                        "scene_upload_s": round(t_upload, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -1,0 +1,144 @@
+"""SURVEY 8(f) rank 1 -- the BVH built ON the GPU (option bvh_builder = 1, csrc/art_lbvh.hip) in place of Embree's
+rtcCommitScene (embree_connect.cpp:241-244).  The bar is the same as for the host build: the tree may be any tree, the
+search result may not change -- hits bit-identical to the oracle's brute-force scan, images bit-identical to the ones
+rendered through the host-built tree, and the exported tree is structurally sound (every triangle exactly once, every
+child box encloses what hangs below it)."""
+import numpy as np
+import pytest
+
+import conv
+import orc
+from test_gpu_parity import _assert_hits_equal, _random_rays, bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def gpu_builder(backend):
+    backend.set_option("bvh_builder", 1)
+    yield backend
+    backend.set_option("bvh_builder", 0)
+
+
+def _check_tree(nodes, tris, info, mesh_pos, mesh_idx):
+    nodes = nodes.reshape(-1, 64); tris = tris.reshape(-1, 12)
+    n = tris.shape[0]
+    prim = tris[:, 9].view(np.int32)
+    assert np.array_equal(np.sort(prim), np.arange(n)), "triangle records are not a permutation of the input"
+    corners = mesh_pos.reshape(-1, 3)[mesh_idx.reshape(-1, 3)[prim]].reshape(n, 9)
+    assert np.array_equal(tris[:, :9].view(np.uint32), corners.astype(np.float32).view(np.uint32))
+    tlo = tris[:, :9].reshape(n, 3, 3).min(axis=1); thi = tris[:, :9].reshape(n, 3, 3).max(axis=1)
+    seen = np.zeros(n, np.int32)
+    visited = np.zeros(nodes.shape[0], np.int32)
+    max_depth_stack = 0
+
+    def walk(ni, stack_before):
+        nonlocal max_depth_stack
+        visited[ni] += 1
+        nd = nodes[ni]
+        ref = nd[3:32:4].view(np.int32); cnt = nd[35:64:4].view(np.int32)
+        nch = int((ref >= 0).sum())
+        assert nch >= 1 and np.all(ref[:nch] >= 0) and np.all(ref[nch:] < 0), "children are not packed to the front"
+        here = stack_before + nch - 1
+        max_depth_stack = max(max_depth_stack, here + 1)
+        lo_all = np.full(3, np.inf, np.float32); hi_all = np.full(3, -np.inf, np.float32)
+        for j in range(nch):
+            lo = nd[4 * j:4 * j + 3]; hi = nd[32 + 4 * j:32 + 4 * j + 3]
+            if cnt[j] > 0:
+                assert cnt[j] <= 8
+                r = slice(int(ref[j]), int(ref[j]) + int(cnt[j]))
+                seen[r] += 1
+                clo, chi = tlo[r].min(axis=0), thi[r].max(axis=0)
+            else:
+                clo, chi = walk(int(ref[j]), here)
+            assert np.all(lo < clo) and np.all(hi > chi), "child box does not strictly enclose its subtree"
+            lo_all = np.minimum(lo_all, clo); hi_all = np.maximum(hi_all, chi)
+        return lo_all, hi_all
+
+    import sys
+    sys.setrecursionlimit(10000)
+    walk(0, 0)
+    assert np.all(seen == 1), "a triangle is referenced %s times" % np.unique(seen)
+    assert np.all(visited == 1) and nodes.shape[0] == info.n_nodes
+    assert max_depth_stack <= info.max_stack, "stack bound %d below the real worst case %d" % (info.max_stack, max_depth_stack)
+
+
+@pytest.mark.parametrize("ntris", [2, 9, 1000, 50000])
+def test_lbvh_tree_is_well_formed(art, gpu_builder, ntris):
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.synthetic_scene(ntris, 3)
+    gpu_builder.upload_scene(sd)
+    nodes, tris, info = gpu_builder.export_bvh()
+    assert info.n_tris == ntris and info.build_ms > 0.0
+    pos, _, idx, _, _ = [a for a, m in zip(sd._mesh_arrays, sd.meshes) if m.mode == art.MESH_CLOSEST][0]
+    _check_tree(nodes, tris, info, pos, idx)
+
+
+@pytest.mark.parametrize("kernel", ["TRACE_COOP", "TRACE_SIMPLE"])
+@pytest.mark.parametrize("ntris", [2, 9, 300, 20000])
+def test_lbvh_hits_match_brute_force(art, gpu_builder, kernel, ntris):
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.synthetic_scene(ntris, 3)
+    osc = conv.OracleScene(sd)
+    gpu_builder.upload_scene(sd)
+    o, d = _random_rays(30000, ntris + 1)
+    _assert_hits_equal(gpu_builder.trace_rays(o, d, kernel=getattr(art, kernel)), orc.closest_hits(osc.scene, o, d))
+
+
+def test_lbvh_equal_morton_codes_and_duplicate_triangles(art, gpu_builder):
+    """Many triangles with the same centroid (equal Morton codes: the radix tree falls back to the sorted position) and exact
+    duplicates (equal t: the lowest triangle index must win, as in the oracle's index-order scan)."""
+    from ada_ray_tracer_amd import scenes
+    mesh = scenes.random_triangles(64, 5)
+    pos = np.asarray(mesh["pos"], np.float32).reshape(-1, 3); idx = np.asarray(mesh["idx"], np.int32).reshape(-1, 3)
+    reps = 40
+    pos2 = np.tile(pos, (reps, 1)); idx2 = np.concatenate([idx + k * pos.shape[0] for k in range(reps)])
+    m2 = dict(mesh); m2["pos"] = pos2.ravel(); m2["nrm"] = np.tile(np.asarray(mesh["nrm"], np.float32).reshape(-1, 3), (reps, 1)).ravel()
+    m2["idx"] = idx2.ravel(); m2["matid"] = np.tile(np.asarray(mesh["matid"], np.int32), reps)
+    mats = scenes.cornell_materials()
+    lights = [dict(shape=art.LIGHT_SPHERE, mat=4, center=(0.0, 4.5, 1.0), radius=0.5, intensity=(10.0, 10.0, 10.0), surfaceArea=3.14159)]
+    sd = art.SceneDesc([], lights, mats, [m2], None, scenes.REFERENCE_CAMERA)
+    osc = conv.OracleScene(sd)
+    gpu_builder.upload_scene(sd)
+    o, d = _random_rays(20000, 4)
+    gh = gpu_builder.trace_rays(o, d); oh = orc.closest_hits(osc.scene, o, d)
+    _assert_hits_equal(gh, oh)
+    prim = np.array([h.prim_index for h in gh if h.is_hit])
+    assert prim.size > 100 and prim.max() < 64, "a duplicate with a higher index won a tie"
+
+
+def test_lbvh_counters_match_oracle_walk_of_the_exported_tree(art, gpu_builder):
+    from ada_ray_tracer_amd import scenes
+    mesh = scenes.random_triangles(20000, 78)
+    mats = scenes.cornell_materials()
+    lights = [dict(shape=art.LIGHT_SPHERE, mat=4, center=(0.0, 4.5, 1.0), radius=0.5, intensity=(10.0, 10.0, 10.0), surfaceArea=3.14159)]
+    sd = art.SceneDesc([], lights, mats, [mesh], None, scenes.REFERENCE_CAMERA)
+    gpu_builder.upload_scene(sd)
+    nodes, tris, info = gpu_builder.export_bvh()
+    o, d = _random_rays(40000, 9)
+    t, prim, cnt = orc.bvh_walk(nodes, tris, o, d)
+    for kernel in (art.TRACE_COOP, art.TRACE_SIMPLE):
+        hits, st = gpu_builder.trace_rays(o, d, kernel=kernel, want_stats=True)
+        gprim = np.array([h.prim_index if h.is_hit else -1 for h in hits], np.int32)
+        assert np.array_equal(gprim, prim)
+        assert (st.box_tests, st.tri_tests, st.node_visits, st.leaf_visits) == (cnt.box_tests, cnt.tri_tests, cnt.node_visits, cnt.leaf_visits)
+
+
+@pytest.mark.parametrize("config", ["c3", "c5"])
+def test_image_does_not_depend_on_the_builder(art, backend, config):
+    """Same scene through the host SAH tree and the GPU LBVH tree: the accum buffers are bit-identical and so are the ray
+    counts (the closest hit is a minimum over (t, key) whatever the traversal order)."""
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.synthetic_scene(100000, 3) if config == "c3" else scenes.mixed_scene(20000, 5)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=21)
+    out = []
+    try:
+        for builder in (0, 1):
+            backend.set_option("bvh_builder", builder)
+            backend.upload_scene(sd)
+            backend.resize(160, 90)
+            accum, screen, spp = backend.render_pass(p, 0, want_screen=True)
+            out.append((accum.copy(), screen.copy(), backend.stats().rays))
+    finally:
+        backend.set_option("bvh_builder", 0)
+    assert np.array_equal(bits(out[0][0]), bits(out[1][0])) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
