@@ -536,6 +536,7 @@ int art_set_option(const char* name, int64_t value) {
   else if (n == "ray_chunk") { if (value < 8 || value > 4096) return fail("ray_chunk: 8..4096"); g_ctx.ray_chunk = (int)value; }
   else if (n == "node_min") { if (value < 1 || value > 8) return fail("node_min: 1..8"); g_ctx.node_min = (int)value; }
   else if (n == "bvh_max_leaf") { if (value < 1 || value > kMaxLeafTris) return fail("bvh_max_leaf: 1..8"); g_ctx.bvh_params.max_leaf = (int)value; }
+  else if (n == "bvh_spatial_splits") { g_ctx.bvh_params.spatial_alpha = value ? 1.0e-5f : -1.0f; }   // host builder: SBVH reference splitting
   else if (n == "bvh_builder") { if (value < 0 || value > 1) return fail("bvh_builder: 0 host SAH, 1 GPU LBVH"); g_ctx.bvh_params.builder = (int)value; }
   else if (n == "bvh_leaf_base_milli") { g_ctx.bvh_params.leaf_base = (float)value / 1000.0f; }
   else if (n == "bvh_tri_cost_milli") { g_ctx.bvh_params.tri_cost = (float)value / 1000.0f; }

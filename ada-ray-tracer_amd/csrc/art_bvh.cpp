@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstring>
 #include <future>
+#include <mutex>
 #include <numeric>
 
 namespace art {
@@ -32,33 +33,88 @@ struct Node2 {            // BVH2 node; leaf when count > 0
   int32_t first = 0, count = 0;
 };
 
+struct Ref { Box box; int32_t tri; };   // a (possibly clipped) reference to a triangle
+
+// bounds of (triangle  intersected with  the slab p0 <= x[a] <= p1), rounded outwards to binary32.  The clipped polygon's
+// corners are the triangle corners inside the slab plus the edge/plane crossings, so their bounds are the polygon's bounds.
+static bool clip_bounds(const float* tri, int a, double p0, double p1, Box& out) {
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  auto grow = [&](const double* p) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } };
+  for (int i = 0; i < 3; ++i) {
+    const float* u = tri + 3 * i; const float* v = tri + 3 * ((i + 1) % 3);
+    const double ua = u[a], va = v[a];
+    if (ua >= p0 && ua <= p1) { const double p[3] = {u[0], u[1], u[2]}; grow(p); }
+    for (int s = 0; s < 2; ++s) {
+      const double pl = s ? p1 : p0;
+      if (!std::isfinite(pl)) continue;
+      if ((ua < pl && va > pl) || (ua > pl && va < pl)) {
+        const double t = (pl - ua) / (va - ua);
+        double p[3] = {u[0] + t * ((double)v[0] - u[0]), u[1] + t * ((double)v[1] - u[1]), u[2] + t * ((double)v[2] - u[2])};
+        p[a] = pl;
+        grow(p);
+      }
+    }
+  }
+  if (!(lo[0] <= hi[0])) return false;
+  for (int k = 0; k < 3; ++k) {
+    float l = (float)lo[k], h = (float)hi[k];
+    if ((double)l > lo[k]) l = std::nextafterf(l, -INFINITY);
+    if ((double)h < hi[k]) h = std::nextafterf(h, INFINITY);
+    out.lo[k] = l; out.hi[k] = h;
+  }
+  return true;
+}
+
+static bool intersect(Box& b, const Box& o) {
+  for (int k = 0; k < 3; ++k) { b.lo[k] = std::max(b.lo[k], o.lo[k]); b.hi[k] = std::min(b.hi[k], o.hi[k]); if (b.lo[k] > b.hi[k]) return false; }
+  return true;
+}
+
 struct Builder {
   const float* tri;       // 9 floats per triangle
   int32_t n;
-  std::vector<Box> tbox;
-  std::vector<float> cen; // 3 per triangle
-  std::vector<int32_t> order;
   std::vector<Node2> nodes;
+  std::vector<int32_t> leaf_ids;   // triangle ids of all leaves, appended leaf by leaf
+  std::mutex leaf_mu;
   std::atomic<int32_t> next_node{0};
+  std::atomic<int64_t> spatial_budget{0};   // extra references spatial splits may still create
+  float root_area = 0.0f;
   BvhBuildParams prm;
 
   int32_t alloc_node() { return next_node.fetch_add(1); }
 
-  // build subtree over order[first, first+count); returns node index
-  int32_t build(int32_t first, int32_t count, int depth, int par_depth) {
+  // build the subtree over `refs` (consumed); returns the node index
+  int32_t build(std::vector<Ref>& refs, int depth, int par_depth) {
     const int32_t id = alloc_node();
+    const int32_t count = (int32_t)refs.size();
     Node2 nd;
     nd.box.reset();
     Box cb; cb.reset();
-    for (int32_t i = first; i < first + count; ++i) {
-      nd.box.grow(tbox[order[i]]);
-      cb.grow(&cen[3 * (size_t)order[i]]);
+    for (const Ref& r : refs) {
+      nd.box.grow(r.box);
+      const float c[3] = {0.5f * r.box.lo[0] + 0.5f * r.box.hi[0], 0.5f * r.box.lo[1] + 0.5f * r.box.hi[1], 0.5f * r.box.lo[2] + 0.5f * r.box.hi[2]};
+      cb.grow(c);
     }
-    auto make_leaf = [&]() { nd.first = first; nd.count = count; nodes[id] = nd; return id; };
+    if (depth == 0) root_area = nd.box.half_area();
+    auto make_leaf = [&]() {
+      std::vector<int32_t> ids; ids.reserve(refs.size());
+      for (const Ref& r : refs) ids.push_back(r.tri);
+      std::sort(ids.begin(), ids.end());                       // ascending prim order: deterministic, and the order the leaf is tested in
+      ids.erase(std::unique(ids.begin(), ids.end()), ids.end());   // two pieces of one triangle may meet again in a leaf
+      {
+        std::lock_guard<std::mutex> lk(leaf_mu);
+        nd.first = (int32_t)leaf_ids.size(); nd.count = (int32_t)ids.size();
+        leaf_ids.insert(leaf_ids.end(), ids.begin(), ids.end());
+      }
+      nodes[id] = nd; return id;
+    };
     if (count <= 1) return make_leaf();
+    auto cen_of = [](const Ref& r, int a) { return 0.5f * r.box.lo[a] + 0.5f * r.box.hi[a]; };
 
+    // ---- object split: binned SAH over the reference centroids
     constexpr int NB = 32;
     float best_cost = INFINITY; int best_axis = -1, best_bin = -1;
+    Box best_lbox, best_rbox; best_lbox.reset(); best_rbox.reset();
     const float parent_area = nd.box.half_area();
     for (int a = 0; a < 3; ++a) {
       const float ext = cb.hi[a] - cb.lo[a];
@@ -66,56 +122,122 @@ struct Builder {
       Box bb[NB]; int32_t bc[NB];
       for (int b = 0; b < NB; ++b) { bb[b].reset(); bc[b] = 0; }
       const float scale = (float)NB / ext;
-      for (int32_t i = first; i < first + count; ++i) {
-        const int32_t t = order[i];
-        int b = (int)((cen[3 * (size_t)t + a] - cb.lo[a]) * scale);
+      for (const Ref& r : refs) {
+        int b = (int)((cen_of(r, a) - cb.lo[a]) * scale);
         b = std::min(std::max(b, 0), NB - 1);
-        bb[b].grow(tbox[t]); bc[b]++;
+        bb[b].grow(r.box); bc[b]++;
       }
-      float la[NB]; int32_t lc[NB];
+      float la[NB]; int32_t lc[NB]; Box lb[NB];
       Box acc; acc.reset(); int32_t c = 0;
-      for (int b = 0; b < NB - 1; ++b) { acc.grow(bb[b]); c += bc[b]; la[b] = acc.half_area(); lc[b] = c; }
+      for (int b = 0; b < NB - 1; ++b) { acc.grow(bb[b]); c += bc[b]; la[b] = acc.half_area(); lc[b] = c; lb[b] = acc; }
       acc.reset(); c = 0;
       for (int b = NB - 1; b >= 1; --b) {
         acc.grow(bb[b]); c += bc[b];
         if (lc[b - 1] == 0 || c == 0) continue;
         const float cost = la[b - 1] * prm.leaf_cost((int)lc[b - 1]) + acc.half_area() * prm.leaf_cost((int)c);
-        if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+        if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; best_lbox = lb[b - 1]; best_rbox = acc; }
       }
     }
+
+    // ---- spatial split (Stich et al. 2009): only where the children of the object split overlap noticeably
+    int sp_axis = -1; double sp_plane = 0.0; float sp_cost = INFINITY; int32_t sp_nl = 0, sp_nr = 0;
+    if (prm.spatial_alpha >= 0.0f && best_axis >= 0 && spatial_budget.load(std::memory_order_relaxed) > 0 && depth <= prm.max_sah_depth) {
+      Box ov = best_lbox;
+      const bool overlap = intersect(ov, best_rbox);
+      if (overlap && ov.half_area() > prm.spatial_alpha * root_area) {
+        const int NS = std::min(std::max(prm.spatial_bins, 2), 32);
+        for (int a = 0; a < 3; ++a) {
+          const double lo = nd.box.lo[a], ext = (double)nd.box.hi[a] - lo;
+          if (!(ext > 0.0)) continue;
+          Box bb[32]; int32_t en[32], ex[32];
+          for (int b = 0; b < NS; ++b) { bb[b].reset(); en[b] = 0; ex[b] = 0; }
+          const double scale = NS / ext;
+          auto plane = [&](int k) { return lo + ext * ((double)k / NS); };
+          for (const Ref& r : refs) {
+            int b0 = std::min(std::max((int)(((double)r.box.lo[a] - lo) * scale), 0), NS - 1);
+            int b1 = std::min(std::max((int)(((double)r.box.hi[a] - lo) * scale), 0), NS - 1);
+            if (b1 < b0) b1 = b0;
+            if (b0 == b1) bb[b0].grow(r.box);
+            else
+              for (int b = b0; b <= b1; ++b) {
+                Box cbx;
+                if (clip_bounds(tri + 9 * (size_t)r.tri, a, plane(b), plane(b + 1), cbx) && intersect(cbx, r.box)) bb[b].grow(cbx);
+              }
+            en[b0]++; ex[b1]++;
+          }
+          float la[32]; int32_t lc[32];
+          Box acc; acc.reset(); int32_t c = 0;
+          for (int b = 0; b < NS - 1; ++b) { acc.grow(bb[b]); c += en[b]; la[b] = acc.half_area(); lc[b] = c; }
+          acc.reset(); c = 0;
+          for (int b = NS - 1; b >= 1; --b) {
+            acc.grow(bb[b]); c += ex[b];
+            if (lc[b - 1] == 0 || c == 0 || lc[b - 1] >= count || c >= count) continue;
+            const float cost = la[b - 1] * prm.leaf_cost((int)lc[b - 1]) + acc.half_area() * prm.leaf_cost((int)c);
+            if (cost < sp_cost) { sp_cost = cost; sp_axis = a; sp_plane = plane(b); sp_nl = lc[b - 1]; sp_nr = c; }
+          }
+        }
+      }
+    }
+    const bool use_spatial = sp_axis >= 0 && sp_cost < best_cost;
+    const float chosen_cost = use_spatial ? sp_cost : best_cost;
+
     const bool can_leaf = count <= prm.max_leaf;
     if (best_axis >= 0 && can_leaf) {
-      const float split_cost = prm.node_cost * parent_area + best_cost;
+      const float split_cost = prm.node_cost * parent_area + chosen_cost;
       if (!(split_cost < parent_area * prm.leaf_cost(count))) return make_leaf();
     }
-    int32_t mid;
-    if (best_axis < 0 || depth > prm.max_sah_depth) {
-      if (can_leaf && best_axis < 0) return make_leaf();
-      // degenerate centroids or depth guard: median split by index on the widest box axis
-      int a = 0;
-      for (int k = 1; k < 3; ++k) if (nd.box.hi[k] - nd.box.lo[k] > nd.box.hi[a] - nd.box.lo[a]) a = k;
-      mid = first + count / 2;
-      std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
-                       [&](int32_t x, int32_t y) { return cen[3 * (size_t)x + a] < cen[3 * (size_t)y + a] || (cen[3 * (size_t)x + a] == cen[3 * (size_t)y + a] && x < y); });
-    } else {
-      const float ext = cb.hi[best_axis] - cb.lo[best_axis];
-      const float scale = (float)NB / ext;
-      auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](int32_t t) {
-        int b = (int)((cen[3 * (size_t)t + best_axis] - cb.lo[best_axis]) * scale);
-        b = std::min(std::max(b, 0), NB - 1);
-        return b < best_bin;
-      });
-      mid = (int32_t)(it - order.begin());
-      if (mid == first || mid == first + count) mid = first + count / 2;
+    std::vector<Ref> left, right;
+    bool done = false;
+    if (use_spatial && spatial_budget.fetch_sub((int64_t)(sp_nl + sp_nr - count), std::memory_order_relaxed) > 0) {
+      const int a = sp_axis;
+      left.reserve(sp_nl + 8); right.reserve(sp_nr + 8);
+      for (const Ref& r : refs) {
+        if ((double)r.box.hi[a] <= sp_plane) left.push_back(r);
+        else if ((double)r.box.lo[a] >= sp_plane) right.push_back(r);
+        else {
+          Ref l = r, q = r;
+          const bool hl = clip_bounds(tri + 9 * (size_t)r.tri, a, -INFINITY, sp_plane, l.box) && intersect(l.box, r.box);
+          const bool hr = clip_bounds(tri + 9 * (size_t)r.tri, a, sp_plane, INFINITY, q.box) && intersect(q.box, r.box);
+          if (hl) left.push_back(l);
+          if (hr) right.push_back(q);
+          if (!hl && !hr) left.push_back(r);   // cannot happen for a finite triangle; keep the reference rather than lose it
+        }
+      }
+      done = !left.empty() && !right.empty() && (int32_t)left.size() < count && (int32_t)right.size() < count;
+      if (!done) { left.clear(); right.clear(); }
     }
-    const int32_t nl = mid - first, nr = count - nl;
+    if (!done) {
+      int32_t mid;
+      if (best_axis < 0 || depth > prm.max_sah_depth) {
+        if (can_leaf && best_axis < 0) return make_leaf();
+        // degenerate centroids or depth guard: median split by index on the widest box axis
+        int a = 0;
+        for (int k = 1; k < 3; ++k) if (nd.box.hi[k] - nd.box.lo[k] > nd.box.hi[a] - nd.box.lo[a]) a = k;
+        mid = count / 2;
+        std::nth_element(refs.begin(), refs.begin() + mid, refs.end(),
+                         [&](const Ref& x, const Ref& y) { const float cx = cen_of(x, a), cy = cen_of(y, a); return cx < cy || (cx == cy && x.tri < y.tri); });
+      } else {
+        const float ext = cb.hi[best_axis] - cb.lo[best_axis];
+        const float scale = (float)NB / ext;
+        auto it = std::partition(refs.begin(), refs.end(), [&](const Ref& r) {
+          int b = (int)((cen_of(r, best_axis) - cb.lo[best_axis]) * scale);
+          b = std::min(std::max(b, 0), NB - 1);
+          return b < best_bin;
+        });
+        mid = (int32_t)(it - refs.begin());
+        if (mid == 0 || mid == count) mid = count / 2;
+      }
+      left.assign(refs.begin(), refs.begin() + mid);
+      right.assign(refs.begin() + mid, refs.end());
+    }
+    std::vector<Ref>().swap(refs);
     if (par_depth > 0 && count > 20000) {
-      auto fut = std::async(std::launch::async, [&, first, nl, depth, par_depth]() { return build(first, nl, depth + 1, par_depth - 1); });
-      nd.right = build(mid, nr, depth + 1, par_depth - 1);
+      auto fut = std::async(std::launch::async, [&, depth, par_depth]() { return build(left, depth + 1, par_depth - 1); });
+      nd.right = build(right, depth + 1, par_depth - 1);
       nd.left = fut.get();
     } else {
-      nd.left = build(first, nl, depth + 1, 0);
-      nd.right = build(mid, nr, depth + 1, 0);
+      nd.left = build(left, depth + 1, 0);
+      nd.right = build(right, depth + 1, 0);
     }
     nodes[id] = nd;
     return id;
@@ -132,20 +254,20 @@ bool build_bvh8(const float* tri9, const int32_t* prim_ids, int32_t n, const Bvh
   if (n <= 0) return true;
   Builder B;
   B.tri = tri9; B.n = n; B.prm = prm;
-  B.tbox.resize(n); B.cen.resize(3 * (size_t)n); B.order.resize(n);
+  std::vector<Ref> refs((size_t)n);
   for (int32_t i = 0; i < n; ++i) {
     Box b; b.reset();
     const float* t = tri9 + 9 * (size_t)i;
     b.grow(t); b.grow(t + 3); b.grow(t + 6);
-    for (int a = 0; a < 3; ++a) {
+    for (int a = 0; a < 3; ++a)
       if (!std::isfinite(b.lo[a]) || !std::isfinite(b.hi[a])) { err = "non-finite triangle vertex"; return false; }
-      B.cen[3 * (size_t)i + a] = 0.5f * b.lo[a] + 0.5f * b.hi[a];
-    }
-    B.tbox[i] = b;
+    refs[i].box = b; refs[i].tri = i;
   }
-  std::iota(B.order.begin(), B.order.end(), 0);
-  B.nodes.resize(2 * (size_t)n);
-  const int32_t root = B.build(0, n, 0, prm.parallel_depth);
+  const int64_t budget = (prm.spatial_alpha >= 0.0f) ? (int64_t)((double)prm.spatial_budget * n) : 0;
+  B.spatial_budget = budget;
+  B.nodes.resize(2 * ((size_t)n + (size_t)budget + 64) + 2);   // every split makes progress, so nodes <= 2 * references
+  B.leaf_ids.reserve((size_t)n + (size_t)budget);
+  const int32_t root = B.build(refs, 0, prm.parallel_depth);
   (void)root;
 
   // ---- collapse to 8-wide
@@ -157,9 +279,8 @@ bool build_bvh8(const float* tri9, const int32_t* prim_ids, int32_t n, const Bvh
   auto emit_leaf_tris = [&](const Node2& lf) -> int32_t {
     const int32_t first = (int32_t)(out.tris.size() / kTriFloats);
     // triangles inside a leaf are stored in ascending prim order (deterministic, and the order the leaf is tested in)
-    std::vector<int32_t> ids(B.order.begin() + lf.first, B.order.begin() + lf.first + lf.count);
-    std::sort(ids.begin(), ids.end());
-    for (int32_t t : ids) {
+    for (int32_t k = lf.first; k < lf.first + lf.count; ++k) {
+      const int32_t t = B.leaf_ids[k];
       float rec[kTriFloats];
       std::memcpy(rec, tri9 + 9 * (size_t)t, 9 * sizeof(float));
       const int32_t pid = prim_ids ? prim_ids[t] : t;
@@ -222,7 +343,7 @@ bool build_bvh8(const float* tri9, const int32_t* prim_ids, int32_t n, const Bvh
   out.n_nodes = (int32_t)(N.size() / kNodeFloats);
   out.n_tris = (int32_t)(out.tris.size() / kTriFloats);
   out.max_stack = max_stack;
-  if (out.n_tris != n) { err = "internal: triangle count mismatch after collapse"; return false; }
+  if (out.n_tris != (int32_t)B.leaf_ids.size() || out.n_tris < n) { err = "internal: triangle count mismatch after collapse"; return false; }
   return true;
 }
 

@@ -18,6 +18,11 @@ struct BvhBuildParams {
   int   parallel_depth = 3;      // top levels built by std::async tasks
   float inflate_rel = 8.0e-6f;   // conservative padding of child boxes (relative to |coordinate|)
   float inflate_abs = 1.0e-6f;
+  // spatial splits (SBVH): references whose boxes straddle a split plane are cut in two, each half bounded by the clipped
+  // triangle.  The same triangle may then sit in several leaves (harmless: the closest hit is a minimum over (t, key)).
+  float spatial_alpha = -1.0f;   // try a spatial split where overlap area of the object split > alpha * root area; < 0: off
+  float spatial_budget = 0.5f;   // extra references allowed, as a fraction of the triangle count
+  int   spatial_bins = 16;
   int   builder = 0;             // 0: binned SAH on the host (art_bvh.cpp); 1: LBVH on the GPU (art_lbvh.hip), needs >= 2 triangles
   float leaf_cost(int n) const { return leaf_base + tri_cost * (float)n; }
 };

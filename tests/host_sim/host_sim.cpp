@@ -13,11 +13,23 @@ using namespace art;
 
 static std::string g_err;
 
+static BvhBuildParams g_bp;   // builder parameters for the following hs_* calls (tests of the spatial-split builder)
+extern "C" void hs_set_bvh_param(const char* name, double v) {
+  const std::string n(name);
+  if (n == "spatial_alpha") g_bp.spatial_alpha = (float)v;
+  else if (n == "spatial_budget") g_bp.spatial_budget = (float)v;
+  else if (n == "spatial_bins") g_bp.spatial_bins = (int)v;
+  else if (n == "max_leaf") g_bp.max_leaf = (int)v;
+  else if (n == "node_cost") g_bp.node_cost = (float)v;
+  else if (n == "leaf_base") g_bp.leaf_base = (float)v;
+  else if (n == "tri_cost") g_bp.tri_cost = (float)v;
+}
+
 extern "C" const char* hs_last_error() { return g_err.c_str(); }
 
 extern "C" int hs_trace(const ArtSceneDesc* sd, const float* o, const float* d, const float* tfar, long long n,
                         ArtHit* out, unsigned long long* stats4) {
-  HostScene hs; BvhBuildParams bp;
+  HostScene hs; BvhBuildParams bp = g_bp;
   if (!flatten_scene(*sd, bp, hs, g_err)) return 1;
   bind_host_pointers(hs);
   BvhStats st = {0, 0, 0, 0};
@@ -42,7 +54,7 @@ extern "C" void hs_set_shard(int rank, int nranks, int tile) { g_rank = rank; g_
 
 extern "C" int hs_render(const ArtSceneDesc* sd, const ArtPassParams* p, int w, int h, int spp0, float* accum /*row-major*/,
                          unsigned long long* rays_out) {
-  HostScene hs; BvhBuildParams bp;
+  HostScene hs; BvhBuildParams bp = g_bp;
   if (!flatten_scene(*sd, bp, hs, g_err)) return 1;
   bind_host_pointers(hs);
   DevFrame F; F.width = w; F.height = h; F.render_type = p->render_type; F.aa_on = p->aa_on ? 1 : 0; F.max_depth = p->max_depth;
@@ -89,7 +101,7 @@ extern "C" int hs_render(const ArtSceneDesc* sd, const ArtPassParams* p, int w, 
 
 // BVH of the scene's CLOSEST mesh in the product's packet layout (what art_export_bvh returns on the GPU box)
 extern "C" int hs_bvh(const ArtSceneDesc* sd, float* nodes, long long node_cap, float* tris, long long tri_cap, int* info3) {
-  HostScene hs; BvhBuildParams bp;
+  HostScene hs; BvhBuildParams bp = g_bp;
   if (!flatten_scene(*sd, bp, hs, g_err)) return 1;
   info3[0] = hs.bvh.n_nodes; info3[1] = hs.bvh.n_tris; info3[2] = hs.bvh.max_stack;
   if (nodes) { if (node_cap < (long long)hs.bvh.nodes.size()) return 2; std::memcpy(nodes, hs.bvh.nodes.data(), hs.bvh.nodes.size() * 4); }

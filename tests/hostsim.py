@@ -57,3 +57,11 @@ def bvh(art, sd):
     if L.hs_bvh(C.byref(sd.desc), nodes.ctypes.data_as(art.f32p), nodes.size, tris.ctypes.data_as(art.f32p), tris.size, info):
         raise RuntimeError("hs_bvh failed")
     return nodes, tris, dict(n_nodes=info[0], n_tris=info[1], max_stack=info[2])
+
+
+def set_bvh_param(art, name, value):
+    """Builder parameter (art_bvh.h BvhBuildParams) for the following host-simulation builds."""
+    L = lib(art)
+    L.hs_set_bvh_param.argtypes = [C.c_char_p, C.c_double]
+    L.hs_set_bvh_param.restype = None
+    L.hs_set_bvh_param(name.encode(), float(value))

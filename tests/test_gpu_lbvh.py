@@ -142,3 +142,22 @@ def test_image_does_not_depend_on_the_builder(art, backend, config):
     finally:
         backend.set_option("bvh_builder", 0)
     assert np.array_equal(bits(out[0][0]), bits(out[1][0])) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+
+
+def test_spatial_split_builder_same_image(art, backend):
+    """Host builder with reference splitting (option bvh_spatial_splits): duplicated triangle references, same image."""
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.synthetic_scene(100000, 3)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=22)
+    out = []
+    try:
+        for spatial in (0, 1):
+            backend.set_option("bvh_spatial_splits", spatial)
+            backend.upload_scene(sd)
+            backend.resize(160, 90)
+            accum, _, spp = backend.render_pass(p, 0)
+            out.append((accum.copy(), backend.stats().rays, backend.bvh_info().n_tris))
+    finally:
+        backend.set_option("bvh_spatial_splits", 0)
+    assert out[1][2] > out[0][2] == 100000
+    assert np.array_equal(bits(out[0][0]), bits(out[1][0])) and out[0][1] == out[1][1]

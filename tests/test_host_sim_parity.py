@@ -160,3 +160,33 @@ def test_bvh_builder_invariants(art):
     sys.setrecursionlimit(10000)
     _, _, depth = bounds(0, 1)
     assert info["max_stack"] <= 7 * depth + 1 and info["n_tris"] == n
+
+
+def test_spatial_split_builder_keeps_every_hit(art):
+    """Option bvh_spatial_splits (SBVH reference splitting, csrc/art_bvh.cpp): a triangle may sit in several leaves, each leaf
+    box bounding only the clipped piece -- the search result must not change.  Long thin triangles force many splits."""
+    from ada_ray_tracer_amd import scenes
+    n = 3000
+    mesh = scenes.random_triangles(n, 9)
+    pos = mesh["pos"].reshape(n, 3, 3).copy()
+    pos[::3, 1] = pos[::3, 0] + (pos[::3, 1] - pos[::3, 0]) * 25.0          # every third triangle becomes a long sliver
+    mesh["pos"] = pos.reshape(-1, 3)
+    light = [dict(shape=art.LIGHT_SPHERE, mat=4, center=(0.0, 4.5, 1.0), radius=0.5, intensity=(10.0, 10.0, 10.0), surfaceArea=3.14159)]
+    sd = art.SceneDesc([], light, scenes.cornell_materials(), [mesh], None, scenes.REFERENCE_CAMERA)
+    osc = conv.OracleScene(sd)
+    o, d = _rays(20000, 12)
+    want = conv.hits_to_arrays(orc.closest_hits(osc.scene, o, d))
+    try:
+        hostsim.set_bvh_param(art, "spatial_alpha", 0.0)
+        nodes, tris, info = hostsim.bvh(art, sd)
+        got = conv.hits_to_arrays(hostsim.trace(art, sd, o, d)[0])
+    finally:
+        hostsim.set_bvh_param(art, "spatial_alpha", -1.0)
+    assert info["n_tris"] > n, "no reference was split"
+    prims = tris.reshape(-1, 12)[:, 9].view(np.int32)
+    assert set(prims.tolist()) == set(range(n))
+    hit = want[1] == 1
+    assert hit.sum() > 2000 and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    for k in (0, 3, 4, 5):
+        x, y = got[k][hit], want[k][hit]
+        assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
