@@ -27,7 +27,7 @@ struct Ctx {
   // frame
   int width = 0, height = 0, spp = 0;
   int rank = 0, nranks = 1, tile = 32, npix_local = 0;
-  DevBuf b_accum, b_screen, b_stage, b_pixmap, b_paths, b_rays, b_ids, b_queue;
+  DevBuf b_accum, b_screen, b_stage, b_pixmap, b_paths, b_rays, b_ids, b_queue, b_ovf;
   float* ext_accum = nullptr;
   // work distribution / counters
   int* d_cursor = nullptr;
@@ -39,6 +39,7 @@ struct Ctx {
   int opt_blocks_per_cu = 0, blocks_per_cu = 0;
   bool count_tests = false;
   int node_min = 4;
+  int stack_cap = 0;            // TRACE_COOP2: LDS stack entries per ray, 0 = the kernel's maximum
   int ray_chunk = 32;
   bool shadow_anyhit = true;   // shadow rays use the visibility rule instead of a full closest-hit search (same decision)
   // timing
