@@ -70,7 +70,7 @@ int ensure_device() {
   HIP_TRY(hipGetDeviceProperties(&prop, c.device));
   c.num_cus = prop.multiProcessorCount;
   c.arch = prop.gcnArchName;
-  HIP_TRY(hipMalloc(&c.d_cursor, 4 * sizeof(int)));   // [0] work cursor, [1] live-ray queue length, [2] overflow queue length
+  HIP_TRY(hipMalloc(&c.d_cursor, kCursorInts * sizeof(int)));   // [0] work cursor, [1] live-ray queue length, [2] overflow queue length, [32*k] cursor of queue segment k
   HIP_TRY(hipMalloc(&c.d_counters, 16 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(c.d_counters, 0, 16 * sizeof(unsigned long long)));
   c.device_ready = true;
@@ -185,7 +185,7 @@ static int coop_grid() {
 
 static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
   Ctx& c = g_ctx;
-  a.n_rays = n_rays; a.stack_entries = c.stack_entries; a.node_min = c.node_min; a.chunk = c.ray_chunk;
+  a.n_rays = n_rays; a.stack_entries = c.stack_entries; a.node_min = c.node_min; a.segments = c.queue_segments; a.chunk = c.ray_chunk;
   a.ray_ox = q.ray_ox; a.ray_oy = q.ray_oy; a.ray_oz = q.ray_oz; a.ray_dx = q.ray_dx; a.ray_dy = q.ray_dy; a.ray_dz = q.ray_dz; a.ray_tfar = q.ray_tfar;
   a.hit_t = q.hit_t; a.hit_key = q.hit_key; a.hit_u = q.hit_u; a.hit_v = q.hit_v;
   a.nodes = c.scene.nodes; a.tris = c.scene.tris; a.n_tris = c.scene.n_tris;
@@ -210,7 +210,7 @@ static int trace(const DevPaths& q, int n_rays) {
       if (arr[k] != q.ray_ox + (size_t)k * (size_t)a.ray_stride) return fail("internal: ray arrays are not laid out with a common stride");
   }
   if (coop) {
-    HIP_TRY(hipMemsetAsync(c.d_cursor, 0, 4 * sizeof(int), c.stream));
+    HIP_TRY(hipMemsetAsync(c.d_cursor, 0, kCursorInts * sizeof(int), c.stream));
   }
   if (c.ev_pool.size() < c.ev_used + 2) {
     hipEvent_t e0, e1;
@@ -540,6 +540,7 @@ int art_set_option(const char* name, int64_t value) {
   if (!name) return fail("null option");
   const std::string n(name);
   if (n == "trace_kernel") { if (value < TRACE_COOP || value > TRACE_COOP2) return fail("trace_kernel: 0 (cooperative), 1 (simple) or 2 (cooperative, two rays per group)"); g_ctx.trace_kernel = (int)value; }
+  else if (n == "queue_segments") { if (value != 1 && value != 2 && value != 4 && value != 8) return fail("queue_segments: 1, 2, 4 or 8"); g_ctx.queue_segments = (int)value; }
   else if (n == "stack_cap") { if (value < 0 || value > 64) return fail("stack_cap: 0 (default) .. 64"); g_ctx.stack_cap = (int)value; }
   else if (n == "batch_paths") { if (value < 1024 || value > (1ll << 29)) return fail("batch_paths: 1024..2^29 (ray indices are 32-bit: 2 rays per path slot)"); g_ctx.batch_paths = value; }
   else if (n == "blocks_per_cu") { g_ctx.opt_blocks_per_cu = (int)value; g_ctx.blocks_per_cu = 0; }

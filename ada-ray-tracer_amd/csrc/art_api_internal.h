@@ -11,6 +11,8 @@
 
 namespace art {
 
+constexpr int kCursorInts = 32 * 9;   // d_cursor: 3 scalars + one work cursor per queue segment, each on its own 128-byte line
+
 struct DevBuf { void* p = nullptr; size_t bytes = 0; void release(); };
 
 struct Ctx {
@@ -39,6 +41,7 @@ struct Ctx {
   int opt_blocks_per_cu = 0, blocks_per_cu = 0;
   bool count_tests = false;
   int node_min = 4;
+  int queue_segments = 8;       // the live-ray queue is cut into this many contiguous segments, one per XCD (1 = a single cursor)
   int stack_cap = 0;            // TRACE_COOP2: LDS stack entries per ray, 0 = the kernel's maximum
   int ray_chunk = 32;
   bool shadow_anyhit = true;   // shadow rays use the visibility rule instead of a full closest-hit search (same decision)

@@ -10,6 +10,8 @@ enum { TRACE_COOP = 0, TRACE_SIMPLE = 1, TRACE_COOP2 = 2 };
 struct TraceArgs {
   int32_t n_rays;
   int32_t stack_entries;        // per-ray-group LDS stack depth (>= Bvh8::max_stack)
+  int32_t segments;             // k_trace_coop: the queue is cut into this many contiguous segments (1, 2, 4, 8); workgroup b starts
+                                // in segment b % segments (its XCD) and moves on to the next segment when that one is drained
   int32_t node_min;             // a wave keeps expanding nodes while at least this many of its 8 ray groups have one
   const float* ray_ox; const float* ray_oy; const float* ray_oz;
   const float* ray_dx; const float* ray_dy; const float* ray_dz;
@@ -20,7 +22,8 @@ struct TraceArgs {
   float* hit_t; uint32_t* hit_key; float* hit_u; float* hit_v;
   const float* nodes; const float* tris; int32_t n_tris;   // BVH of the closest-hit mesh (hot-loop operands)
   int32_t chunk;                // rays a wave claims per atomic on the cursor
-  int* cursor;                  // work cursor, zeroed before every launch
+  int* cursor;                  // work cursors, zeroed before every launch: segment k's cursor is cursor[32 * (k + 1)] (cursor[0] serves the
+                                // kernels with a single cursor)
   int* queue; int* queue_count; // live-ray queue filled by k_analytic (indices into the ray arrays), count zeroed before every launch
   int64_t ray_stride;           // TRACE_COOP2: ray_ox, ray_oy, ..., ray_tfar, hit_t, hit_key, hit_u, hit_v are ray_stride floats apart
   int32_t stack_cap;            // TRACE_COOP2: LDS stack entries per ray (<= 22); deeper rays go to ovf_queue

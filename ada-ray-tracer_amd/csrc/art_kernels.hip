@@ -22,7 +22,7 @@ namespace art {
 // cross-lane helpers for 8-lane groups (DPP: quad_perm + row_half_mirror stay inside 8 lanes)
 // ------------------------------------------------------------------------------------------------
 template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }   // old = 0 + bound_ctrl: no tie to v, so no copy and the move can fold into its user (v_min_u32_dpp)
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
 
@@ -111,6 +111,11 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
 
   int chunk_pos = 0, chunk_end = 0;   // wave-uniform
   bool exhausted = false;             // wave-uniform
+  // The live-ray queue is in ray order (neighbouring rays start at neighbouring surface points), so it is cut into one
+  // contiguous segment per XCD: workgroups are dealt round-robin to the XCDs, each XCD has its own L2, and rays that walk
+  // the same part of the tree then share an L2.  A wave whose segment is drained helps with the next one.
+  const int n_seg = A.segments;
+  int seg = (int)blockIdx.x & (n_seg - 1), segs_left = n_seg;   // wave-uniform
   bool has_ray = false;               // group-uniform from here on
   int sp = 0, ray = 0;
   f3 o = mk3(0, 0, 0), d = o, inv = o, noi = o;
@@ -128,11 +133,17 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       const uint64_t need_mask = ballot64(need) & leaders;
       if (need_mask == 0) break;
       if (chunk_pos == chunk_end) {
+        const int seg_lo = (int)(((int64_t)n_queue * seg) / n_seg), seg_hi = (int)(((int64_t)n_queue * (seg + 1)) / n_seg);
         int base = 0;
-        if (lane == 0) base = atomicAdd(A.cursor, A.chunk);
-        base = __builtin_amdgcn_readfirstlane(base);
-        chunk_pos = base; chunk_end = min(base + A.chunk, n_queue);
-        if (chunk_pos >= n_queue) { exhausted = true; chunk_pos = chunk_end = 0; break; }
+        if (lane == 0) base = atomicAdd(A.cursor + 32 * (seg + 1), A.chunk);
+        base = __builtin_amdgcn_readfirstlane(base) + seg_lo;
+        chunk_pos = base; chunk_end = min(base + A.chunk, seg_hi);
+        if (chunk_pos >= seg_hi) {
+          chunk_pos = chunk_end = 0;
+          seg = (seg + 1) & (n_seg - 1);
+          if (--segs_left == 0) { exhausted = true; break; }
+          continue;
+        }
       }
       const int avail = chunk_end - chunk_pos;
       const int n_need = __popcll(need_mask);
