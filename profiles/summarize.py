@@ -10,6 +10,12 @@ import os
 import shutil
 import sys
 
+
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: take the most recent run of a pass"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_final")
 
@@ -17,10 +23,10 @@ SRC = os.path.join(ROOT, "gpurun_out", "prof_final")
 def main(tag):
     dst = os.path.join(ROOT, "profiles", tag)
     os.makedirs(dst, exist_ok=True)
-    shutil.copyfile(glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, "kernel_stats.csv"))
+    shutil.copyfile(newest(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv")), os.path.join(dst, "kernel_stats.csv"))
     out = {}
     for name in ("fetch", "write", "sq", "tcc"):
-        rows = list(csv.DictReader(open(glob.glob(os.path.join(SRC, name, "*", "*_counter_collection.csv"))[0])))
+        rows = list(csv.DictReader(open(newest(os.path.join(SRC, name, "*", "*_counter_collection.csv")))))
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         disp = collections.defaultdict(dict)
         for r in rows:
