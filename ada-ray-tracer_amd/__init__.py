@@ -85,7 +85,7 @@ class ArtHit(C.Structure):
 
 
 class ArtBvhInfo(C.Structure):
-    _fields_ = [("n_nodes", C.c_int32), ("n_tris", C.c_int32), ("max_stack", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("n_nodes", C.c_int32), ("n_tris", C.c_int32), ("max_stack", C.c_int32), ("node_width", C.c_int32),
                 ("build_ms", C.c_double)]
 
 
@@ -297,7 +297,7 @@ class Backend:
     def export_bvh(self):
         info = ArtBvhInfo()
         _check(self.lib.art_export_bvh(None, 0, None, 0, C.byref(info)))
-        nodes = np.zeros(info.n_nodes * 64, np.float32); tris = np.zeros(info.n_tris * 12, np.float32)
+        nodes = np.zeros(info.n_nodes * 8 * info.node_width, np.float32); tris = np.zeros(info.n_tris * 12, np.float32)
         _check(self.lib.art_export_bvh(_fp(nodes), nodes.size, _fp(tris), tris.size, C.byref(info)))
         return nodes, tris, info
 

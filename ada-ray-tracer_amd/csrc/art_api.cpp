@@ -113,18 +113,27 @@ int upload_scene(const ArtSceneDesc* d) {
     tri9.release();
     if (!ok) { if (g.nodes) (void)hipFree(g.nodes); if (g.tris) (void)hipFree(g.tris); return fail("GPU BVH build: " + err); }
     c.b_nodes.release(); c.b_tris.release();
-    c.b_nodes.p = g.nodes; c.b_nodes.bytes = (size_t)g.n_nodes * kNodeFloats * 4;
+    c.b_nodes.p = g.nodes; c.b_nodes.bytes = (size_t)g.n_nodes * node_floats(c.bvh_params.width) * 4;
+    hs.bvh.width = c.bvh_params.width;
     c.b_tris.p = g.tris; c.b_tris.bytes = (size_t)g.n_tris * kTriFloats * 4;
     hs.bvh.n_nodes = g.n_nodes; hs.bvh.n_tris = g.n_tris; hs.bvh.max_stack = g.max_stack;
     hs.hdr.n_nodes = g.n_nodes; hs.hdr.n_tris = g.n_tris;
     hs.bvh_build_ms = g.build_ms; hs.gpu_built = true;
     std::vector<float>().swap(hs.deferred_tri9);
   }
-  if ((uint64_t)hs.bvh.n_nodes * kNodeFloats * 4 >= (1ull << 32) || (uint64_t)hs.bvh.n_tris * kTriFloats * 4 >= (1ull << 32))
+  if ((uint64_t)hs.bvh.n_nodes * node_floats(hs.hdr.node_width) * 4 >= (1ull << 32) || (uint64_t)hs.bvh.n_tris * kTriFloats * 4 >= (1ull << 32))
     return fail("mesh too large: the trace kernel addresses nodes and triangles with 32-bit byte offsets (max ~89M triangles)");
   if (hs.bvh.max_stack > kStackEntries) return fail("BVH traversal stack bound " + std::to_string(hs.bvh.max_stack) + " exceeds " + std::to_string(kStackEntries));
   if (upload_scene_arrays(hs)) return 1;
-  c.stack_entries = std::max(8, hs.bvh.max_stack);
+  // LDS stack per ray: the tree's worst-case bound if 8 workgroups per CU (8 waves per SIMD) still fit in the CU's 160 KB, else the
+  // largest size that does; then pushes are checked and the few rays that go deeper are finished by k_trace_overflow.
+  {
+    const int groups = 64 / hs.hdr.node_width;
+    const int lds_cap = (160 * 1024 / 8) / (4 * groups * 8) - 1;            // entries per ray (one extra slot is the sink of masked pushes)
+    const int want = std::max(8, hs.bvh.max_stack);
+    c.stack_entries = std::min(want, c.lds_stack_cap > 0 ? c.lds_stack_cap : lds_cap);
+    c.stack_overflow = want > c.stack_entries;
+  }
   c.blocks_per_cu = 0;   // re-query occupancy
   c.host_scene = std::move(hs);
   c.scene_ready = true;
@@ -179,13 +188,13 @@ static void carve(DevPaths& q, int P, int depth) {
 static int coop_grid() {
   Ctx& c = g_ctx;
   if (c.trace_kernel == TRACE_COOP2) return c.num_cus * (c.opt_blocks_per_cu > 0 ? c.opt_blocks_per_cu : trace_coop2_blocks_per_cu());
-  if (c.blocks_per_cu <= 0) c.blocks_per_cu = c.opt_blocks_per_cu > 0 ? c.opt_blocks_per_cu : trace_coop_blocks_per_cu(c.stack_entries);
+  if (c.blocks_per_cu <= 0) c.blocks_per_cu = c.opt_blocks_per_cu > 0 ? c.opt_blocks_per_cu : trace_coop_blocks_per_cu(c.stack_entries, c.scene.node_width);
   return c.num_cus * c.blocks_per_cu;
 }
 
 static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
   Ctx& c = g_ctx;
-  a.n_rays = n_rays; a.stack_entries = c.stack_entries; a.node_min = c.node_min; a.segments = c.queue_segments; a.chunk = c.ray_chunk;
+  a.n_rays = n_rays; a.stack_entries = c.stack_entries; a.width = c.scene.node_width; a.stack_overflow = c.stack_overflow ? 1 : 0; a.node_min = c.node_min; a.segments = c.queue_segments; a.chunk = c.ray_chunk;
   a.ray_ox = q.ray_ox; a.ray_oy = q.ray_oy; a.ray_oz = q.ray_oz; a.ray_dx = q.ray_dx; a.ray_dy = q.ray_dy; a.ray_dz = q.ray_dz; a.ray_tfar = q.ray_tfar;
   a.hit_t = q.hit_t; a.hit_key = q.hit_key; a.hit_u = q.hit_u; a.hit_v = q.hit_v;
   a.nodes = c.scene.nodes; a.tris = c.scene.tris; a.n_tris = c.scene.n_tris;
@@ -202,7 +211,8 @@ static int trace(const DevPaths& q, int n_rays) {
   Ctx& c = g_ctx;
   const bool coop = (c.trace_kernel == TRACE_COOP || c.trace_kernel == TRACE_COOP2);
   if (coop && ensure(c.b_queue, (size_t)n_rays * sizeof(int))) return 1;
-  if (c.trace_kernel == TRACE_COOP2 && ensure(c.b_ovf, (size_t)n_rays * sizeof(int))) return 1;
+  if (c.trace_kernel == TRACE_COOP2 && c.scene.node_width != 8 && c.scene.n_tris > 0) return fail("trace_kernel 2 needs a BVH of width 8 (option bvh_width)");
+  if ((c.trace_kernel == TRACE_COOP2 || (c.trace_kernel == TRACE_COOP && c.stack_overflow)) && ensure(c.b_ovf, (size_t)n_rays * sizeof(int))) return 1;
   TraceArgs a; fill_trace_args(a, q, n_rays);
   if (c.trace_kernel == TRACE_COOP2) {
     const float* arr[11] = {q.ray_ox, q.ray_oy, q.ray_oz, q.ray_dx, q.ray_dy, q.ray_dz, q.ray_tfar, q.hit_t, (const float*)q.hit_key, q.hit_u, q.hit_v};
@@ -517,11 +527,11 @@ int art_export_bvh(float* nodes, int64_t node_cap, float* tris, int64_t tri_cap,
   if (!g_ctx.scene_ready) return fail("no scene uploaded");
   Bvh8& b = g_ctx.host_scene.bvh;
   if (g_ctx.host_scene.gpu_built && b.nodes.empty() && (nodes || tris)) {     // the GPU-built tree is fetched on first request
-    b.nodes.resize((size_t)b.n_nodes * kNodeFloats); b.tris.resize((size_t)b.n_tris * kTriFloats);
+    b.nodes.resize((size_t)b.n_nodes * node_floats(b.width)); b.tris.resize((size_t)b.n_tris * kTriFloats);
     HIP_TRY(hipMemcpy(b.nodes.data(), g_ctx.b_nodes.p, b.nodes.size() * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(b.tris.data(), g_ctx.b_tris.p, b.tris.size() * 4, hipMemcpyDeviceToHost));
   }
-  if (info) { info->n_nodes = b.n_nodes; info->n_tris = b.n_tris; info->max_stack = b.max_stack; info->reserved = 0; info->build_ms = g_ctx.host_scene.bvh_build_ms; }
+  if (info) { info->n_nodes = b.n_nodes; info->n_tris = b.n_tris; info->max_stack = b.max_stack; info->node_width = b.width; info->build_ms = g_ctx.host_scene.bvh_build_ms; }
   if (nodes) { if (node_cap < (int64_t)b.nodes.size()) return fail("art_export_bvh: node buffer too small"); std::memcpy(nodes, b.nodes.data(), b.nodes.size() * 4); }
   if (tris) { if (tri_cap < (int64_t)b.tris.size()) return fail("art_export_bvh: triangle buffer too small"); std::memcpy(tris, b.tris.data(), b.tris.size() * 4); }
   return 0;
@@ -548,6 +558,8 @@ int art_set_option(const char* name, int64_t value) {
   else if (n == "shadow_anyhit") { g_ctx.shadow_anyhit = value != 0; }
   else if (n == "ray_chunk") { if (value < 8 || value > 4096) return fail("ray_chunk: 8..4096"); g_ctx.ray_chunk = (int)value; }
   else if (n == "node_min") { if (value < 1 || value > 8) return fail("node_min: 1..8"); g_ctx.node_min = (int)value; }
+  else if (n == "bvh_width") { if (value != 4 && value != 8) return fail("bvh_width: 4 or 8"); g_ctx.bvh_params.width = (int)value; }
+  else if (n == "lds_stack_cap") { if (value < 0 || value > kStackEntries) return fail("lds_stack_cap: 0 (automatic) .. 160"); g_ctx.lds_stack_cap = (int)value; }
   else if (n == "bvh_max_leaf") { if (value < 1 || value > kMaxLeafTris) return fail("bvh_max_leaf: 1..8"); g_ctx.bvh_params.max_leaf = (int)value; }
   else if (n == "bvh_spatial_splits") { g_ctx.bvh_params.spatial_alpha = value ? 1.0e-5f : -1.0f; }   // host builder: SBVH reference splitting
   else if (n == "bvh_builder") { if (value < 0 || value > 1) return fail("bvh_builder: 0 host SAH, 1 GPU LBVH"); g_ctx.bvh_params.builder = (int)value; }

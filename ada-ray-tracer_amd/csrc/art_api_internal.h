@@ -25,7 +25,7 @@ struct Ctx {
   DevScene* d_scene = nullptr;                 // the same header in HBM (the trace kernels take it by pointer)
   BvhBuildParams bvh_params;
   DevBuf b_spheres, b_sphere_mat, b_lights, b_materials, b_bf_pos, b_bf_nrm, b_bf_uv, b_bf_idx, b_nodes, b_tris, b_m_nrm, b_m_uv, b_m_idx, b_m_matid;
-  int stack_entries = 8;
+  int stack_entries = 8; bool stack_overflow = false; int lds_stack_cap = 0;
   // frame
   int width = 0, height = 0, spp = 0;
   int rank = 0, nranks = 1, tile = 32, npix_local = 0;
@@ -43,7 +43,7 @@ struct Ctx {
   int node_min = 4;
   int queue_segments = 8;       // the live-ray queue is cut into this many contiguous segments, one per XCD (1 = a single cursor)
   int stack_cap = 0;            // TRACE_COOP2: LDS stack entries per ray, 0 = the kernel's maximum
-  int ray_chunk = 32;
+  int ray_chunk = 16;
   bool shadow_anyhit = true;   // shadow rays use the visibility rule instead of a full closest-hit search (same decision)
   // timing
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;

@@ -251,9 +251,13 @@ inline float next_up(float v) { return std::nextafterf(v, INFINITY); }
 
 bool build_bvh8(const float* tri9, const int32_t* prim_ids, int32_t n, const BvhBuildParams& prm, Bvh8& out, std::string& err) {
   out = Bvh8();
+  if (prm.width != 4 && prm.width != 8) { err = "BVH width must be 4 or 8"; return false; }
+  out.width = prm.width;
+  const int W = prm.width, NF = node_floats(W);
   if (n <= 0) return true;
   Builder B;
   B.tri = tri9; B.n = n; B.prm = prm;
+  B.prm.max_leaf = std::min(B.prm.max_leaf, W);      // a leaf is one W-lane packet of triangle tests
   std::vector<Ref> refs((size_t)n);
   for (int32_t i = 0; i < n; ++i) {
     Box b; b.reset();
@@ -272,7 +276,7 @@ bool build_bvh8(const float* tri9, const int32_t* prim_ids, int32_t n, const Bvh
 
   // ---- collapse to 8-wide
   std::vector<float>& N = out.nodes;
-  auto new_node8 = [&]() { const int32_t id = (int32_t)(N.size() / kNodeFloats); N.resize(N.size() + kNodeFloats, 0.0f); return id; };
+  auto new_node8 = [&]() { const int32_t id = (int32_t)(N.size() / NF); N.resize(N.size() + NF, 0.0f); return id; };
   out.tris.reserve((size_t)n * kTriFloats);
   const float inflate_rel = prm.inflate_rel, inflate_abs = prm.inflate_abs;
 
@@ -302,7 +306,7 @@ bool build_bvh8(const float* tri9, const int32_t* prim_ids, int32_t n, const Bvh
     const Node2& top = B.nodes[p.n2];
     if (top.count > 0) ch.push_back(p.n2);
     else { ch.push_back(top.left); ch.push_back(top.right); }
-    while ((int)ch.size() < 8) {
+    while ((int)ch.size() < W) {
       int best = -1; float best_a = -1.0f;
       for (int i = 0; i < (int)ch.size(); ++i) {
         const Node2& c = B.nodes[ch[i]];
@@ -315,11 +319,11 @@ bool build_bvh8(const float* tri9, const int32_t* prim_ids, int32_t n, const Bvh
       ch[best] = c.left; ch.push_back(c.right);
     }
     // a BVH2 leaf with more than kMaxLeafTris triangles cannot occur (max_leaf <= 8 is enforced below)
-    float* nd = &N[(size_t)p.n8 * kNodeFloats];
+    float* nd = &N[(size_t)p.n8 * NF];
     const int nch = (int)ch.size();
     const int32_t stack_here = p.stack_before + (nch - 1);
     max_stack = std::max(max_stack, stack_here + 1);
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < W; ++j) {
       int32_t ref = -1, cnt = 0;
       float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
       if (j < nch) {
@@ -332,15 +336,15 @@ bool build_bvh8(const float* tri9, const int32_t* prim_ids, int32_t n, const Bvh
         if (c.count > 0) { ref = emit_leaf_tris(c); cnt = c.count; }
         else {
           ref = new_node8(); cnt = 0;
-          nd = &N[(size_t)p.n8 * kNodeFloats];      // N may have been reallocated
+          nd = &N[(size_t)p.n8 * NF];      // N may have been reallocated
           todo.push_back({ch[j], ref, stack_here});
         }
       }
       nd[4 * j + 0] = lo[0]; nd[4 * j + 1] = lo[1]; nd[4 * j + 2] = lo[2]; std::memcpy(&nd[4 * j + 3], &ref, 4);
-      nd[32 + 4 * j + 0] = hi[0]; nd[32 + 4 * j + 1] = hi[1]; nd[32 + 4 * j + 2] = hi[2]; std::memcpy(&nd[32 + 4 * j + 3], &cnt, 4);
+      nd[4 * W + 4 * j + 0] = hi[0]; nd[4 * W + 4 * j + 1] = hi[1]; nd[4 * W + 4 * j + 2] = hi[2]; std::memcpy(&nd[4 * W + 4 * j + 3], &cnt, 4);
     }
   }
-  out.n_nodes = (int32_t)(N.size() / kNodeFloats);
+  out.n_nodes = (int32_t)(N.size() / NF);
   out.n_tris = (int32_t)(out.tris.size() / kTriFloats);
   out.max_stack = max_stack;
   if (out.n_tris != (int32_t)B.leaf_ids.size() || out.n_tris < n) { err = "internal: triangle count mismatch after collapse"; return false; }

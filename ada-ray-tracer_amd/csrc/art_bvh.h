@@ -8,12 +8,13 @@
 namespace art {
 
 struct BvhBuildParams {
+  int   width = 4;               // children per node: 8 or 4 (= lanes per ray in the trace kernel); leaves hold <= width triangles
   int   max_leaf = 8;            // <= kMaxLeafTris: one leaf = one 8-lane packet of triangle tests
   // SAH costs in units of one cooperative traversal step: a leaf of <= 8 triangles is ONE 8-lane packet whatever
   // its size, and a BVH2 split only costs a fraction of a BVH8 node step after the collapse.
   float node_cost = 0.4f;        // cost of one BVH2 inner node
   float leaf_base = 1.0f;        // fixed cost of visiting a leaf
-  float tri_cost = 0.05f;        // cost per triangle in a leaf
+  float tri_cost = -1.0f;        // cost per triangle in a leaf; < 0: 0.05 for width 8, 0.2 for width 4 (measured optima on C4)
   int   max_sah_depth = 48;      // beyond this BVH2 depth fall back to median splits
   int   parallel_depth = 3;      // top levels built by std::async tasks
   float inflate_rel = 8.0e-6f;   // conservative padding of child boxes (relative to |coordinate|)
@@ -24,11 +25,12 @@ struct BvhBuildParams {
   float spatial_budget = 0.5f;   // extra references allowed, as a fraction of the triangle count
   int   spatial_bins = 16;
   int   builder = 0;             // 0: binned SAH on the host (art_bvh.cpp); 1: LBVH on the GPU (art_lbvh.hip), needs >= 2 triangles
-  float leaf_cost(int n) const { return leaf_base + tri_cost * (float)n; }
+  float leaf_cost(int n) const { return leaf_base + (tri_cost >= 0.0f ? tri_cost : (width == 4 ? 0.2f : 0.05f)) * (float)n; }
 };
 
 struct Bvh8 {
-  std::vector<float> nodes;      // kNodeFloats per node, node 0 = root
+  std::vector<float> nodes;      // node_floats(width) per node, node 0 = root
+  int32_t width = 8;
   std::vector<float> tris;       // kTriFloats per triangle, in leaf order
   int32_t n_nodes = 0, n_tris = 0;
   int32_t max_stack = 1;         // worst-case traversal stack entries for this tree

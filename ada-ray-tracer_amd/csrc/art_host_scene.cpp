@@ -45,6 +45,7 @@ bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& o
   std::memset(&h, 0, sizeof h);
   h.n_spheres = d.n_spheres; h.n_lights = d.n_lights; h.n_materials = d.n_materials;
   h.has_cornell = d.has_cornell ? 1 : 0;
+  h.node_width = bp.width;
   std::memcpy(h.cb_min, d.cb_min, 12); std::memcpy(h.cb_max, d.cb_max, 12);
   std::memcpy(h.cb_mat, d.cb_mat, sizeof h.cb_mat); std::memcpy(h.cb_nrm, d.cb_nrm, sizeof h.cb_nrm);
   if (h.has_cornell) for (int i = 0; i < 6; ++i) if (!mat_ok(h.cb_mat[i])) { err = "scene: Cornell box material index out of range"; return false; }
@@ -82,6 +83,7 @@ bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& o
       std::vector<float> tri9(9 * (size_t)m.ntris);
       for (int i = 0; i < m.ntris; ++i)
         for (int k = 0; k < 3; ++k) std::memcpy(&tri9[9 * (size_t)i + 3 * k], m.pos + 3 * (size_t)m.idx[3 * (size_t)i + k], 12);
+      h.node_width = bp.width;
       if (bp.builder == 1 && m.ntris >= 2) { out.deferred_tri9 = std::move(tri9); h.n_tris = m.ntris; continue; }   // built on the GPU by the caller
       const auto t0 = std::chrono::steady_clock::now();
       if (!build_bvh8(tri9.data(), nullptr, m.ntris, bp, out.bvh, err)) return false;

@@ -136,8 +136,8 @@ ART_HD void slab_interval(f3 lo, f3 hi, f3 inv, f3 noi, float tbest, float& tmn,
   tmx = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tbest));
 }
 
-ART_HD void slab_fast(const float* nd, int j, f3 inv, f3 noi, float tbest, float& tmn, float& tmx) {
-  slab_interval(ld3(nd + 4 * j), ld3(nd + 32 + 4 * j), inv, noi, tbest, tmn, tmx);
+ART_HD void slab_fast(const float* nd, int width, int j, f3 inv, f3 noi, float tbest, float& tmn, float& tmx) {
+  slab_interval(ld3(nd + 4 * j), ld3(nd + 4 * width + 4 * j), inv, noi, tbest, tmn, tmx);
 }
 
 ART_HD void tri_leaf_test(const float* tr, f3 o, f3 d, Cand& best) {
@@ -176,18 +176,19 @@ ART_HD void bvh_closest(const DevScene& s, f3 o, f3 d, Cand& best, BvhStats* st,
     if (stk_t[sp] > best.t) continue;
     const int32_t ref = e >> 4, cnt = e & 15;
     if (cnt == 0) {
-      const float* nd = s.nodes + (size_t)ref * kNodeFloats;
+      const int W = s.node_width;
+      const float* nd = s.nodes + (size_t)ref * (size_t)node_floats(W);
       uint32_t key[8]; int32_t ent[8]; float tm[8]; int nh = 0;
       if (STATS) st->node_visits++;
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < W; ++j) {
         const int32_t rj = __builtin_bit_cast(int32_t, nd[4 * j + 3]);
         if (rj < 0) continue;
         if (STATS) st->box_tests++;
         float tmn, tmx;
-        slab_fast(nd, j, inv, noi, best.t, tmn, tmx);
+        slab_fast(nd, W, j, inv, noi, best.t, tmn, tmx);
         if (tmn <= tmx) {
           key[nh] = (__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j;
-          ent[nh] = (rj << 4) | __builtin_bit_cast(int32_t, nd[32 + 4 * j + 3]);
+          ent[nh] = (rj << 4) | __builtin_bit_cast(int32_t, nd[4 * W + 4 * j + 3]);
           tm[nh] = tmn; ++nh;
         }
       }

@@ -9,7 +9,9 @@ enum { TRACE_COOP = 0, TRACE_SIMPLE = 1, TRACE_COOP2 = 2 };
 
 struct TraceArgs {
   int32_t n_rays;
-  int32_t stack_entries;        // per-ray-group LDS stack depth (>= Bvh8::max_stack)
+  int32_t stack_entries;        // per-ray LDS stack depth; >= Bvh8::max_stack unless stack_overflow
+  int32_t width;                // node width = lanes per ray in k_trace_coop (8 or 4)
+  int32_t stack_overflow;       // the LDS stack is smaller than the tree's bound: pushes are checked, rays that do not fit go to ovf_queue
   int32_t segments;             // k_trace_coop: the queue is cut into this many contiguous segments (1, 2, 4, 8); workgroup b starts
                                 // in segment b % segments (its XCD) and moves on to the next segment when that one is drained
   int32_t node_min;             // a wave keeps expanding nodes while at least this many of its 8 ray groups have one
@@ -41,10 +43,10 @@ void launch_debug(hipStream_t st, const DevFrame& F, const DevScene& S, const De
 void launch_to_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, int h);
 void launch_to_xmajor_u32(hipStream_t st, const uint32_t* src, uint32_t* dst, int w, int h);
 void launch_from_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, int h);
-size_t trace_coop_lds_bytes(int stack_entries);
+size_t trace_coop_lds_bytes(int stack_entries, int width);
 void launch_trace(hipStream_t st, const DevScene* d_scene, const TraceArgs& A, int kernel, bool stats, int grid_blocks);
 void launch_analytic(hipStream_t st, const DevScene* d_scene, const TraceArgs& A, bool stats);
-int  trace_coop_blocks_per_cu(int stack_entries);
+int  trace_coop_blocks_per_cu(int stack_entries, int width);
 int  trace_coop2_blocks_per_cu();
 int  trace_coop2_stack_cap();
 

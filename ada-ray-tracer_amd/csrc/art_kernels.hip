@@ -37,6 +37,14 @@ __device__ __forceinline__ float xor4_f(float v) { return dpp_f<DPP_XOR3>(dpp_f<
 
 // number of lanes in my 8-lane group whose key is smaller than mine (keys are < 2^31).  (A hand-scheduled
 // v_sub_co_u32_dpp / v_addc chain has fewer instructions but measured 4 % slower: its carry chain serialises.)
+template <int G> __device__ __forceinline__ int group_rank_g(int key);
+template <> __device__ __forceinline__ int group_rank_g<4>(int key) {       // 4-lane groups = DPP quads: three quad_perm compares
+  int r = 0;
+  r += (dpp_i<DPP_XOR1>(key) < key);
+  r += (dpp_i<DPP_XOR2>(key) < key);
+  r += (dpp_i<DPP_XOR3>(key) < key);
+  return r;
+}
 __device__ __forceinline__ int group_rank(int key) {
   const int m = dpp_i<DPP_HALF_MIRROR>(key);
   int r = 0;
@@ -76,6 +84,15 @@ __device__ __forceinline__ uint32_t group_min_u32(uint32_t k) {
   return k;
 }
 
+template <> __device__ __forceinline__ int group_rank_g<8>(int key) { return group_rank(key); }
+template <int G> __device__ __forceinline__ uint32_t group_min_u32_g(uint32_t k);
+template <> __device__ __forceinline__ uint32_t group_min_u32_g<8>(uint32_t k) { return group_min_u32(k); }
+template <> __device__ __forceinline__ uint32_t group_min_u32_g<4>(uint32_t k) {
+  k = min(k, (uint32_t)dpp_i<DPP_XOR1>((int)k));
+  k = min(k, (uint32_t)dpp_i<DPP_XOR2>((int)k));
+  return k;
+}
+
 // hip's __ballot() round-trips the predicate through a VGPR (v_cndmask + v_cmp); the builtin keeps it a lane mask
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
@@ -95,14 +112,18 @@ __device__ __forceinline__ void wave_lds_sync() {
 #define ART_COOP_LEAF_MIN 3          // a wave runs its leaf phase once this many of its 8 ray groups wait on a leaf
 #endif
 
-template <bool STATS>
+// G = lanes per ray = children per node = triangles per leaf (8 or 4); 64 / G rays per wave.  OVF: the LDS stack holds fewer entries
+// than the tree's worst-case bound, so a push is checked and a ray that would not fit is handed to k_trace_overflow.
+template <bool STATS, int G, bool OVF>
 __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(const DevScene* __restrict__ Sp, const TraceArgs A) {
   extern __shared__ uint2 lds_stack[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 7, g = lane >> 3;
-  const int gbase = lane & ~7;
-  uint2* const stk = lds_stack + (size_t)(wave * 8 + g) * (A.stack_entries + 1);
-  const uint64_t leaders = 0x0101010101010101ull;
+  constexpr int NG = 64 / G;                                   // ray groups per wave
+  const int j = lane & (G - 1), g = lane / G;
+  const int gbase = lane & ~(G - 1);
+  uint2* const stk = lds_stack + (size_t)(wave * NG + g) * (A.stack_entries + 1);
+  const uint64_t leaders = (G == 8) ? 0x0101010101010101ull : 0x1111111111111111ull;
+  constexpr uint64_t gmask = (1ull << G) - 1ull;
   // kernel-argument bases stay in SGPRs; per-lane addressing is a 32-bit byte offset (scalar base + vector offset loads).
   // art_upload_scene guarantees n_nodes * 256 and n_tris * 48 fit in 32 bits.
   const char* const nodes_b = reinterpret_cast<const char*>(A.nodes);
@@ -201,19 +222,26 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       }
       // ---- node phase: lane j slab-tests child j; groups not taking part read the root node and discard the result
       const int ref = (int)(pend >> 4);
-      const uint32_t noff = (uint32_t)(want_node ? ref : 0) * (uint32_t)(kNodeFloats * 4) + (uint32_t)j * 16u;
+      const uint32_t noff = (uint32_t)(want_node ? ref : 0) * (uint32_t)(G * 32) + (uint32_t)j * 16u;
       const float4 r0 = *reinterpret_cast<const float4*>(nodes_b + noff);
-      const float4 r1 = *reinterpret_cast<const float4*>(nodes_b + noff + 128u);
+      const float4 r1 = *reinterpret_cast<const float4*>(nodes_b + noff + (uint32_t)(G * 16));
       const int cref = __builtin_bit_cast(int, r0.w), ccnt = __builtin_bit_cast(int, r1.w);
       float tmn, tmx;
       slab_interval(mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), inv, noi, best_t, tmn, tmx);
       const bool hit = want_node && (cref >= 0) && (tmn <= tmx);
       const int key = hit ? (int)((__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j) : 0x7fffffff;
-      const int rank = group_rank(key);
-      const int nh = __popcll((ballot64(hit) >> gbase) & 0xffull);
-      uint2* const dst = hit ? (stk + sp + (nh - 1 - rank)) : trash;
+      const int rank = group_rank_g<G>(key);
+      const int nh = __popcll((ballot64(hit) >> gbase) & gmask);
+      const bool ovf = OVF && want_node && (sp + nh > A.stack_entries);     // the ray moves to k_trace_overflow
+      uint2* const dst = (hit && !ovf) ? (stk + sp + (nh - 1 - rank)) : trash;
       *dst = make_uint2((uint32_t)((cref << 4) | ccnt), __builtin_bit_cast(uint32_t, tmn));
-      sp += nh;
+      sp = ovf ? 0 : sp + nh;
+      if (OVF) {
+        if (ballot64(ovf) != 0) {
+          if (ovf && j == 0) A.ovf_queue[atomicAdd(A.ovf_count, 1)] = ray;
+          has_ray = has_ray && !ovf;
+        }
+      }
       pend_valid = pend_valid && !want_node;
       if (STATS) { st_box += (want_node && cref >= 0); st_node += (want_node && j == 0); st_it_node += (lane == 0); }
       wave_lds_sync();
@@ -245,8 +273,8 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       const uint32_t tb = valid ? __builtin_bit_cast(uint32_t, tt) : 0x7f7fffffu;
       const uint32_t key = valid ? (KEY_TRI | (uint32_t)__builtin_bit_cast(int, q2.y)) : KEY_MISS;
       // lexicographic (t, key) minimum as two 32-bit reductions: smallest t, then smallest key among the lanes holding it
-      const uint32_t win_tb = group_min_u32(tb);
-      const uint32_t win_key = group_min_u32(tb == win_tb ? key : 0xffffffffu);
+      const uint32_t win_tb = group_min_u32_g<G>(tb);
+      const uint32_t win_key = group_min_u32_g<G>(tb == win_tb ? key : 0xffffffffu);
       const uint64_t win = pack_tk(win_tb, win_key);
       // cand_wins for t > 0:  (t, key) < (best_t, best_key), where an equal t never displaces the initial bound
       const uint32_t bt = (best_t == 0.0f) ? 0u : __builtin_bit_cast(uint32_t, best_t);
@@ -741,7 +769,7 @@ void launch_from_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, 
   hipLaunchKernelGGL(k_from_xmajor_f3, dim3(blocks_for(w * h)), dim3(256), 0, st, src, dst, w, h);
 }
 
-size_t trace_coop_lds_bytes(int stack_entries) { return (size_t)4 * 8 * (stack_entries + 1) * sizeof(uint2); }
+size_t trace_coop_lds_bytes(int stack_entries, int width) { return (size_t)4 * (64 / width) * (stack_entries + 1) * sizeof(uint2); }
 
 void launch_analytic(hipStream_t st, const DevScene* S, const TraceArgs& A, bool stats) {
   TraceArgs B = A;
@@ -765,9 +793,22 @@ void launch_trace(hipStream_t st, const DevScene* S, const TraceArgs& A, int ker
     else hipLaunchKernelGGL(k_trace_overflow<false>, dim3(64), dim3(256), 0, st, S, A);
     return;
   }
-  const size_t lds = trace_coop_lds_bytes(A.stack_entries);
-  if (stats) hipLaunchKernelGGL(k_trace_coop<true>, dim3(grid_blocks), dim3(256), lds, st, S, A);
-  else hipLaunchKernelGGL(k_trace_coop<false>, dim3(grid_blocks), dim3(256), lds, st, S, A);
+  const size_t lds = trace_coop_lds_bytes(A.stack_entries, A.width);
+  const int variant = (stats ? 4 : 0) | (A.width == 4 ? 2 : 0) | (A.stack_overflow ? 1 : 0);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL((k_trace_coop<false, 8, false>), dim3(grid_blocks), dim3(256), lds, st, S, A); break;
+    case 1: hipLaunchKernelGGL((k_trace_coop<false, 8, true>), dim3(grid_blocks), dim3(256), lds, st, S, A); break;
+    case 2: hipLaunchKernelGGL((k_trace_coop<false, 4, false>), dim3(grid_blocks), dim3(256), lds, st, S, A); break;
+    case 3: hipLaunchKernelGGL((k_trace_coop<false, 4, true>), dim3(grid_blocks), dim3(256), lds, st, S, A); break;
+    case 4: hipLaunchKernelGGL((k_trace_coop<true, 8, false>), dim3(grid_blocks), dim3(256), lds, st, S, A); break;
+    case 5: hipLaunchKernelGGL((k_trace_coop<true, 8, true>), dim3(grid_blocks), dim3(256), lds, st, S, A); break;
+    case 6: hipLaunchKernelGGL((k_trace_coop<true, 4, false>), dim3(grid_blocks), dim3(256), lds, st, S, A); break;
+    default: hipLaunchKernelGGL((k_trace_coop<true, 4, true>), dim3(grid_blocks), dim3(256), lds, st, S, A); break;
+  }
+  if (A.stack_overflow) {
+    if (stats) hipLaunchKernelGGL(k_trace_overflow<true>, dim3(64), dim3(256), 0, st, S, A);
+    else hipLaunchKernelGGL(k_trace_overflow<false>, dim3(64), dim3(256), 0, st, S, A);
+  }
 }
 
 }  // namespace art
@@ -779,9 +820,12 @@ int trace_coop2_blocks_per_cu() {
   return nb;
 }
 int trace_coop2_stack_cap() { return kSlotStackCap; }
-int trace_coop_blocks_per_cu(int stack_entries) {
+int trace_coop_blocks_per_cu(int stack_entries, int width) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_coop<false>, 256, trace_coop_lds_bytes(stack_entries)) != hipSuccess || nb < 1) nb = 1;
+  const size_t lds = trace_coop_lds_bytes(stack_entries, width);
+  const hipError_t e = (width == 4) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_coop<false, 4, true>, 256, lds)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_coop<false, 8, true>, 256, lds);
+  if (e != hipSuccess || nb < 1) nb = 1;
   return nb;
 }
 }  // namespace art

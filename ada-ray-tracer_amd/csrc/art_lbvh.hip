@@ -159,7 +159,7 @@ __device__ __forceinline__ float next_dn(float v) { return (v == 0.0f) ? -1.4012
 __device__ __forceinline__ float next_up(float v) { return (v == 0.0f) ? 1.401298464e-45f : __int_as_float(__float_as_int(v) + (v > 0.0f ? 1 : -1)); }
 
 __global__ __launch_bounds__(128) void k_collapse(Lbvh T, const Item* __restrict__ in, int n_in, Item* __restrict__ out, int* out_count, int* node_count,
-                                                  int* max_stack, float* __restrict__ nodes, int max_leaf, float inflate_rel, float inflate_abs) {
+                                                  int* max_stack, float* __restrict__ nodes, int width, int max_leaf, float inflate_rel, float inflate_abs) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n_in) return;
   const Item it = in[q];
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(128) void k_collapse(Lbvh T, const Item* __restrict
   auto hi_of = [&](int id) { return id >= 0 ? T.nhi[id] : T.lhi[~id]; };
   if (it.n2 >= 0 && count_of(it.n2) > max_leaf) { const int2 c = T.child[it.n2]; ch[0] = c.x; ch[1] = c.y; nc = 2; }
   else { ch[0] = it.n2; nc = 1; }                       // tiny tree: a root with a single leaf child
-  while (nc < 8) {
+  while (nc < width) {
     int best = -1; float best_a = -1.0f;
     for (int k = 0; k < nc; ++k) {
       const int id = ch[k];
@@ -186,8 +186,9 @@ __global__ __launch_bounds__(128) void k_collapse(Lbvh T, const Item* __restrict
   }
   const int stack_here = it.stack_before + nc - 1;
   atomicMax(max_stack, stack_here + 1);
-  float* nd = nodes + (size_t)it.n8 * kNodeFloats;
-  for (int j = 0; j < 8; ++j) {
+  float* nd = nodes + (size_t)it.n8 * (size_t)node_floats(width);
+  const int hb = 4 * width;
+  for (int j = 0; j < width; ++j) {
     int ref = -1, cnt = 0;
     float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     if (j < nc) {
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(128) void k_collapse(Lbvh T, const Item* __restrict
       }
     }
     nd[4 * j + 0] = lo[0]; nd[4 * j + 1] = lo[1]; nd[4 * j + 2] = lo[2]; nd[4 * j + 3] = __int_as_float(ref);
-    nd[32 + 4 * j + 0] = hi[0]; nd[32 + 4 * j + 1] = hi[1]; nd[32 + 4 * j + 2] = hi[2]; nd[32 + 4 * j + 3] = __int_as_float(cnt);
+    nd[hb + 4 * j + 0] = hi[0]; nd[hb + 4 * j + 1] = hi[1]; nd[hb + 4 * j + 2] = hi[2]; nd[hb + 4 * j + 3] = __int_as_float(cnt);
   }
 }
 
@@ -226,6 +227,8 @@ struct Scratch {
 
 bool build_bvh8_gpu(const float* d_tri9, int n, const BvhBuildParams& prm, hipStream_t st, GpuBvh& out, std::string& err) {
   if (n < 2) { err = "build_bvh8_gpu needs at least 2 triangles"; return false; }
+  if (prm.width != 4 && prm.width != 8) { err = "BVH width must be 4 or 8"; return false; }
+  const int max_leaf = std::min(prm.max_leaf, prm.width);
   Scratch S;
   float4 *blo, *bhi, *llo, *lhi, *nlo, *nhi; uint32_t *keys, *keys2, *vals, *vals2; int *scene, *parent, *flag, *counters; int2 *child, *range; Item *qa, *qb;
   if (!S.get(&blo, n, err) || !S.get(&bhi, n, err) || !S.get(&llo, n, err) || !S.get(&lhi, n, err) || !S.get(&nlo, n, err) || !S.get(&nhi, n, err) ||
@@ -255,9 +258,9 @@ bool build_bvh8_gpu(const float* d_tri9, int n, const BvhBuildParams& prm, hipSt
   const size_t tri_bytes = (size_t)n * kTriFloats * sizeof(float);
   LB_TRY(hipMalloc(&out.tris, tri_bytes));
   hipLaunchKernelGGL(k_emit_tris, dim3(nb), dim3(256), 0, st, d_tri9, vals2, n, out.tris);
-  // collapse, one launch per BVH8 level; at most n/2+1 nodes can appear (every inner BVH8 node has >= 2 children)
+  // collapse, one launch per level of the wide tree; at most n/2+1 nodes can appear (every inner node has >= 2 children)
   const size_t node_cap = (size_t)n / 2 + 2;
-  LB_TRY(hipMalloc(&out.nodes, node_cap * kNodeFloats * sizeof(float)));
+  LB_TRY(hipMalloc(&out.nodes, node_cap * (size_t)node_floats(prm.width) * sizeof(float)));
   const int h_cnt[4] = {0, 1, 1, 0};    // [0] next-queue length, [1] node count (root = 0 taken), [2] max stack
   LB_TRY(hipMemcpyAsync(counters, h_cnt, sizeof h_cnt, hipMemcpyHostToDevice, st));
   const Item root = {0, 0, 0};
@@ -266,7 +269,7 @@ bool build_bvh8_gpu(const float* d_tri9, int n, const BvhBuildParams& prm, hipSt
   Item *in = qa, *nx = qb;
   while (n_in > 0) {
     hipLaunchKernelGGL(k_collapse, dim3((n_in + 127) / 128), dim3(128), 0, st, T, in, n_in, nx, counters, counters + 1, counters + 2, out.nodes,
-                       prm.max_leaf, prm.inflate_rel, prm.inflate_abs);
+                       prm.width, max_leaf, prm.inflate_rel, prm.inflate_abs);
     int h[3];
     LB_TRY(hipMemcpyAsync(h, counters, sizeof h, hipMemcpyDeviceToHost, st));
     LB_TRY(hipStreamSynchronize(st));

@@ -31,13 +31,14 @@ constexpr uint32_t KEY_SPHERE = 0u << 28, KEY_CORNELL = 1u << 28, KEY_QUAD = 2u 
 constexpr uint32_t KEY_MISS = 0x7fffffffu;
 constexpr uint32_t KEY_INDEX_MASK = (1u << 28) - 1u;
 
-// BVH8 node, 256 bytes = 64 floats, 256-byte aligned:
-//   half A (128 B): child j -> { lo.x, lo.y, lo.z, ref }      j = 0..7
-//   half B (128 B): child j -> { hi.x, hi.y, hi.z, count }
-//   ref = -1: empty slot.  count == 0: inner child, ref = node index.  count 1..8: leaf, ref = first
-//   triangle record.  Lane j of an 8-lane ray group loads exactly its 2 x 16 B; a group reads 2 x 128 B.
+// BVH node of width W (8 or 4 children), 32*W bytes = 8*W floats, aligned to its size:
+//   half A (16*W B): child j -> { lo.x, lo.y, lo.z, ref }      j = 0..W-1
+//   half B (16*W B): child j -> { hi.x, hi.y, hi.z, count }
+//   ref = -1: empty slot.  count == 0: inner child, ref = node index.  count 1..W: leaf, ref = first
+//   triangle record.  Lane j of a W-lane ray group loads exactly its 2 x 16 B; a group reads 2 x 16*W contiguous bytes.
 // Triangle record, 48 bytes = 12 floats: A.xyz B.xyz C.xyz prim(int) pad pad   (prim = index in the caller's mesh)
-constexpr int kNodeFloats = 64;
+constexpr int kNodeFloats = 64;      // W = 8; a node of width W has node_floats(W) floats
+constexpr int node_floats(int width) { return 8 * width; }
 constexpr int kTriFloats = 12;
 constexpr int kMaxLeafTris = 8;
 constexpr int kStackEntries = 160;  // private stack of the one-ray-per-lane traversal; art_upload_scene rejects deeper trees
@@ -55,7 +56,7 @@ struct DevScene {
   const float* bf_pos; const float* bf_nrm; const float* bf_uv; const int32_t* bf_idx;
   float bf_bbmin[3], bf_bbmax[3];
   // closest-hit mesh behind the BVH
-  int32_t n_tris; int32_t n_nodes;
+  int32_t n_tris; int32_t n_nodes; int32_t node_width;   // node_width: 8 or 4 children per node
   const float* nodes; const float* tris;
   const float* m_nrm; const float* m_uv; const int32_t* m_idx; const int32_t* m_matid;
   // camera (scene.ads:27-32)

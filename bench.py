@@ -90,8 +90,8 @@ def cpu_baseline(art, sd, args):
     osc = conv.OracleScene(sd)
     be = args._backend
     if sd.desc.n_meshes and sd.desc.meshes[0].mode == art.MESH_CLOSEST:
-        nodes, tris, _ = be.export_bvh()
-        osc.attach_bvh(nodes, tris)
+        nodes, tris, binfo = be.export_bvh()
+        osc.attach_bvh(nodes, tris, binfo.node_width)
     cores = args.cpu_threads if args.cpu_threads > 0 else host_cpu_share()
     prm = orc.make_params(w, h, orc.PT_MIS, True, 8, 1, seed=1, nthreads=cores)
     orc.render(osc.scene, orc.make_params(32, 18, orc.PT_MIS, True, 8, 1, seed=1, nthreads=cores))      # warm threads / caches
@@ -250,7 +250,7 @@ def main():
             "config": {"workload": "%s, %dx%d, PT_MIS depth 8, 2x2 AA, %d spp per step" % (scene_name, W, H, 4 * args.vthreads),
                        "spp_per_step": 4 * args.vthreads, "rays_per_sample": round(total_rays / max(1.0, total_samples), 3),
                        "Msamples_per_s": round(total_samples / elapsed / 1e6, 3), "parallelism": "pixel-tiles x%d" % world,
-                       "bvh_nodes": info.n_nodes, "bvh_build_ms": round(info.build_ms, 1), "bvh_max_stack": info.max_stack, "scene_gen_s": round(t_gen, 2),
+                       "bvh_width": info.node_width, "bvh_nodes": info.n_nodes, "bvh_build_ms": round(info.build_ms, 1), "bvh_max_stack": info.max_stack, "scene_gen_s": round(t_gen, 2),
                        "scene_upload_s": round(t_upload, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -125,7 +125,7 @@ typedef struct ArtHit {          /* geometry.ads:57-67 flattened */
   float   u, v;                  /* triangle barycentrics (weight of C, weight of B; geometry.adb:245-246) */
 } ArtHit;
 
-typedef struct ArtBvhInfo { int32_t n_nodes, n_tris, max_stack, reserved; double build_ms; } ArtBvhInfo;
+typedef struct ArtBvhInfo { int32_t n_nodes, n_tris, max_stack, node_width; double build_ms; } ArtBvhInfo;   /* nodes: 8*node_width floats each */
 
 int  art_init(int device_ordinal);                       /* -1: keep the current HIP device */
 int  art_set_stream(void* hip_stream);                   /* hipStream_t; NULL = default stream */

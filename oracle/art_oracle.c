@@ -715,13 +715,13 @@ static hit_t intersect_mesh_bf(const ray_t* r, const orc_mesh* m, uint64_t* tri_
  * (embree_connect.cpp:196-238) with the reference's Moeller-Trumbore arithmetic (geometry.adb:231-263)
  * and window (0, 1e6) (geometry.adb:277-278).  Ties: lowest triangle index.  matId from material_ids.
  * Hit record for the shader uses the interpolated vertex normal exactly like geometry.adb:301.       */
-static void bvh_walk_one(const float* nodes, const float* tris, const ray_t* r, float tfar,
+static void bvh_walk_one(const float* nodes, const float* tris, int width, const ray_t* r, float tfar,
                          lite_hit* best, int32_t* best_prim, uint64_t* counters /* box, tri, node, leaf */);
 
 static hit_t intersect_mesh_closest(const ray_t* r, const orc_mesh* m, uint64_t* tri_tests) {
   if (m->bvh_nodes && m->bvh_tris) {
     lite_hit bh; int32_t prim = -1; uint64_t c[4] = { 0, 0, 0, 0 };
-    bvh_walk_one(m->bvh_nodes, m->bvh_tris, r, ORC_INFINITY, &bh, &prim, c);
+    bvh_walk_one(m->bvh_nodes, m->bvh_tris, m->bvh_width ? m->bvh_width : 8, r, ORC_INFINITY, &bh, &prim, c);
     *tri_tests += c[1];
     if (prim < 0) return null_hit();
     return mesh_hit_record(m, bh, prim, m->matid[prim]);
@@ -1185,8 +1185,9 @@ void orc_build_cornell(orc_cornell_storage* st, const orc_mesh* pyramid, int use
 /* Tri  = 12 floats: A.xyz B.xyz C.xyz prim(int bits) pad pad.                               */
 /* ======================================================================================== */
 
-static void bvh_walk_one(const float* nodes, const float* tris, const ray_t* rp, float tfar,
+static void bvh_walk_one(const float* nodes, const float* tris, int width, const ray_t* rp, float tfar,
                          lite_hit* best, int32_t* best_prim_out, uint64_t* counters) {
+  const int W = width, HB = 4 * width;          /* children per node; float offset of the {hi, count} half */
   const ray_t r = *rp;
   /* the product's slab arithmetic (csrc/art_isect.h slab_setup / slab_interval): finite inverse, one fma per plane */
   const float tiny = 1.0e-30f;
@@ -1206,21 +1207,21 @@ static void bvh_walk_one(const float* nodes, const float* tris, const ray_t* rp,
     int32_t ref = stack[sp].ref, c = stack[sp].cnt; float etmin = stack[sp].tmin;
     if (etmin > best_t) continue;
     if (c == 0) {
-      const float* nd = nodes + (size_t)ref * 64;
+      const float* nd = nodes + (size_t)ref * (size_t)(8 * W);
       uint32_t key[8]; int32_t cref[8], ccnt[8]; float ctm[8]; int nh = 0;
       counters[2]++;
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < W; ++j) {
         int32_t rj = f2i(nd[4 * j + 3]);
         if (rj < 0) continue;
         counters[0]++;
-        float t0x = fmaf(nd[4 * j + 0], idx, nox), t1x = fmaf(nd[32 + 4 * j + 0], idx, nox);
-        float t0y = fmaf(nd[4 * j + 1], idy, noy), t1y = fmaf(nd[32 + 4 * j + 1], idy, noy);
-        float t0z = fmaf(nd[4 * j + 2], idz, noz), t1z = fmaf(nd[32 + 4 * j + 2], idz, noz);
+        float t0x = fmaf(nd[4 * j + 0], idx, nox), t1x = fmaf(nd[HB + 4 * j + 0], idx, nox);
+        float t0y = fmaf(nd[4 * j + 1], idy, noy), t1y = fmaf(nd[HB + 4 * j + 1], idy, noy);
+        float t0z = fmaf(nd[4 * j + 2], idz, noz), t1z = fmaf(nd[HB + 4 * j + 2], idz, noz);
         float tmn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
         float tmx = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best_t));
         if (tmn <= tmx) {
           uint32_t kb; memcpy(&kb, &tmn, 4);
-          key[nh] = (kb & ~7u) | (uint32_t)j; cref[nh] = rj; ccnt[nh] = f2i(nd[32 + 4 * j + 3]); ctm[nh] = tmn; nh++;
+          key[nh] = (kb & ~7u) | (uint32_t)j; cref[nh] = rj; ccnt[nh] = f2i(nd[HB + 4 * j + 3]); ctm[nh] = tmn; nh++;
         }
       }
       for (int a = 1; a < nh; ++a) {              /* ascending insertion sort by key */
@@ -1246,6 +1247,12 @@ static void bvh_walk_one(const float* nodes, const float* tris, const ray_t* rp,
 void orc_bvh_walk(const float* nodes, int32_t n_nodes, const float* tris, int32_t n_tris,
                   const float* origins, const float* dirs, const float* tfar, int64_t n,
                   float* out_t, int32_t* out_prim, orc_bvh_counters* cnt) {
+  orc_bvh_walk_w(nodes, n_nodes, tris, n_tris, 8, origins, dirs, tfar, n, out_t, out_prim, cnt);
+}
+
+void orc_bvh_walk_w(const float* nodes, int32_t n_nodes, const float* tris, int32_t n_tris, int32_t width,
+                    const float* origins, const float* dirs, const float* tfar, int64_t n,
+                    float* out_t, int32_t* out_prim, orc_bvh_counters* cnt) {
   uint64_t boxes = 0, tritests = 0, nvis = 0, lvis = 0;
   (void)n_nodes; (void)n_tris;
 #pragma omp parallel for schedule(dynamic, 256) reduction(+ : boxes, tritests, nvis, lvis)
@@ -1253,7 +1260,7 @@ void orc_bvh_walk(const float* nodes, int32_t n_nodes, const float* tris, int32_
     ray_t r; r.x = 0; r.y = 0; r.origin = ld3(origins + 3 * i); r.direction = ld3(dirs + 3 * i);
     lite_hit bh; int32_t prim; uint64_t c[4] = { 0, 0, 0, 0 };
     const float tf = tfar ? tfar[i] : ORC_INFINITY;   /* the product's unbounded rays start at Float'Last */
-    bvh_walk_one(nodes, tris, &r, tf, &bh, &prim, c);
+    bvh_walk_one(nodes, tris, width, &r, tf, &bh, &prim, c);
     boxes += c[0]; tritests += c[1]; nvis += c[2]; lvis += c[3];
     if (out_t) out_t[i] = (prim >= 0) ? bh.tmin : tf;
     if (out_prim) out_prim[i] = prim;

@@ -79,6 +79,7 @@ typedef struct {
    * search walks it instead of scanning all triangles -- same result (tests), used for the timed CPU baseline. */
   const float* bvh_nodes;
   const float* bvh_tris;
+  int32_t bvh_width;      /* children per node of that tree: 8 or 4 (0 = 8) */
 } orc_mesh;
 
 typedef struct {
@@ -173,6 +174,10 @@ void orc_bvh_walk(const float* nodes /* 64 floats per node */, int32_t n_nodes,
                   const float* tris /* 12 floats per tri  */, int32_t n_tris,
                   const float* origins, const float* dirs, const float* tfar, int64_t n,
                   float* out_t, int32_t* out_prim, orc_bvh_counters* cnt);
+/* same for a tree of `width` children per node (8 * width floats per node: width x {lo.xyz, ref}, then width x {hi.xyz, count}) */
+void orc_bvh_walk_w(const float* nodes, int32_t n_nodes, const float* tris, int32_t n_tris, int32_t width,
+                    const float* origins, const float* dirs, const float* tfar, int64_t n,
+                    float* out_t, int32_t* out_prim, orc_bvh_counters* cnt);
 
 #ifdef __cplusplus
 }

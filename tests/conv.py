@@ -59,13 +59,14 @@ class OracleScene:
         self.scene = s
         self._keep = sd
 
-    def attach_bvh(self, nodes, tris):
+    def attach_bvh(self, nodes, tris, width=8):
         """Let the oracle's closest-hit mesh search walk the product's exported BVH (CPU baseline timing)."""
         self._bvh = (np.ascontiguousarray(nodes, np.float32), np.ascontiguousarray(tris, np.float32))
         for i in range(self.scene.n_meshes):
             if self.meshes[i].mode == orc.MESH_CLOSEST:
                 self.meshes[i].bvh_nodes = self._bvh[0].ctypes.data_as(orc.f32p)
                 self.meshes[i].bvh_tris = self._bvh[1].ctypes.data_as(orc.f32p)
+                self.meshes[i].bvh_width = width
 
 
 def hits_to_arrays(hits):

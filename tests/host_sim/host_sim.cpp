@@ -20,6 +20,7 @@ extern "C" void hs_set_bvh_param(const char* name, double v) {
   else if (n == "spatial_budget") g_bp.spatial_budget = (float)v;
   else if (n == "spatial_bins") g_bp.spatial_bins = (int)v;
   else if (n == "max_leaf") g_bp.max_leaf = (int)v;
+  else if (n == "width") g_bp.width = (int)v;
   else if (n == "node_cost") g_bp.node_cost = (float)v;
   else if (n == "leaf_base") g_bp.leaf_base = (float)v;
   else if (n == "tri_cost") g_bp.tri_cost = (float)v;
@@ -100,10 +101,10 @@ extern "C" int hs_render(const ArtSceneDesc* sd, const ArtPassParams* p, int w, 
 }
 
 // BVH of the scene's CLOSEST mesh in the product's packet layout (what art_export_bvh returns on the GPU box)
-extern "C" int hs_bvh(const ArtSceneDesc* sd, float* nodes, long long node_cap, float* tris, long long tri_cap, int* info3) {
+extern "C" int hs_bvh(const ArtSceneDesc* sd, float* nodes, long long node_cap, float* tris, long long tri_cap, int* info3 /* n_nodes, n_tris, max_stack, width */) {
   HostScene hs; BvhBuildParams bp = g_bp;
   if (!flatten_scene(*sd, bp, hs, g_err)) return 1;
-  info3[0] = hs.bvh.n_nodes; info3[1] = hs.bvh.n_tris; info3[2] = hs.bvh.max_stack;
+  info3[0] = hs.bvh.n_nodes; info3[1] = hs.bvh.n_tris; info3[2] = hs.bvh.max_stack; info3[3] = hs.bvh.width;
   if (nodes) { if (node_cap < (long long)hs.bvh.nodes.size()) return 2; std::memcpy(nodes, hs.bvh.nodes.data(), hs.bvh.nodes.size() * 4); }
   if (tris) { if (tri_cap < (long long)hs.bvh.tris.size()) return 2; std::memcpy(tris, hs.bvh.tris.data(), hs.bvh.tris.size() * 4); }
   return 0;

@@ -49,14 +49,14 @@ def trace(art, sd, origins, dirs, tfar=None):
 
 def bvh(art, sd):
     L = lib(art)
-    info = (C.c_int * 3)()
+    info = (C.c_int * 4)()
     L.hs_bvh.argtypes = [C.POINTER(art.ArtSceneDesc), art.f32p, C.c_longlong, art.f32p, C.c_longlong, C.POINTER(C.c_int)]
     if L.hs_bvh(C.byref(sd.desc), None, 0, None, 0, info):
         raise RuntimeError(L.hs_last_error().decode())
-    nodes = np.zeros(info[0] * 64, np.float32); tris = np.zeros(info[1] * 12, np.float32)
+    nodes = np.zeros(info[0] * 8 * info[3], np.float32); tris = np.zeros(info[1] * 12, np.float32)
     if L.hs_bvh(C.byref(sd.desc), nodes.ctypes.data_as(art.f32p), nodes.size, tris.ctypes.data_as(art.f32p), tris.size, info):
         raise RuntimeError("hs_bvh failed")
-    return nodes, tris, dict(n_nodes=info[0], n_tris=info[1], max_stack=info[2])
+    return nodes, tris, dict(n_nodes=info[0], n_tris=info[1], max_stack=info[2], width=info[3])
 
 
 def set_bvh_param(art, name, value):

@@ -42,7 +42,7 @@ class Mesh(C.Structure):
     _fields_ = [("mode", C.c_int32), ("nverts", C.c_int32), ("ntris", C.c_int32),
                 ("pos", f32p), ("nrm", f32p), ("uv", f32p), ("idx", i32p), ("matid", i32p),
                 ("bbmin", C.c_float * 3), ("bbmax", C.c_float * 3),
-                ("bvh_nodes", f32p), ("bvh_tris", f32p)]
+                ("bvh_nodes", f32p), ("bvh_tris", f32p), ("bvh_width", C.c_int32)]
 
 
 class Scene(C.Structure):
@@ -117,8 +117,8 @@ def lib():
     L.orc_save_bmp.restype = C.c_int; L.orc_save_bmp.argtypes = [C.c_char_p, u32p, C.c_int32, C.c_int32]
     L.orc_bmp_bytes.restype = C.c_int64
     L.orc_bmp_bytes.argtypes = [u32p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.c_int64]
-    L.orc_bvh_walk.argtypes = [f32p, C.c_int32, f32p, C.c_int32, f32p, f32p, f32p, C.c_int64, f32p, i32p,
-                               C.POINTER(BvhCounters)]
+    L.orc_bvh_walk_w.argtypes = [f32p, C.c_int32, f32p, C.c_int32, C.c_int32, f32p, f32p, f32p, C.c_int64, f32p, i32p,
+                                 C.POINTER(BvhCounters)]
     _lib = L
     return L
 
@@ -223,11 +223,11 @@ def closest_hits(scene, origins, dirs):
     return out
 
 
-def bvh_walk(nodes, tris, origins, dirs, tfar=None):
+def bvh_walk(nodes, tris, origins, dirs, tfar=None, width=8):
     nodes = np.ascontiguousarray(nodes, np.float32); tris = np.ascontiguousarray(tris, np.float32)
     o = np.ascontiguousarray(origins, np.float32); d = np.ascontiguousarray(dirs, np.float32)
     n = o.shape[0]
     t = np.zeros(n, np.float32); prim = np.zeros(n, np.int32); cnt = BvhCounters()
     tf = None if tfar is None else fp(np.ascontiguousarray(tfar, np.float32))
-    lib().orc_bvh_walk(fp(nodes), nodes.size // 64, fp(tris), tris.size // 12, fp(o), fp(d), tf, n, fp(t), ip(prim), C.byref(cnt))
+    lib().orc_bvh_walk_w(fp(nodes), nodes.size // (8 * width), fp(tris), tris.size // 12, width, fp(o), fp(d), tf, n, fp(t), ip(prim), C.byref(cnt))
     return t, prim, cnt

@@ -10,6 +10,14 @@ from test_gpu_parity import _assert_hits_equal, _random_rays, assert_radiance_eq
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def width8(backend):
+    """k_trace_coop2 is written for 8-lane groups: these tests build width-8 trees"""
+    backend.set_option("bvh_width", 8)
+    yield
+    backend.set_option("bvh_width", 4)
+
+
 @pytest.fixture()
 def coop2(art, backend):
     backend.set_option("trace_kernel", art.TRACE_COOP2)
@@ -56,7 +64,7 @@ def test_coop2_counters_match_oracle_walk(art, backend):
     backend.upload_scene(sd)
     nodes, tris, info = backend.export_bvh()
     o, d = _random_rays(40000, 8)
-    t, prim, cnt = orc.bvh_walk(nodes, tris, o, d)
+    t, prim, cnt = orc.bvh_walk(nodes, tris, o, d, width=info.node_width)
     hits, st = backend.trace_rays(o, d, kernel=art.TRACE_COOP2, want_stats=True)
     gprim = np.array([h.prim_index if h.is_hit else -1 for h in hits], np.int32)
     assert np.array_equal(gprim, prim)

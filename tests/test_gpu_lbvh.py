@@ -13,15 +13,19 @@ from test_gpu_parity import _assert_hits_equal, _random_rays, bits
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture()
-def gpu_builder(backend):
+@pytest.fixture(params=[4, 8])
+def gpu_builder(backend, request):
+    """GPU builder for both node widths (4 = default kernel layout, 8 = the 8-lanes-per-ray layout)"""
     backend.set_option("bvh_builder", 1)
+    backend.set_option("bvh_width", request.param)
     yield backend
     backend.set_option("bvh_builder", 0)
+    backend.set_option("bvh_width", 4)
 
 
 def _check_tree(nodes, tris, info, mesh_pos, mesh_idx):
-    nodes = nodes.reshape(-1, 64); tris = tris.reshape(-1, 12)
+    W = info.node_width
+    nodes = nodes.reshape(-1, 8 * W); tris = tris.reshape(-1, 12)
     n = tris.shape[0]
     prim = tris[:, 9].view(np.int32)
     assert np.array_equal(np.sort(prim), np.arange(n)), "triangle records are not a permutation of the input"
@@ -36,16 +40,16 @@ def _check_tree(nodes, tris, info, mesh_pos, mesh_idx):
         nonlocal max_depth_stack
         visited[ni] += 1
         nd = nodes[ni]
-        ref = nd[3:32:4].view(np.int32); cnt = nd[35:64:4].view(np.int32)
+        ref = nd[3:4 * W:4].view(np.int32); cnt = nd[4 * W + 3:8 * W:4].view(np.int32)
         nch = int((ref >= 0).sum())
         assert nch >= 1 and np.all(ref[:nch] >= 0) and np.all(ref[nch:] < 0), "children are not packed to the front"
         here = stack_before + nch - 1
         max_depth_stack = max(max_depth_stack, here + 1)
         lo_all = np.full(3, np.inf, np.float32); hi_all = np.full(3, -np.inf, np.float32)
         for j in range(nch):
-            lo = nd[4 * j:4 * j + 3]; hi = nd[32 + 4 * j:32 + 4 * j + 3]
+            lo = nd[4 * j:4 * j + 3]; hi = nd[4 * W + 4 * j:4 * W + 4 * j + 3]
             if cnt[j] > 0:
-                assert cnt[j] <= 8
+                assert cnt[j] <= W
                 r = slice(int(ref[j]), int(ref[j]) + int(cnt[j]))
                 seen[r] += 1
                 clo, chi = tlo[r].min(axis=0), thi[r].max(axis=0)
@@ -116,7 +120,7 @@ def test_lbvh_counters_match_oracle_walk_of_the_exported_tree(art, gpu_builder):
     gpu_builder.upload_scene(sd)
     nodes, tris, info = gpu_builder.export_bvh()
     o, d = _random_rays(40000, 9)
-    t, prim, cnt = orc.bvh_walk(nodes, tris, o, d)
+    t, prim, cnt = orc.bvh_walk(nodes, tris, o, d, width=info.node_width)
     for kernel in (art.TRACE_COOP, art.TRACE_SIMPLE):
         hits, st = gpu_builder.trace_rays(o, d, kernel=kernel, want_stats=True)
         gprim = np.array([h.prim_index if h.is_hit else -1 for h in hits], np.int32)

@@ -182,7 +182,7 @@ def test_traversal_counters_match_oracle_walk(art, backend):
     nodes, tris, info = backend.export_bvh()
     o, d = _random_rays(40000, 8)
     d[:100, 0] = 0.0   # axis-parallel directions: 1/0 = inf in the slab test
-    t, prim, cnt = orc.bvh_walk(nodes, tris, o, d)
+    t, prim, cnt = orc.bvh_walk(nodes, tris, o, d, width=info.node_width)
     for kernel in (art.TRACE_COOP, art.TRACE_SIMPLE):
         hits, st = backend.trace_rays(o, d, kernel=kernel, want_stats=True)
         gprim = np.array([h.prim_index if h.is_hit else -1 for h in hits], np.int32)
@@ -247,8 +247,8 @@ def test_baseline_scenes_at_full_triangle_count(art, backend, config):
           "c5": lambda: scenes.mixed_scene(20000, 5)}[config]()
     backend.upload_scene(sd)
     osc = conv.OracleScene(sd)
-    nodes, tris, _ = backend.export_bvh()
-    osc.attach_bvh(nodes, tris)
+    nodes, tris, info = backend.export_bvh()
+    osc.attach_bvh(nodes, tris, info.node_width)
     W, H = (96, 54)
     backend.resize(W, H)
     p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=1)

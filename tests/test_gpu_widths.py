@@ -1,0 +1,101 @@
+"""Both node widths of the cooperative trace kernel -- 4 lanes per ray with 4-wide nodes (the default: fewer lane-steps per ray)
+and 8 lanes per ray with 8-wide nodes -- and the capped LDS stack with its overflow path (k_trace_overflow), against the CPU oracle."""
+import numpy as np
+import pytest
+
+import conv
+import orc
+from test_gpu_parity import _assert_hits_equal, _random_rays, assert_radiance_equal, bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=[4, 8])
+def wbackend(backend, request):
+    backend.set_option("bvh_width", request.param)
+    yield backend
+    backend.set_option("bvh_width", 4)
+    backend.set_option("lds_stack_cap", 0)
+
+
+@pytest.mark.parametrize("ntris", [1, 3, 7, 300, 20000])
+def test_hits_match_brute_force(art, wbackend, ntris):
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.synthetic_scene(ntris, 3)
+    osc = conv.OracleScene(sd)
+    wbackend.upload_scene(sd)
+    o, d = _random_rays(30000, ntris + 2)
+    want = orc.closest_hits(osc.scene, o, d)
+    for kernel in (art.TRACE_COOP, art.TRACE_SIMPLE):
+        _assert_hits_equal(wbackend.trace_rays(o, d, kernel=kernel), want)
+
+
+def test_counters_match_oracle_walk(art, wbackend):
+    from ada_ray_tracer_amd import scenes
+    mesh = scenes.random_triangles(20000, 77)
+    lights = [dict(shape=art.LIGHT_SPHERE, mat=4, center=(0.0, 4.5, 1.0), radius=0.5, intensity=(10.0, 10.0, 10.0), surfaceArea=3.14159)]
+    sd = art.SceneDesc([], lights, scenes.cornell_materials(), [mesh], None, scenes.REFERENCE_CAMERA)
+    wbackend.upload_scene(sd)
+    nodes, tris, info = wbackend.export_bvh()
+    assert nodes.size == info.n_nodes * 8 * info.node_width
+    o, d = _random_rays(40000, 8)
+    d[:100, 0] = 0.0
+    t, prim, cnt = orc.bvh_walk(nodes, tris, o, d, width=info.node_width)
+    for kernel in (art.TRACE_COOP, art.TRACE_SIMPLE):
+        hits, st = wbackend.trace_rays(o, d, kernel=kernel, want_stats=True)
+        gprim = np.array([h.prim_index if h.is_hit else -1 for h in hits], np.int32)
+        assert np.array_equal(gprim, prim)
+        assert (st.box_tests, st.tri_tests, st.node_visits, st.leaf_visits, st.traced_rays) == \
+               (cnt.box_tests, cnt.tri_tests, cnt.node_visits, cnt.leaf_visits, cnt.rays)
+
+
+@pytest.mark.parametrize("rt", ["PT_MIS", "PT_SHADOW", "PT_STUPID"])
+def test_render_bit_exact(art, wbackend, rt):
+    from ada_ray_tracer_amd import scenes
+    for sd, seed in ((scenes.synthetic_scene(2000, 3), 3), (scenes.mixed_scene(1500, 5), 6)):
+        osc = conv.OracleScene(sd)
+        wbackend.upload_scene(sd)
+        wbackend.resize(64, 64)
+        accum, _, spp = wbackend.render_pass(art.Backend.pass_params(getattr(art, rt), True, 8, 1, seed=seed), 0)
+        ref, _, cnt = orc.render(osc.scene, orc.make_params(64, 64, getattr(orc, rt), True, 8, 1, seed=seed))
+        assert_radiance_equal(accum, ref, spp)
+        assert wbackend.stats().rays == cnt.rays
+
+
+@pytest.mark.parametrize("cap", [2, 5, 9])
+def test_capped_lds_stack_overflow_path(art, wbackend, cap):
+    """A tiny LDS stack sends most rays through the overflow queue and k_trace_overflow: same hits, same image."""
+    from ada_ray_tracer_amd import scenes
+    wbackend.set_option("lds_stack_cap", cap)
+    sd = scenes.synthetic_scene(20000, 3)
+    osc = conv.OracleScene(sd)
+    wbackend.upload_scene(sd)
+    o, d = _random_rays(30000, 78)
+    _assert_hits_equal(wbackend.trace_rays(o, d), orc.closest_hits(osc.scene, o, d))
+    sd = scenes.synthetic_scene(2000, 3)
+    osc = conv.OracleScene(sd)
+    wbackend.upload_scene(sd)
+    wbackend.resize(64, 64)
+    accum, _, spp = wbackend.render_pass(art.Backend.pass_params(art.PT_MIS, True, 8, 1, seed=3), 0)
+    ref, _, cnt = orc.render(osc.scene, orc.make_params(64, 64, orc.PT_MIS, True, 8, 1, seed=3))
+    assert_radiance_equal(accum, ref, spp)
+    assert wbackend.stats().rays == cnt.rays
+
+
+def test_full_size_scene_same_image_for_both_widths(art, backend):
+    """C4 (1M triangles), reduced frame: the image does not depend on the node width (nor on the overflow path, which the
+    width-4 tree of this scene uses: its stack bound exceeds the LDS stack)."""
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.synthetic_scene(1000000, 4)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 4, seed=5)
+    out = []
+    try:
+        for w in (4, 8):
+            backend.set_option("bvh_width", w)
+            backend.upload_scene(sd)
+            backend.resize(320, 180)
+            accum, _, spp = backend.render_pass(p, 0)
+            out.append((accum.copy(), backend.stats().rays))
+    finally:
+        backend.set_option("bvh_width", 4)
+    assert np.array_equal(bits(out[0][0]), bits(out[1][0])) and out[0][1] == out[1][1]
