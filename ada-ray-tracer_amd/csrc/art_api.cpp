@@ -129,7 +129,7 @@ int upload_scene(const ArtSceneDesc* d) {
   // largest size that does; then pushes are checked and the few rays that go deeper are finished by k_trace_overflow.
   {
     const int groups = 64 / hs.hdr.node_width;
-    const int lds_cap = (160 * 1024 / 8) / (4 * groups * 8) - 1;            // entries per ray (one extra slot is the sink of masked pushes)
+    const int lds_cap = (160 * 1024 / 8) / (4 * groups * 8) - 3;            // entries per ray (+ 2 guard entries + the sink of masked pushes)
     const int want = std::max(8, hs.bvh.max_stack);
     c.stack_entries = std::min(want, c.lds_stack_cap > 0 ? c.lds_stack_cap : lds_cap);
     c.stack_overflow = want > c.stack_entries;

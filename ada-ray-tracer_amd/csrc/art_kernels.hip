@@ -93,6 +93,16 @@ template <> __device__ __forceinline__ uint32_t group_min_u32_g<4>(uint32_t k) {
   return k;
 }
 
+// number of lanes of my group for which p holds
+template <int G> __device__ __forceinline__ int group_count_g(bool p, int gbase);
+template <> __device__ __forceinline__ int group_count_g<8>(bool p, int gbase) { return __popcll((__builtin_amdgcn_ballot_w64(p) >> gbase) & 0xffull); }
+template <> __device__ __forceinline__ int group_count_g<4>(bool p, int) {       // two DPP adds inside the quad
+  int h = p ? 1 : 0;
+  h += dpp_i<DPP_XOR1>(h);
+  h += dpp_i<DPP_XOR2>(h);
+  return h;
+}
+
 // hip's __ballot() round-trips the predicate through a VGPR (v_cndmask + v_cmp); the builtin keeps it a lane mask
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
@@ -117,13 +127,18 @@ __device__ __forceinline__ void wave_lds_sync() {
 template <bool STATS, int G, bool OVF>
 __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(const DevScene* __restrict__ Sp, const TraceArgs A) {
   extern __shared__ uint2 lds_stack[];
+  char* const lds = reinterpret_cast<char*>(lds_stack);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int NG = 64 / G;                                   // ray groups per wave
   const int j = lane & (G - 1), g = lane / G;
   const int gbase = lane & ~(G - 1);
-  uint2* const stk = lds_stack + (size_t)(wave * NG + g) * (A.stack_entries + 1);
+  // Stack of one ray in LDS (bytes from sb):  0, 8: two guard entries | 16 + 8 i: entry i | 16 + 8 entries: sink of masked pushes.
+  // The stack pointer is kept as the LDS address `sa = sb + 8 sp`: the two top entries are then always at sa + 8 and sa + 0 (one
+  // ds_read2_b64, no clamping: an empty stack reads the guards), and a push goes to sa + 8 (nh - rank) + 8.
+  const uint32_t sb = (uint32_t)(wave * NG + g) * (uint32_t)(A.stack_entries + 3) * 8u;
+  const uint32_t sink = sb + 16u + (uint32_t)A.stack_entries * 8u;
+  const uint32_t slimit = sb + (uint32_t)A.stack_entries * 8u;      // sa + 8 nh > slimit: the push does not fit
   const uint64_t leaders = (G == 8) ? 0x0101010101010101ull : 0x1111111111111111ull;
-  constexpr uint64_t gmask = (1ull << G) - 1ull;
   // kernel-argument bases stay in SGPRs; per-lane addressing is a 32-bit byte offset (scalar base + vector offset loads).
   // art_upload_scene guarantees n_nodes * 256 and n_tris * 48 fit in 32 bits.
   const char* const nodes_b = reinterpret_cast<const char*>(A.nodes);
@@ -138,7 +153,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
   const int n_seg = A.segments;
   int seg = (int)blockIdx.x & (n_seg - 1), segs_left = n_seg;   // wave-uniform
   bool has_ray = false;               // group-uniform from here on
-  int sp = 0, ray = 0;
+  uint32_t sa = sb; int ray = 0;
   f3 o = mk3(0, 0, 0), d = o, inv = o, noi = o;
   float best_t = 0.0f; uint32_t best_key = KEY_MISS;
   uint32_t pend = 0; bool pend_valid = false;        // popped entry waiting for its phase
@@ -182,7 +197,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         best_t = far_found ? next_up_pos(shm) : best_t;
         best_key = far_found ? KEY_MISS : best_key;
         held_key = KEY_MISS;
-        sp = 0; pend = 0u; pend_valid = true;                     // entry 0 = root node
+        sa = sb; pend = 0u; pend_valid = true;                    // entry 0 = root node
         has_ray = true; need = false;
       }
       chunk_pos += min(avail, n_need);
@@ -194,7 +209,6 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
     // lanes compute on clamped operands and are masked by selects; LDS pushes of non-hit lanes go to the group's
     // spare (padding) slot.  The kernel is now VALU-issue-bound, so bookkeeping (retire / refill / leaf vote) is kept
     // out of the inner node loop.
-    uint2* const trash = stk + A.stack_entries;
 
     // ---------------- inner loop: pop + node phase, as long as enough of the wave's groups have a node to expand
     bool want_leaf = false;
@@ -202,14 +216,14 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       // next stack entry: the two top entries are read together (one LDS wait); entries culled by the current hit are dropped
       {
         const bool need = has_ray && !pend_valid;
-        const uint2 e1 = stk[max(sp - 1, 0)], e2 = stk[max(sp - 2, 0)];
-        const bool v1 = need && sp > 0;
+        const uint2 e2 = *reinterpret_cast<const uint2*>(lds + sa), e1 = *reinterpret_cast<const uint2*>(lds + sa + 8u);
+        const bool v1 = need && sa > sb;
         const bool ok1 = v1 && !(__builtin_bit_cast(float, e1.y) > best_t);
-        const bool v2 = v1 && !ok1 && sp > 1;
+        const bool v2 = v1 && !ok1 && sa > sb + 8u;
         const bool ok2 = v2 && !(__builtin_bit_cast(float, e2.y) > best_t);
         pend = ok1 ? e1.x : (ok2 ? e2.x : pend);
         pend_valid = pend_valid || ok1 || ok2;
-        sp -= (v1 ? 1 : 0) + (v2 ? 1 : 0);
+        sa = v2 ? sa - 16u : (v1 ? sa - 8u : sa);
       }
       const int cnt = (int)(pend & 15u);
       const bool active = has_ray && pend_valid;
@@ -218,7 +232,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       const uint64_t node_mask = ballot64(want_node);
       // leave when fewer than node_min groups still expand nodes (the others wait on a leaf, are finished, or idle)
       if (__popcll(node_mask) < 8 * A.node_min) {
-        if (node_mask == 0 || ballot64(want_leaf || (has_ray && !active && sp == 0)) != 0 || !exhausted) break;
+        if (node_mask == 0 || ballot64(want_leaf || (has_ray && !active && sa == sb)) != 0 || !exhausted) break;
       }
       // ---- node phase: lane j slab-tests child j; groups not taking part read the root node and discard the result
       const int ref = (int)(pend >> 4);
@@ -231,11 +245,13 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       const bool hit = want_node && (cref >= 0) && (tmn <= tmx);
       const int key = hit ? (int)((__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j) : 0x7fffffff;
       const int rank = group_rank_g<G>(key);
-      const int nh = __popcll((ballot64(hit) >> gbase) & gmask);
-      const bool ovf = OVF && want_node && (sp + nh > A.stack_entries);     // the ray moves to k_trace_overflow
-      uint2* const dst = (hit && !ovf) ? (stk + sp + (nh - 1 - rank)) : trash;
-      *dst = make_uint2((uint32_t)((cref << 4) | ccnt), __builtin_bit_cast(uint32_t, tmn));
-      sp = ovf ? 0 : sp + nh;
+      const int nh = group_count_g<G>(hit, gbase);
+      const uint32_t top = sa + (uint32_t)nh * 8u;
+      const bool ovf = OVF && want_node && (top > slimit);                  // the ray moves to k_trace_overflow
+      const uint32_t dst_hit = sa + (uint32_t)(nh - rank) * 8u + 8u;
+      const uint32_t dst = (hit && !ovf) ? dst_hit : sink;
+      *reinterpret_cast<uint2*>(lds + dst) = make_uint2((uint32_t)((cref << 4) | ccnt), __builtin_bit_cast(uint32_t, tmn));
+      sa = ovf ? sb : top;
       if (OVF) {
         if (ballot64(ovf) != 0) {
           if (ovf && j == 0) A.ovf_queue[atomicAdd(A.ovf_count, 1)] = ray;
@@ -248,7 +264,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
     }
 
     // ---------------- retire rays whose stack ran dry
-    const bool done = has_ray && !pend_valid && sp == 0;
+    const bool done = has_ray && !pend_valid && sa == sb;
     if (ballot64(done) != 0) {
       if (done) {
         const bool keep_far = far_found && best_key == KEY_MISS;      // shadow ray whose far hit is already stored
@@ -291,7 +307,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         far_found = far_found || far;
         best_t = far ? next_up_pos(shm) : best_t;
         best_key = far ? KEY_MISS : best_key;
-        sp = near ? 0 : sp;                                // near hit: nothing left to learn
+        sa = near ? sb : sa;                               // near hit: nothing left to learn
       }
       const bool mine = accept && valid && (key == (uint32_t)win);
       held_key = mine ? key : held_key; held_u = mine ? uu : held_u; held_v = mine ? vv : held_v;
@@ -769,7 +785,7 @@ void launch_from_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, 
   hipLaunchKernelGGL(k_from_xmajor_f3, dim3(blocks_for(w * h)), dim3(256), 0, st, src, dst, w, h);
 }
 
-size_t trace_coop_lds_bytes(int stack_entries, int width) { return (size_t)4 * (64 / width) * (stack_entries + 1) * sizeof(uint2); }
+size_t trace_coop_lds_bytes(int stack_entries, int width) { return (size_t)4 * (64 / width) * (stack_entries + 3) * sizeof(uint2); }   // + 2 guards + sink
 
 void launch_analytic(hipStream_t st, const DevScene* S, const TraceArgs& A, bool stats) {
   TraceArgs B = A;
