@@ -187,7 +187,6 @@ static void carve(DevPaths& q, int P, int depth) {
 
 static int coop_grid() {
   Ctx& c = g_ctx;
-  if (c.trace_kernel == TRACE_COOP2) return c.num_cus * (c.opt_blocks_per_cu > 0 ? c.opt_blocks_per_cu : trace_coop2_blocks_per_cu());
   if (c.blocks_per_cu <= 0) c.blocks_per_cu = c.opt_blocks_per_cu > 0 ? c.opt_blocks_per_cu : trace_coop_blocks_per_cu(c.stack_entries, c.scene.node_width);
   return c.num_cus * c.blocks_per_cu;
 }
@@ -201,24 +200,16 @@ static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
   a.sh_min = (c.shadow_anyhit && q.sh_min_t && n_rays > q.P) ? q.sh_min_t : nullptr; a.shadow_begin = q.P;
   a.cursor = c.d_cursor; a.stats = c.d_counters + 3; a.live_rays = c.d_counters;
   a.queue = (int*)c.b_queue.p; a.queue_count = c.d_cursor + 1;
-  a.ray_stride = (int64_t)(q.ray_oy - q.ray_ox);
-  a.stack_cap = c.stack_cap > 0 ? std::min(c.stack_cap, trace_coop2_stack_cap()) : trace_coop2_stack_cap();
   a.ovf_queue = (int*)c.b_ovf.p; a.ovf_count = c.d_cursor + 2;
 }
 
 // one trace launch, bracketed by HIP events on the launch stream
 static int trace(const DevPaths& q, int n_rays) {
   Ctx& c = g_ctx;
-  const bool coop = (c.trace_kernel == TRACE_COOP || c.trace_kernel == TRACE_COOP2);
+  const bool coop = (c.trace_kernel == TRACE_COOP);
   if (coop && ensure(c.b_queue, (size_t)n_rays * sizeof(int))) return 1;
-  if (c.trace_kernel == TRACE_COOP2 && c.scene.node_width != 8 && c.scene.n_tris > 0) return fail("trace_kernel 2 needs a BVH of width 8 (option bvh_width)");
-  if ((c.trace_kernel == TRACE_COOP2 || (c.trace_kernel == TRACE_COOP && c.stack_overflow)) && ensure(c.b_ovf, (size_t)n_rays * sizeof(int))) return 1;
+  if (coop && c.stack_overflow && ensure(c.b_ovf, (size_t)n_rays * sizeof(int))) return 1;
   TraceArgs a; fill_trace_args(a, q, n_rays);
-  if (c.trace_kernel == TRACE_COOP2) {
-    const float* arr[11] = {q.ray_ox, q.ray_oy, q.ray_oz, q.ray_dx, q.ray_dy, q.ray_dz, q.ray_tfar, q.hit_t, (const float*)q.hit_key, q.hit_u, q.hit_v};
-    for (int k = 0; k < 11; ++k)
-      if (arr[k] != q.ray_ox + (size_t)k * (size_t)a.ray_stride) return fail("internal: ray arrays are not laid out with a common stride");
-  }
   if (coop) {
     HIP_TRY(hipMemsetAsync(c.d_cursor, 0, kCursorInts * sizeof(int), c.stream));
   }
@@ -403,7 +394,7 @@ int trace_rays(const float* origins, const float* dirs, const float* tfar, int64
   Ctx& c = g_ctx;
   if (!c.scene_ready) return fail("no scene uploaded");
   if (n <= 0 || n > (1ll << 28) || !origins || !dirs || !out) return fail("art_trace_rays: bad arguments");
-  if (kernel != TRACE_COOP && kernel != TRACE_SIMPLE && kernel != TRACE_COOP2) return fail("art_trace_rays: unknown kernel");
+  if (kernel != TRACE_COOP && kernel != TRACE_SIMPLE) return fail("art_trace_rays: unknown kernel");
   const size_t N = (size_t)n;
   if (ensure(c.b_rays, N * 11 * 4)) return 1;
   std::vector<float> soa(7 * N);
@@ -549,9 +540,8 @@ int art_set_option(const char* name, int64_t value) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!name) return fail("null option");
   const std::string n(name);
-  if (n == "trace_kernel") { if (value < TRACE_COOP || value > TRACE_COOP2) return fail("trace_kernel: 0 (cooperative), 1 (simple) or 2 (cooperative, two rays per group)"); g_ctx.trace_kernel = (int)value; }
+  if (n == "trace_kernel") { if (value != TRACE_COOP && value != TRACE_SIMPLE) return fail("trace_kernel: 0 (cooperative) or 1 (simple)"); g_ctx.trace_kernel = (int)value; }
   else if (n == "queue_segments") { if (value != 1 && value != 2 && value != 4 && value != 8) return fail("queue_segments: 1, 2, 4 or 8"); g_ctx.queue_segments = (int)value; }
-  else if (n == "stack_cap") { if (value < 0 || value > 64) return fail("stack_cap: 0 (default) .. 64"); g_ctx.stack_cap = (int)value; }
   else if (n == "batch_paths") { if (value < 1024 || value > (1ll << 29)) return fail("batch_paths: 1024..2^29 (ray indices are 32-bit: 2 rays per path slot)"); g_ctx.batch_paths = value; }
   else if (n == "blocks_per_cu") { g_ctx.opt_blocks_per_cu = (int)value; g_ctx.blocks_per_cu = 0; }
   else if (n == "count_tests") { g_ctx.count_tests = value != 0; }

@@ -42,7 +42,6 @@ struct Ctx {
   bool count_tests = false;
   int node_min = 4;
   int queue_segments = 8;       // the live-ray queue is cut into this many contiguous segments, one per XCD (1 = a single cursor)
-  int stack_cap = 0;            // TRACE_COOP2: LDS stack entries per ray, 0 = the kernel's maximum
   int ray_chunk = 16;
   bool shadow_anyhit = true;   // shadow rays use the visibility rule instead of a full closest-hit search (same decision)
   // timing

@@ -5,7 +5,7 @@
 
 namespace art {
 
-enum { TRACE_COOP = 0, TRACE_SIMPLE = 1, TRACE_COOP2 = 2 };
+enum { TRACE_COOP = 0, TRACE_SIMPLE = 1 };
 
 struct TraceArgs {
   int32_t n_rays;
@@ -27,9 +27,7 @@ struct TraceArgs {
   int* cursor;                  // work cursors, zeroed before every launch: segment k's cursor is cursor[32 * (k + 1)] (cursor[0] serves the
                                 // kernels with a single cursor)
   int* queue; int* queue_count; // live-ray queue filled by k_analytic (indices into the ray arrays), count zeroed before every launch
-  int64_t ray_stride;           // TRACE_COOP2: ray_ox, ray_oy, ..., ray_tfar, hit_t, hit_key, hit_u, hit_v are ray_stride floats apart
-  int32_t stack_cap;            // TRACE_COOP2: LDS stack entries per ray (<= 22); deeper rays go to ovf_queue
-  int* ovf_queue; int* ovf_count;   // TRACE_COOP2: rays handed to k_trace_overflow, count zeroed before every launch
+  int* ovf_queue; int* ovf_count;   // stack_overflow: rays handed to k_trace_overflow, count zeroed before every launch
   unsigned long long* stats;    // [box, tri, node, leaf, rays] when counting
   unsigned long long* live_rays;   // += closest-hit queries actually issued by this launch (Mrays/s numerator)
 };
@@ -47,7 +45,5 @@ size_t trace_coop_lds_bytes(int stack_entries, int width);
 void launch_trace(hipStream_t st, const DevScene* d_scene, const TraceArgs& A, int kernel, bool stats, int grid_blocks);
 void launch_analytic(hipStream_t st, const DevScene* d_scene, const TraceArgs& A, bool stats);
 int  trace_coop_blocks_per_cu(int stack_entries, int width);
-int  trace_coop2_blocks_per_cu();
-int  trace_coop2_stack_cap();
 
 }  // namespace art

@@ -323,254 +323,9 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
 }
 
 // ------------------------------------------------------------------------------------------------
-// cooperative kernel with TWO rays per 8-lane group (TRACE_COOP2)
-//
-// k_trace_coop binds one ray to each group; a wave-uniform step is either a node step or a leaf step, so the groups whose
-// ray waits for the other kind idle (measured: 5.4 of 8 groups take part in a node step, 4.8 in a leaf step).  Here each
-// group owns two rays ("slots").  The per-ray state that k_trace_coop holds in registers lives in a 256-byte LDS record next
-// to the ray's traversal stack; a step loads what it needs from the slot it picked (the one that wants this kind of step), so
-// a group only idles when neither of its rays matches.  To fit 16 rays per wave the LDS stack is capped at kSlotStackCap
-// entries: the worst-case bound of the tree is far above what rays reach (1M-triangle tree: bound 51, deepest of 400k rays
-// 21); a ray that would exceed the cap is handed to k_trace_overflow (one ray per lane, full-size private stack) -- the
-// closest hit is an order-independent minimum, so which kernel finishes a ray cannot change the result.
-//
-// slot record (bytes):   0 inv.xyz, best_t | 16 noi.xyz, best_key | 32 o.xyz, shm | 48 d.xyz, ray | 64 u, v | 72 spare (sink for
-//                        masked stores) | 80 stack: kSlotStackCap x (ref << 4 | count, tmin)
+// overflow path of k_trace_coop
 // ------------------------------------------------------------------------------------------------
-constexpr int kSlotBytes = 256, kSlotStackCap = 22;
-constexpr uint32_t kRecInv = 0, kRecNoi = 16, kRecO = 32, kRecD = 48, kRecUV = 64, kRecSink = 72, kRecStack = 80;
-static_assert(kRecStack + kSlotStackCap * 8 == kSlotBytes, "slot layout");
-
-constexpr uint32_t kPendNone = 0xffffffffu;   // no popped entry: the slot is empty, or its ray's stack ran dry (count field reads 15)
-constexpr uint32_t kRayFarBit = 0x80000000u;  // record word `ray`: the shadow ray's far hit is already stored (art_isect.h shadow_rule)
-
-template <bool STATS>
-__global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop2(const DevScene* __restrict__ Sp, const TraceArgs A) {
-  extern __shared__ uint4 lds_slots[];
-  char* const lds = reinterpret_cast<char*>(lds_slots);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 7, g = lane >> 3;
-  const int gbase = lane & ~7;
-  const uint32_t offA = (uint32_t)((wave * 16 + 2 * g) * kSlotBytes), offB = offA + kSlotBytes;
-  const uint64_t leaders = 0x0101010101010101ull;
-  const char* const nodes_b = reinterpret_cast<const char*>(A.nodes);
-  const char* const tris_b = reinterpret_cast<const char*>(A.tris);
-  const int n_queue = *A.queue_count;
-  const int cap = A.stack_cap;
-  // the 11 ray / hit arrays are one allocation with a common stride (checked by the host): one base pointer instead of 11
-  // keeps the kernel inside its scalar-register budget (the first version spilled SGPRs into VGPR lanes in the step loop)
-  float* const rb = const_cast<float*>(A.ray_ox);
-  const size_t S = (size_t)A.ray_stride;
-  auto rayf = [&](int k, int ray) -> float& { return rb[(size_t)k * S + (size_t)ray]; };
-
-  int chunk_pos = 0, chunk_end = 0;   // wave-uniform
-  bool exhausted = false;             // wave-uniform
-  // group-uniform state of the two slots.  pend = popped stack entry waiting for its step, kPendNone if there is none.
-  // Between steps:  has && pend == kPendNone  <=>  the ray's stack ran dry (it is retired right after the step).
-  bool hasA = false, hasB = false;
-  int spA = 0, spB = 0;
-  uint32_t pendA = kPendNone, pendB = kPendNone;
-  uint64_t st_box = 0, st_tri = 0, st_node = 0, st_leaf = 0, st_it_node = 0, st_it_leaf = 0, st_it_all = 0;
-
-  auto lds4 = [&](uint32_t off) { return *reinterpret_cast<const float4*>(lds + off); };
-
-  auto refill = [&](bool& has, int& sp, uint32_t& pend, uint32_t off) {
-    bool need = !has;
-    while (!exhausted) {
-      const uint64_t need_mask = ballot64(need) & leaders;
-      if (need_mask == 0) break;
-      if (chunk_pos == chunk_end) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(A.cursor, A.chunk);
-        base = __builtin_amdgcn_readfirstlane(base);
-        chunk_pos = base; chunk_end = min(base + A.chunk, n_queue);
-        if (chunk_pos >= n_queue) { exhausted = true; chunk_pos = chunk_end = 0; break; }
-      }
-      const int avail = chunk_end - chunk_pos;
-      const int n_need = __popcll(need_mask);
-      const int my_rank = __popcll(need_mask & ((1ull << gbase) - 1ull));
-      const bool got = need && (my_rank < avail);
-      if (got) {
-        const int ray = A.queue[chunk_pos + my_rank];
-        const f3 o = mk3(rayf(0, ray), rayf(1, ray), rayf(2, ray));
-        const f3 d = mk3(rayf(3, ray), rayf(4, ray), rayf(5, ray));
-        f3 inv, noi;
-        slab_setup(o, d, inv, noi);
-        float best_t = rayf(7, ray); uint32_t best_key = __builtin_bit_cast(uint32_t, rayf(8, ray));      // bound left by k_analytic
-        const float shm = (A.sh_min != nullptr && ray >= A.shadow_begin) ? A.sh_min[ray - A.shadow_begin] : -1.0f;
-        const bool far = (shm >= 0.0f) && (best_key != KEY_MISS);             // a queued shadow ray with a hit has a far hit
-        best_t = far ? next_up_pos(shm) : best_t;
-        best_key = far ? KEY_MISS : best_key;
-        if (j == 0) {
-          *reinterpret_cast<float4*>(lds + off + kRecInv) = make_float4(inv.x, inv.y, inv.z, best_t);
-          *reinterpret_cast<float4*>(lds + off + kRecNoi) = make_float4(noi.x, noi.y, noi.z, __builtin_bit_cast(float, best_key));
-          *reinterpret_cast<float4*>(lds + off + kRecO) = make_float4(o.x, o.y, o.z, shm);
-          *reinterpret_cast<float4*>(lds + off + kRecD) = make_float4(d.x, d.y, d.z, __builtin_bit_cast(float, (uint32_t)ray | (far ? kRayFarBit : 0u)));
-        }
-        sp = 0; pend = 0u;                                          // entry 0 = root node
-        has = true; need = false;
-      }
-      chunk_pos += min(avail, n_need);
-    }
-  };
-
-  // pops entries of the slot at `off` until one survives the bound or the stack is empty; returns the entry or kPendNone
-  auto pop = [&](bool act, uint32_t off, int& sp, float best_t) -> uint32_t {
-    uint32_t pend = kPendNone;
-    for (;;) {
-      const bool need = act && pend == kPendNone;
-      const uint32_t a1 = off + kRecStack + (uint32_t)max(sp - 1, 0) * 8u, a2 = off + kRecStack + (uint32_t)max(sp - 2, 0) * 8u;
-      const uint2 e1 = *reinterpret_cast<const uint2*>(lds + a1), e2 = *reinterpret_cast<const uint2*>(lds + a2);
-      const bool v1 = need && sp > 0;
-      const bool ok1 = v1 && !(__builtin_bit_cast(float, e1.y) > best_t);
-      const bool v2 = v1 && !ok1 && sp > 1;
-      const bool ok2 = v2 && !(__builtin_bit_cast(float, e2.y) > best_t);
-      pend = ok1 ? e1.x : (ok2 ? e2.x : pend);
-      sp -= (v1 ? 1 : 0) + (v2 ? 1 : 0);
-      if (ballot64(act && pend == kPendNone && sp > 0) == 0) break;
-    }
-    return pend;
-  };
-
-  auto retire = [&](bool done, uint32_t off) {
-    if (done) {
-      const float4 r0 = lds4(off + kRecInv), r1 = lds4(off + kRecNoi), r2 = lds4(off + kRecO), r3 = lds4(off + kRecD);
-      const float2 uv = *reinterpret_cast<const float2*>(lds + off + kRecUV);
-      const float best_t = r0.w, shm = r2.w;
-      const uint32_t best_key = __builtin_bit_cast(uint32_t, r1.w);
-      const uint32_t rw = __builtin_bit_cast(uint32_t, r3.w);
-      const int ray = (int)(rw & ~kRayFarBit);
-      const bool keep_far = (rw & kRayFarBit) != 0u && best_key == KEY_MISS;   // shadow ray whose far hit is already stored
-      if (j == 0) {
-        if (!keep_far) { rayf(7, ray) = best_t; rayf(8, ray) = __builtin_bit_cast(float, best_key); }
-        // barycentrics: only a BVH triangle found by this kernel needs storing (the bound left by k_analytic never is one)
-        if (shm < 0.0f && (best_key & ~KEY_INDEX_MASK) == KEY_TRI) { rayf(9, ray) = uv.x; rayf(10, ray) = uv.y; }
-      }
-    }
-  };
-
-  for (;;) {
-    if (STATS) st_it_all += (lane == 0);
-    if (!exhausted && ballot64(!hasA || !hasB) != 0) {
-      refill(hasA, spA, pendA, offA);
-      refill(hasB, spB, pendB, offB);
-      wave_lds_sync();
-    }
-    // kPendNone reads as count 15: neither a node (0) nor a leaf (1..8)
-    const uint32_t cA = pendA & 15u, cB = pendB & 15u;
-    const bool nodeA = cA == 0u, nodeB = cB == 0u;
-    const bool leafA = (cA - 1u) < 8u, leafB = (cB - 1u) < 8u;
-    const bool gn = nodeA || nodeB, gl = leafA || leafB;
-    const uint64_t mn = ballot64(gn), ml = ballot64(gl);
-    if ((mn | ml) == 0) break;          // every slot is empty (finished rays were retired at the end of their step)
-
-    if (__popcll(mn) >= __popcll(ml)) {
-      // ---------------- node step: lane j slab-tests child j of the picked slot's node
-      const bool useB = !nodeA;                                     // meaningful where gn
-      const uint32_t pend = useB ? pendB : pendA;
-      const int sp0 = useB ? spB : spA;
-      const uint32_t off = useB ? offB : offA;
-      const float4 rinv = lds4(off + kRecInv), rnoi = lds4(off + kRecNoi);
-      const float best_t = rinv.w;
-      const uint32_t noff = (gn ? (pend >> 4) : 0u) * (uint32_t)(kNodeFloats * 4) + (uint32_t)j * 16u;
-      const float4 r0 = *reinterpret_cast<const float4*>(nodes_b + noff);
-      const float4 r1 = *reinterpret_cast<const float4*>(nodes_b + noff + 128u);
-      const int cref = __builtin_bit_cast(int, r0.w), ccnt = __builtin_bit_cast(int, r1.w);
-      float tmn, tmx;
-      slab_interval(mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), mk3(rinv.x, rinv.y, rinv.z), mk3(rnoi.x, rnoi.y, rnoi.z), best_t, tmn, tmx);
-      const bool hit = gn && (cref >= 0) && (tmn <= tmx);
-      const int key = hit ? (int)((__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j) : 0x7fffffff;
-      const int rank = group_rank(key);
-      const int nh = __popcll((ballot64(hit) >> gbase) & 0xffull);
-      const bool ovf = gn && (sp0 + nh > cap);                      // rare: the ray moves to k_trace_overflow
-      const uint32_t dst_hit = off + kRecStack + (uint32_t)(sp0 + (nh - 1 - rank)) * 8u, dst_sink = off + kRecSink;
-      const uint32_t dst = (hit && !ovf) ? dst_hit : dst_sink;
-      *reinterpret_cast<uint2*>(lds + dst) = make_uint2((uint32_t)((cref << 4) | ccnt), __builtin_bit_cast(uint32_t, tmn));
-      int sp = ovf ? 0 : sp0 + nh;
-      if (STATS) { st_box += (gn && cref >= 0); st_node += (gn && j == 0); st_it_node += (lane == 0); }
-      wave_lds_sync();
-      const uint32_t npend = pop(gn, off, sp, best_t);
-      if (ballot64(ovf) != 0) {
-        if (ovf && j == 0) A.ovf_queue[atomicAdd(A.ovf_count, 1)] = (int)(__builtin_bit_cast(uint32_t, lds4(off + kRecD).w) & ~kRayFarBit);
-        hasA = hasA && !(ovf && !useB); hasB = hasB && !(ovf && useB);
-      }
-      const bool wa = gn && !useB, wb = gn && useB;
-      spA = wa ? sp : spA; pendA = wa ? npend : pendA;
-      spB = wb ? sp : spB; pendB = wb ? npend : pendB;
-    } else {
-      // ---------------- leaf step: lane j < cnt tests triangle j of the picked slot's leaf
-      const bool useB = !leafA;                                     // meaningful where gl
-      const uint32_t pend = useB ? pendB : pendA;
-      int sp = useB ? spB : spA;
-      const uint32_t off = useB ? offB : offA;
-      const float4 rinv = lds4(off + kRecInv), rnoi = lds4(off + kRecNoi), ro = lds4(off + kRecO), rd = lds4(off + kRecD);
-      float best_t = rinv.w; uint32_t best_key = __builtin_bit_cast(uint32_t, rnoi.w);
-      const float shm = ro.w;
-      const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
-      const int cnt = (int)(pend & 15u), ref = (int)(pend >> 4);
-      const bool tri_lane = gl && (j < cnt);
-      const uint32_t toff = (uint32_t)(tri_lane ? (ref + j) : 0) * (uint32_t)(kTriFloats * 4);
-      const float4 q0 = *reinterpret_cast<const float4*>(tris_b + toff);
-      const float4 q1 = *reinterpret_cast<const float4*>(tris_b + toff + 16u);
-      const float4 q2 = *reinterpret_cast<const float4*>(tris_b + toff + 32u);
-      float tt, uu, vv;
-      const bool pass = tri_raw(o, d, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x), tt, uu, vv);
-      const bool valid = tri_lane && pass && (tt > 0.0f) && (tt < 1000000.0f);
-      const uint32_t tb = valid ? __builtin_bit_cast(uint32_t, tt) : 0x7f7fffffu;
-      const uint32_t key = valid ? (KEY_TRI | (uint32_t)__builtin_bit_cast(int, q2.y)) : KEY_MISS;
-      const uint32_t win_tb = group_min_u32(tb);
-      const uint32_t win_key = group_min_u32(tb == win_tb ? key : 0xffffffffu);
-      const uint64_t win = pack_tk(win_tb, win_key);
-      const uint32_t bt = (best_t == 0.0f) ? 0u : __builtin_bit_cast(uint32_t, best_t);
-      const uint64_t cur = pack_tk(bt, best_key == KEY_MISS ? 0u : best_key);
-      const bool accept = gl && ((uint32_t)win != KEY_MISS) && (win < cur);
-      const float win_t = __builtin_bit_cast(float, (uint32_t)(win >> 32));
-      best_t = accept ? win_t : best_t;
-      best_key = accept ? (uint32_t)win : best_key;
-      const bool sh_hit = accept && (shm >= 0.0f);
-      if (ballot64(sh_hit) != 0) {                         // shadow_rule (art_isect.h), group-uniform
-        const bool near = sh_hit && (win_t <= shm);
-        const bool far = sh_hit && !near;                  // first far hit (afterwards the bound is <= shm)
-        if (far && j == 0) {
-          const uint32_t rw = __builtin_bit_cast(uint32_t, rd.w);
-          const int ray = (int)(rw & ~kRayFarBit);
-          rayf(7, ray) = win_t; rayf(8, ray) = __builtin_bit_cast(float, (uint32_t)win);
-          *reinterpret_cast<uint32_t*>(lds + off + kRecD + 12u) = rw | kRayFarBit;
-        }
-        best_t = far ? next_up_pos(shm) : best_t;
-        best_key = far ? KEY_MISS : best_key;
-        sp = near ? 0 : sp;                                // near hit: nothing left to learn
-      }
-      // write the new bound back (lane 0 of the group) and the winner's barycentrics (the lane that holds them)
-      const bool wr = accept && j == 0;
-      const uint32_t a_t = off + kRecInv + 12u, a_k = off + kRecNoi + 12u, a_uv = off + kRecUV, a_s = off + kRecSink;
-      *reinterpret_cast<float*>(lds + (wr ? a_t : a_s)) = best_t;
-      *reinterpret_cast<uint32_t*>(lds + (wr ? a_k : a_s + 4u)) = best_key;
-      const bool mine = accept && valid && (key == (uint32_t)win);
-      *reinterpret_cast<float2*>(lds + (mine ? a_uv : a_s)) = make_float2(uu, vv);
-      if (STATS) { st_tri += tri_lane; st_leaf += (gl && j == 0); st_it_leaf += (lane == 0); }
-      const uint32_t npend = pop(gl, off, sp, best_t);
-      wave_lds_sync();
-      const bool wa = gl && !useB, wb = gl && useB;
-      spA = wa ? sp : spA; pendA = wa ? npend : pendA;
-      spB = wb ? sp : spB; pendB = wb ? npend : pendB;
-    }
-
-    // ---------------- retire rays whose stack ran dry
-    const bool doneA = hasA && pendA == kPendNone, doneB = hasB && pendB == kPendNone;
-    if (ballot64(doneA || doneB) != 0) {
-      retire(doneA, offA); retire(doneB, offB);
-      hasA = hasA && !doneA; hasB = hasB && !doneB;
-    }
-  }
-  if (STATS) {
-    atomicAdd(&A.stats[0], (unsigned long long)st_box); atomicAdd(&A.stats[1], (unsigned long long)st_tri);
-    atomicAdd(&A.stats[2], (unsigned long long)st_node); atomicAdd(&A.stats[3], (unsigned long long)st_leaf);
-    if (lane == 0) { atomicAdd(&A.stats[5], (unsigned long long)st_it_node); atomicAdd(&A.stats[6], (unsigned long long)st_it_leaf); atomicAdd(&A.stats[7], (unsigned long long)st_it_all); }
-  }
-}
-
-// rays k_trace_coop2 gave up on (LDS stack cap): one ray per lane, full search with the private full-size stack
+// rays k_trace_coop<.., OVF = true> gave up on (capped LDS stack): one ray per lane, full search with the private full-size stack
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_trace_overflow(const DevScene* __restrict__ Sp, const TraceArgs A) {
   const DevScene& S = *Sp;
@@ -801,14 +556,6 @@ void launch_trace(hipStream_t st, const DevScene* S, const TraceArgs& A, int ker
     return;
   }
   if (A.n_tris <= 0) return;                       // no BVH mesh: the analytic pass (launch_analytic) is the whole search
-  if (kernel == TRACE_COOP2) {
-    const size_t lds2 = (size_t)4 * 16 * kSlotBytes;
-    if (stats) hipLaunchKernelGGL(k_trace_coop2<true>, dim3(grid_blocks), dim3(256), lds2, st, S, A);
-    else hipLaunchKernelGGL(k_trace_coop2<false>, dim3(grid_blocks), dim3(256), lds2, st, S, A);
-    if (stats) hipLaunchKernelGGL(k_trace_overflow<true>, dim3(64), dim3(256), 0, st, S, A);
-    else hipLaunchKernelGGL(k_trace_overflow<false>, dim3(64), dim3(256), 0, st, S, A);
-    return;
-  }
   const size_t lds = trace_coop_lds_bytes(A.stack_entries, A.width);
   const int variant = (stats ? 4 : 0) | (A.width == 4 ? 2 : 0) | (A.stack_overflow ? 1 : 0);
   switch (variant) {
@@ -830,12 +577,6 @@ void launch_trace(hipStream_t st, const DevScene* S, const TraceArgs& A, int ker
 }  // namespace art
 
 namespace art {
-int trace_coop2_blocks_per_cu() {
-  int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_coop2<false>, 256, (size_t)4 * 16 * kSlotBytes) != hipSuccess || nb < 1) nb = 1;
-  return nb;
-}
-int trace_coop2_stack_cap() { return kSlotStackCap; }
 int trace_coop_blocks_per_cu(int stack_entries, int width) {
   int nb = 0;
   const size_t lds = trace_coop_lds_bytes(stack_entries, width);
