@@ -1,0 +1,46 @@
+// hydra_scene.hpp -- C++ mirror of the reference's "external_cpp" Scene body, scene_hydra_embree.adb:
+// Init (:303-390) reads <folder>/statex_00001.xml (Hydra legacy scene library), loads every mesh of <geometry_lib> from its
+// VSGF file (Load_Meshes :85-103), reads <materials_lib> (Load_Materials :192-225: diffuse colour only, as in the reference),
+// hands the meshes to the geometry core (Add_Meshes_To_GCore :252-270) and instances them with the 16-float matrices of
+// <scenes>/<scene>/<instance> (Instance_All_Meshes :272-296), then commits.  Find_Closest_Hit (:426-446) is one
+// gcore_closest_hit call.  The geometry core is this repository's libart_hip.so instead of cpp/embree_connect.cpp.
+//
+// The reference parses XML with pugixml through an Ada binding; this mirror carries a ~100-line reader for the subset the
+// scene library uses (elements, quoted attributes, text, comments, declarations).
+#pragma once
+#include <string>
+#include <vector>
+#include "art_host.hpp"
+
+namespace art_host {
+
+struct XmlNode {
+  std::string name, text;
+  std::vector<std::pair<std::string, std::string>> attrs;
+  std::vector<XmlNode> children;
+  const XmlNode* child(const std::string& n) const;             // first child called n, or nullptr  (XML_Node.child)
+  std::string attribute(const std::string& n) const;            // "" when absent                     (XML_Node.attribute(..).value)
+};
+bool ParseXml(const std::string& text, XmlNode& root, std::string& err);     // root = synthetic document node
+
+bool Read_Float3_From_String(const std::string& s, float out[3]);           // scene_hydra_embree.adb:106-133
+bool Read_Float16_From_String(const std::string& s, float out[16]);         // :137-165
+
+struct HydraMaterial { std::string name; float diffuse[3]; };
+struct HydraInstance { int mesh_id; float matrix[16]; };
+
+struct Hydra_Scene {                    // Render_Scene of scene_hydra_embree.adb
+  std::vector<Mesh> meshes;
+  std::vector<HydraMaterial> materials;
+  std::vector<HydraInstance> instances;
+  std::vector<int> geom_ids;            // value returned by gcore_add_mesh_3f per mesh
+  int num_lights = 0;
+
+  bool Load(const std::string& a_path, std::string& err);      // parsing + VSGF loading only (no GPU)
+  bool Init(const std::string& a_path, std::string& err);      // Load + gcore_init_and_clear / add / instance / commit
+  void Destroy();                                              // gcore_destroy (:392-397)
+  // Scene.Find_Closest_Hit (:426-446): tnear 0, tfar 1e5
+  bool Find_Closest_Hit(const float origin[3], const float direction[3], HitCpp& hit) const;
+};
+
+}  // namespace art_host

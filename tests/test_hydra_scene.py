@@ -1,0 +1,84 @@
+"""SURVEY 8(f) rank 4 -- the Hydra scene library import of the reference's "external_cpp" scene body (scene_hydra_embree.adb:303-390),
+mirrored in C++ (host/hydra_scene.cpp) on top of the gcore_* seam of libart_hip.so."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import conv
+import orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SCENE_DIR = os.path.join(HERE, "golden", "hydra_scene")
+F = np.float32
+
+MATS = [np.array([[1, 0, 0, -1.5], [0, 1, 0, 0.25], [0, 0, 1, 2], [0, 0, 0, 1]], F),
+        np.array([[1.7320508, 0, -1, 0.75], [0, 2, 0, 0.1], [1, 0, 1.7320508, 3.1], [0, 0, 0, 1]], F),
+        np.array([[3, 0, 0, 0], [0, -3, 0, 4], [0, 0, 3, 1], [0, 0, 0, 1]], F)]
+
+
+def _host(art):
+    L = C.CDLL(os.path.join(art.PKG_DIR, "libart_host.so"))
+    L.art_host_hydra_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), art.f32p, art.f32p]
+    L.art_host_hydra_init.argtypes = [C.c_char_p]
+    L.art_host_hydra_closest_hits.argtypes = [art.f32p, art.f32p, C.c_int, C.POINTER(art.HitCpp), C.POINTER(C.c_int)]
+    return L
+
+
+def test_scene_library_is_parsed_like_the_reference_reads_it(art):
+    L = _host(art)
+    counts = (C.c_int * 4)(); diffuse = np.zeros(3, F); mats = np.zeros((64, 16), F)
+    assert L.art_host_hydra_load(SCENE_DIR.encode(), counts, diffuse.ctypes.data_as(art.f32p), mats.ctypes.data_as(art.f32p)) == 0
+    assert list(counts) == [1, 2, 3, 1]                       # meshes, materials, instances, lights
+    assert list(diffuse) == [0.5, 0.25, 0.125]                # <color val="..."> (Read_Float3_Val prefers the attribute)
+    for k in range(3):
+        assert np.array_equal(mats[k].reshape(4, 4), MATS[k])
+    assert L.art_host_hydra_load(os.path.join(HERE, "golden").encode(), counts, diffuse.ctypes.data_as(art.f32p), mats.ctypes.data_as(art.f32p)) != 0   # no statex_00001.xml there
+
+
+@pytest.mark.gpu
+def test_instanced_scene_hits_equal_the_oracle_on_the_flattened_mesh(art, backend):
+    """Init -> gcore_add_mesh_3f / gcore_instance_meshes (3x4 row-major from 16 floats) / gcore_commit_scene, then
+    Find_Closest_Hit per ray == the oracle's closest hit on the explicitly transformed, two-sided triangles."""
+    L = _host(art)
+    assert L.art_host_hydra_init(SCENE_DIR.encode()) == 0
+    ident = np.eye(4, dtype=F).ravel(); om = orc.Mesh()
+    assert orc.lib().orc_load_vsgf(orc.PYRAMID_VSGF.encode(), orc.fp(ident), C.byref(om)) == 0      # object-space vertices
+    pos = np.ctypeslib.as_array(om.pos, (om.nverts, 3)).copy(); idx = np.ctypeslib.as_array(om.idx, (om.ntris, 3)).copy()
+    wpos, widx = [], []
+    for k, m in enumerate(MATS):
+        # gcore_commit_scene: ((m0*x + m1*y) + m2*z) + m3 in binary32, per row
+        w = np.stack([((m[r, 0] * pos[:, 0] + m[r, 1] * pos[:, 1]).astype(F) + m[r, 2] * pos[:, 2]).astype(F) + m[r, 3] for r in range(3)], 1).astype(F)
+        base = k * pos.shape[0]
+        for t in idx:
+            widx.append([base + t[0], base + t[1], base + t[2]])       # front winding: prim 2k
+            widx.append([base + t[0], base + t[2], base + t[1]])       # back winding:  prim 2k+1
+        wpos.append(w)
+    wpos = np.concatenate(wpos); widx = np.asarray(widx, np.int32)
+    from ada_ray_tracer_amd import scenes
+    mesh = dict(mode=art.MESH_CLOSEST, pos=wpos, nrm=np.zeros_like(wpos), idx=widx, matid=np.ones(widx.shape[0], np.int32))
+    light = [dict(shape=art.LIGHT_SPHERE, mat=4, center=(0.0, 40.5, 1.0), radius=0.5, intensity=(10.0, 10.0, 10.0), surfaceArea=3.14159)]
+    osc = conv.OracleScene(art.SceneDesc([], light, scenes.cornell_materials(), [mesh], None, scenes.REFERENCE_CAMERA))
+    rng = np.random.default_rng(3)
+    n = 600
+    o = (rng.random((n, 3)) * [6, 5, 6] + [-3, -0.5, 0]).astype(F)
+    centres = np.stack([m[:3, 3] for m in MATS])[rng.integers(0, 3, n)]             # aim near one of the instances
+    tgt = (centres + (rng.random((n, 3)) - 0.5) * [0.9, 0.9, 0.9]).astype(F)
+    d = tgt - o; d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(F)
+    want = orc.closest_hits(osc.scene, o, d)
+    hits = (art.HitCpp * n)(); flags = (C.c_int * n)()
+    L.art_host_hydra_closest_hits(o.ctypes.data_as(art.f32p), d.ctypes.data_as(art.f32p), n, hits, flags)
+    nhit = 0
+    for i in range(n):
+        w = want[i]
+        expect = bool(w.is_hit) and w.t < 100000.0
+        assert bool(flags[i]) == expect, i
+        if not expect:
+            continue
+        nhit += 1
+        k = w.prim_index >> 1
+        assert hits[i].instIndex == k // 8 and hits[i].primIndex == k % 8 and hits[i].geomIndex == 0
+        assert np.float32(hits[i].t).view(np.uint32) == np.float32(w.t).view(np.uint32)
+    assert nhit > 100
+    L.art_host_hydra_destroy()
