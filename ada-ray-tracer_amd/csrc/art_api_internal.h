@@ -25,7 +25,8 @@ struct Ctx {
   DevScene* d_scene = nullptr;                 // the same header in HBM (the trace kernels take it by pointer)
   BvhBuildParams bvh_params;
   DevBuf b_spheres, b_sphere_mat, b_lights, b_materials, b_bf_pos, b_bf_nrm, b_bf_uv, b_bf_idx, b_nodes, b_tris, b_m_nrm, b_m_uv, b_m_idx, b_m_matid;
-  int stack_entries = 8; bool stack_overflow = false; int lds_stack_cap = 0;
+  int bvh_stack_bound = 8;      // worst-case traversal stack of the uploaded tree
+  int lds_stack_cap = 0;        // option: force the LDS stack size (tests of the overflow path)
   // frame
   int width = 0, height = 0, spp = 0;
   int rank = 0, nranks = 1, tile = 32, npix_local = 0;
@@ -41,6 +42,7 @@ struct Ctx {
   int opt_blocks_per_cu = 0, blocks_per_cu = 0;
   bool count_tests = false;
   int node_min = 4;
+  int pool_go = 48, pool_dry = 2;    // TRACE_POOL: drain the pool at this many items; leave the node loop when this many rays ran dry
   int queue_segments = 8;       // the live-ray queue is cut into this many contiguous segments, one per XCD (1 = a single cursor)
   int ray_chunk = 16;
   bool shadow_anyhit = true;   // shadow rays use the visibility rule instead of a full closest-hit search (same decision)
