@@ -28,7 +28,7 @@ LIGHT_RECT, LIGHT_SPHERE = 0, 1
 MESH_REFERENCE_BF, MESH_CLOSEST = 0, 1
 RT_DEBUG, RT_WHITTED, PT_STUPID, PT_SHADOW, PT_MIS = range(5)
 LAYOUT_ADA_XY, LAYOUT_ROW_MAJOR = 0, 1
-TRACE_COOP, TRACE_SIMPLE, TRACE_POOL = 0, 1, 2
+TRACE_COOP, TRACE_SIMPLE = 0, 1
 
 
 class ArtError(RuntimeError):

@@ -182,8 +182,8 @@ static void carve(DevPaths& q, int P, int depth) {
 static void stack_plan(int kernel, int& entries, bool& overflow) {
   Ctx& c = g_ctx;
   const int per_block = 160 * 1024 / 8, groups = 64 / c.scene.node_width;
-  int cap = (kernel == TRACE_POOL) ? (per_block / 4 - trace_pool_extra_bytes_per_wave()) / (16 * 8) - 3
-                                   : per_block / (4 * groups * 8) - 3;     // entries per ray (+ 2 guard entries + the sink of masked pushes)
+  (void)kernel;
+  int cap = per_block / (4 * groups * 8) - 3;     // entries per ray (+ 2 guard entries + the sink of masked pushes)
   if (c.lds_stack_cap > 0) cap = c.lds_stack_cap;
   entries = std::min(c.bvh_stack_bound, cap);
   overflow = c.bvh_stack_bound > entries;
@@ -193,7 +193,6 @@ static int coop_grid() {
   Ctx& c = g_ctx;
   int entries; bool ovf; stack_plan(c.trace_kernel, entries, ovf);
   if (c.opt_blocks_per_cu > 0) return c.num_cus * c.opt_blocks_per_cu;
-  if (c.trace_kernel == TRACE_POOL) return c.num_cus * trace_pool_blocks_per_cu(entries);
   return c.num_cus * trace_coop_blocks_per_cu(entries, c.scene.node_width);
 }
 
@@ -201,7 +200,7 @@ static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
   Ctx& c = g_ctx;
   a.n_rays = n_rays; a.width = c.scene.node_width;
   { int e; bool o; stack_plan(c.trace_kernel, e, o); a.stack_entries = e; a.stack_overflow = o ? 1 : 0; }
-  a.node_min = c.node_min; a.pool_go = c.pool_go; a.pool_dry = c.pool_dry; a.segments = c.queue_segments; a.chunk = c.ray_chunk;
+  a.node_min = c.node_min; a.segments = c.queue_segments; a.chunk = c.ray_chunk;
   a.ray_ox = q.ray_ox; a.ray_oy = q.ray_oy; a.ray_oz = q.ray_oz; a.ray_dx = q.ray_dx; a.ray_dy = q.ray_dy; a.ray_dz = q.ray_dz; a.ray_tfar = q.ray_tfar;
   a.hit_t = q.hit_t; a.hit_key = q.hit_key; a.hit_u = q.hit_u; a.hit_v = q.hit_v;
   a.nodes = c.scene.nodes; a.tris = c.scene.tris; a.n_tris = c.scene.n_tris;
@@ -214,16 +213,9 @@ static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
 // one trace launch, bracketed by HIP events on the launch stream
 static int trace(const DevPaths& q, int n_rays) {
   Ctx& c = g_ctx;
-  const bool coop = (c.trace_kernel == TRACE_COOP || c.trace_kernel == TRACE_POOL);
-  if (c.trace_kernel == TRACE_POOL && c.scene.node_width != 4 && c.scene.n_tris > 0) return fail("trace_kernel 2 (pooled leaves) needs a BVH of width 4");
+  const bool coop = (c.trace_kernel == TRACE_COOP);
   if (coop && ensure(c.b_queue, (size_t)n_rays * sizeof(int))) return 1;
   TraceArgs a; fill_trace_args(a, q, n_rays);
-  a.ray_stride = (int64_t)(q.ray_oy - q.ray_ox);
-  if (c.trace_kernel == TRACE_POOL) {
-    const float* arr[11] = {q.ray_ox, q.ray_oy, q.ray_oz, q.ray_dx, q.ray_dy, q.ray_dz, q.ray_tfar, q.hit_t, (const float*)q.hit_key, q.hit_u, q.hit_v};
-    for (int k = 0; k < 11; ++k)
-      if (arr[k] != q.ray_ox + (size_t)k * (size_t)a.ray_stride) return fail("internal: ray arrays are not laid out with a common stride");
-  }
   if (coop && a.stack_overflow && ensure(c.b_ovf, (size_t)n_rays * sizeof(int))) return 1;
   a.ovf_queue = (int*)c.b_ovf.p;
   if (coop) {
@@ -410,7 +402,7 @@ int trace_rays(const float* origins, const float* dirs, const float* tfar, int64
   Ctx& c = g_ctx;
   if (!c.scene_ready) return fail("no scene uploaded");
   if (n <= 0 || n > (1ll << 28) || !origins || !dirs || !out) return fail("art_trace_rays: bad arguments");
-  if (kernel != TRACE_COOP && kernel != TRACE_SIMPLE && kernel != TRACE_POOL) return fail("art_trace_rays: unknown kernel");
+  if (kernel != TRACE_COOP && kernel != TRACE_SIMPLE) return fail("art_trace_rays: unknown kernel");
   const size_t N = (size_t)n;
   if (ensure(c.b_rays, N * 11 * 4)) return 1;
   std::vector<float> soa(7 * N);
@@ -556,7 +548,7 @@ int art_set_option(const char* name, int64_t value) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!name) return fail("null option");
   const std::string n(name);
-  if (n == "trace_kernel") { if (value < TRACE_COOP || value > TRACE_POOL) return fail("trace_kernel: 0 (cooperative), 1 (simple) or 2 (cooperative with pooled leaves)"); g_ctx.trace_kernel = (int)value; }
+  if (n == "trace_kernel") { if (value != TRACE_COOP && value != TRACE_SIMPLE) return fail("trace_kernel: 0 (cooperative) or 1 (simple)"); g_ctx.trace_kernel = (int)value; }
   else if (n == "queue_segments") { if (value != 1 && value != 2 && value != 4 && value != 8) return fail("queue_segments: 1, 2, 4 or 8"); g_ctx.queue_segments = (int)value; }
   else if (n == "batch_paths") { if (value < 1024 || value > (1ll << 29)) return fail("batch_paths: 1024..2^29 (ray indices are 32-bit: 2 rays per path slot)"); g_ctx.batch_paths = value; }
   else if (n == "blocks_per_cu") { g_ctx.opt_blocks_per_cu = (int)value; g_ctx.blocks_per_cu = 0; }
@@ -565,8 +557,6 @@ int art_set_option(const char* name, int64_t value) {
   else if (n == "ray_chunk") { if (value < 8 || value > 4096) return fail("ray_chunk: 8..4096"); g_ctx.ray_chunk = (int)value; }
   else if (n == "node_min") { if (value < 1 || value > 8) return fail("node_min: 1..8"); g_ctx.node_min = (int)value; }
   else if (n == "bvh_width") { if (value != 4 && value != 8) return fail("bvh_width: 4 or 8"); g_ctx.bvh_params.width = (int)value; }
-  else if (n == "pool_go") { if (value < 1 || value > 64) return fail("pool_go: 1..64"); g_ctx.pool_go = (int)value; }
-  else if (n == "pool_dry") { if (value < 1 || value > 17) return fail("pool_dry: 1..17"); g_ctx.pool_dry = (int)value; }
   else if (n == "lds_stack_cap") { if (value < 0 || value > kStackEntries) return fail("lds_stack_cap: 0 (automatic) .. 160"); g_ctx.lds_stack_cap = (int)value; }
   else if (n == "bvh_max_leaf") { if (value < 1 || value > kMaxLeafTris) return fail("bvh_max_leaf: 1..8"); g_ctx.bvh_params.max_leaf = (int)value; }
   else if (n == "bvh_spatial_splits") { g_ctx.bvh_params.spatial_alpha = value ? 1.0e-5f : -1.0f; }   // host builder: SBVH reference splitting

@@ -5,7 +5,7 @@
 
 namespace art {
 
-enum { TRACE_COOP = 0, TRACE_SIMPLE = 1, TRACE_POOL = 2 };
+enum { TRACE_COOP = 0, TRACE_SIMPLE = 1 };
 
 struct TraceArgs {
   int32_t n_rays;
@@ -14,8 +14,6 @@ struct TraceArgs {
   int32_t stack_overflow;       // the LDS stack is smaller than the tree's bound: pushes are checked, rays that do not fit go to ovf_queue
   int32_t segments;             // k_trace_coop: the queue is cut into this many contiguous segments (1, 2, 4, 8); workgroup b starts
                                 // in segment b % segments (its XCD) and moves on to the next segment when that one is drained
-  int64_t ray_stride;           // TRACE_POOL: ray_ox, ray_oy, ..., ray_tfar, hit_t, hit_key, hit_u, hit_v are ray_stride floats apart
-  int32_t pool_go, pool_dry;    // TRACE_POOL: drain the leaf pool at this many items (<= 64) / when this many rays ran dry
   int32_t node_min;             // a wave keeps expanding nodes while at least this many of its 8 ray groups have one
   const float* ray_ox; const float* ray_oy; const float* ray_oz;
   const float* ray_dx; const float* ray_dy; const float* ray_dz;
@@ -44,9 +42,6 @@ void launch_to_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, in
 void launch_to_xmajor_u32(hipStream_t st, const uint32_t* src, uint32_t* dst, int w, int h);
 void launch_from_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, int h);
 size_t trace_coop_lds_bytes(int stack_entries, int width);
-size_t trace_pool_lds_bytes(int stack_entries);
-int  trace_pool_blocks_per_cu(int stack_entries);
-int  trace_pool_extra_bytes_per_wave();
 void launch_trace(hipStream_t st, const DevScene* d_scene, const TraceArgs& A, int kernel, bool stats, int grid_blocks);
 void launch_analytic(hipStream_t st, const DevScene* d_scene, const TraceArgs& A, bool stats);
 int  trace_coop_blocks_per_cu(int stack_entries, int width);

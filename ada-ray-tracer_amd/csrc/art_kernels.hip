@@ -323,279 +323,6 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
 }
 
 // ------------------------------------------------------------------------------------------------
-// cooperative kernel with a pooled leaf step (TRACE_POOL)
-//
-// In k_trace_coop a group that popped a leaf waits for the wave's next leaf step (3.6 of 16 groups on average), and a leaf step
-// uses 7.7 groups x 1.6 triangles of its 64 lanes although it is 22 % of the issued VALU work.  Here a popped leaf is not tested by
-// its ray's group: its triangles are appended to a per-wave pool in LDS as (ray slot, triangle) items and the ray goes on with its
-// next stack entry.  When 64 items are pooled (or little node work is left) ONE leaf step tests up to 64 triangles of many rays, one
-// per lane: the lane reads its ray's origin / direction from that ray's LDS record, runs the same Moeller-Trumbore arithmetic, and
-// folds (bits(t) << 32 | key) into the ray's 64-bit "best" slot with ds_min_u64; the ray's own group then reads the slot.  The search
-// result is the same minimum over (t, key); only culling happens later (a hit is known a few node steps after its leaf was popped).
-//
-// LDS per wave: 16 stacks (as k_trace_coop) | 16 ray records {o.xyz, -, d.xyz, -} | 16 slots u64 | 16 x (u, v) | 16 pending-item
-// counters | pool of 128 items (slot << 28 | triangle record index).   Width 4 only (16 rays per wave).
-// ------------------------------------------------------------------------------------------------
-constexpr int kPoolItems = 128;
-constexpr int kPoolSlots = 32;                                   // two ray slots per group: the traversing ray and one "zombie"
-constexpr uint32_t kPoolExtraBytes = kPoolSlots * (32 + 8 + 8 + 4) + kPoolItems * 4;     // per wave, after the stacks
-
-template <bool STATS, bool OVF>
-__global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_pool(const DevScene* __restrict__ Sp, const TraceArgs A) {
-  extern __shared__ uint2 lds_stack[];
-  char* const lds = reinterpret_cast<char*>(lds_stack);
-  constexpr int G = 4, NG = 16;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & (G - 1), g = lane / G;
-  const int gbase = lane & ~(G - 1);
-  const uint32_t stack_bytes = (uint32_t)(A.stack_entries + 3) * 8u;
-  const uint32_t wbase = (uint32_t)wave * (NG * stack_bytes + kPoolExtraBytes);
-  const uint32_t sb = wbase + (uint32_t)g * stack_bytes;                 // this group's stack (layout as in k_trace_coop)
-  const uint32_t sink = sb + 16u + (uint32_t)A.stack_entries * 8u;
-  const uint32_t slimit = sb + (uint32_t)A.stack_entries * 8u;
-  // per ray slot s (0..31; group g owns s = g and s = g + 16):
-  const uint32_t rec0 = wbase + NG * stack_bytes;                         // {o.xyz, -, d.xyz, -}, 32 B
-  const uint32_t slot0 = rec0 + kPoolSlots * 32;                          // best (bits(t) << 32 | key), u64
-  const uint32_t uv0 = slot0 + kPoolSlots * 8;                            // barycentrics of the slot's hit
-  const uint32_t cnt0 = uv0 + kPoolSlots * 8;                             // pooled items not yet tested
-  const uint32_t pool0 = cnt0 + kPoolSlots * 4;                           // items: slot << 27 | triangle record index
-  const uint64_t leaders = 0x1111111111111111ull;
-  const char* const nodes_b = reinterpret_cast<const char*>(A.nodes);
-  const char* const tris_b = reinterpret_cast<const char*>(A.tris);
-  const int n_queue = *A.queue_count;
-  // the 11 ray / hit arrays are one allocation with a common stride (checked by the host): one base pointer instead of 11 keeps
-  // the kernel inside its scalar-register budget
-  float* const rb = const_cast<float*>(A.ray_ox);
-  const size_t RS = (size_t)A.ray_stride;
-  auto rayf = [&](int k, int r) -> float& { return rb[(size_t)k * RS + (size_t)r]; };
-
-  int chunk_pos = 0, chunk_end = 0;   // wave-uniform
-  bool exhausted = false;             // wave-uniform
-  const int n_seg = A.segments;
-  int seg = (int)blockIdx.x & (n_seg - 1), segs_left = n_seg;   // wave-uniform
-  int pool_count = 0;                 // wave-uniform: items in the pool
-  // group-uniform from here on.  The traversing ray:
-  bool has_ray = false;
-  bool dead = false;                  // it went to the overflow queue (k_trace_overflow redoes it); only its pooled items still drain
-  uint32_t sid = (uint32_t)g;         // its slot
-  uint32_t sa = sb; int ray = 0;
-  f3 inv = mk3(0, 0, 0), noi = inv;
-  float best_t = 0.0f; uint32_t best_key = KEY_MISS;
-  uint32_t pend = 0; bool pend_valid = false;
-  float shm = -1.0f; bool far_found = false;
-  // The zombie: a ray whose stack ran dry while some of its triangles were still pooled.  Its result so far is already stored; when its
-  // last item is tested the slot's value replaces it if it is better.  Meanwhile the group traverses its next ray in the other slot.
-  bool z_valid = false, z_dead = false; int z_ray = 0; float z_shm = -1.0f; uint64_t z_cur = 0;
-  uint64_t st_box = 0, st_tri = 0, st_node = 0, st_leaf = 0, st_it_node = 0, st_it_leaf = 0, st_it_all = 0;
-
-  auto cur_packed = [&]() {      // the bound as a (t, key) word: an equal t never displaces the initial bound (key 0)
-    const uint32_t bt = (best_t == 0.0f) ? 0u : __builtin_bit_cast(uint32_t, best_t);
-    return pack_tk(bt, best_key == KEY_MISS ? 0u : best_key);
-  };
-
-  for (;;) {
-    if (STATS) st_it_all += (lane == 0);
-    // ---------------- zombies whose last pooled item has been tested
-    if (ballot64(z_valid) != 0) {
-      const uint32_t zs = sid ^ 16u;
-      const int left = *reinterpret_cast<const int*>(lds + cnt0 + zs * 4u);
-      if (z_valid && left == 0) {
-        const uint64_t fin = *reinterpret_cast<const uint64_t*>(lds + slot0 + zs * 8u);
-        if (!z_dead && fin < z_cur && j == 0) {      // closest hit after all: for a shadow ray the same decision as shadow_rule (the minimum is near if any hit is)
-          rayf(7, z_ray) = __builtin_bit_cast(float, (uint32_t)(fin >> 32)); rayf(8, z_ray) = __builtin_bit_cast(float, (uint32_t)fin);
-          if (z_shm < 0.0f) { const float2 uv = *reinterpret_cast<const float2*>(lds + uv0 + zs * 8u); rayf(9, z_ray) = uv.x; rayf(10, z_ray) = uv.y; }
-        }
-        z_valid = false;
-      }
-    }
-    // ---------------- refill idle groups
-    bool need = !has_ray;
-    while (!exhausted) {
-      const uint64_t need_mask = ballot64(need) & leaders;
-      if (need_mask == 0) break;
-      if (chunk_pos == chunk_end) {
-        const int seg_lo = (int)(((int64_t)n_queue * seg) / n_seg), seg_hi = (int)(((int64_t)n_queue * (seg + 1)) / n_seg);
-        int base = 0;
-        if (lane == 0) base = atomicAdd(A.cursor + 32 * (seg + 1), A.chunk);
-        base = __builtin_amdgcn_readfirstlane(base) + seg_lo;
-        chunk_pos = base; chunk_end = min(base + A.chunk, seg_hi);
-        if (chunk_pos >= seg_hi) {
-          chunk_pos = chunk_end = 0;
-          seg = (seg + 1) & (n_seg - 1);
-          if (--segs_left == 0) { exhausted = true; break; }
-          continue;
-        }
-      }
-      const int avail = chunk_end - chunk_pos;
-      const int n_need = __popcll(need_mask);
-      const int my_rank = __popcll(need_mask & ((1ull << gbase) - 1ull));
-      const bool got = need && (my_rank < avail);
-      if (got) {
-        ray = A.queue[chunk_pos + my_rank];
-        const f3 o = mk3(rayf(0, ray), rayf(1, ray), rayf(2, ray));
-        const f3 d = mk3(rayf(3, ray), rayf(4, ray), rayf(5, ray));
-        slab_setup(o, d, inv, noi);
-        best_t = rayf(7, ray); best_key = __builtin_bit_cast(uint32_t, rayf(8, ray));
-        shm = (A.sh_min != nullptr && ray >= A.shadow_begin) ? A.sh_min[ray - A.shadow_begin] : -1.0f;
-        far_found = (shm >= 0.0f) && (best_key != KEY_MISS);
-        best_t = far_found ? next_up_pos(shm) : best_t;
-        best_key = far_found ? KEY_MISS : best_key;
-        if (j == 0) {
-          *reinterpret_cast<float4*>(lds + rec0 + sid * 32u) = make_float4(o.x, o.y, o.z, 0.0f);
-          *reinterpret_cast<float4*>(lds + rec0 + sid * 32u + 16u) = make_float4(d.x, d.y, d.z, 0.0f);
-          *reinterpret_cast<uint64_t*>(lds + slot0 + sid * 8u) = cur_packed();
-          *reinterpret_cast<int*>(lds + cnt0 + sid * 4u) = 0;
-        }
-        sa = sb; pend = 0u; pend_valid = true; dead = false;      // entry 0 = root node
-        has_ray = true; need = false;
-      }
-      chunk_pos += min(avail, n_need);
-    }
-    if (ballot64(has_ray || z_valid) == 0) break;      // pooled items always belong to a traversing ray or a zombie
-
-    // ---------------- inner loop: pop, pool the popped leaves, node step
-    for (;;) {
-      {
-        const bool need = has_ray && !pend_valid;
-        const uint2 e2 = *reinterpret_cast<const uint2*>(lds + sa), e1 = *reinterpret_cast<const uint2*>(lds + sa + 8u);
-        const bool v1 = need && sa > sb;
-        const bool ok1 = v1 && !(__builtin_bit_cast(float, e1.y) > best_t);
-        const bool v2 = v1 && !ok1 && sa > sb + 8u;
-        const bool ok2 = v2 && !(__builtin_bit_cast(float, e2.y) > best_t);
-        pend = ok1 ? e1.x : (ok2 ? e2.x : pend);
-        pend_valid = pend_valid || ok1 || ok2;
-        sa = v2 ? sa - 16u : (v1 ? sa - 8u : sa);
-      }
-      const int cnt = (int)(pend & 15u);
-      const bool is_leaf = has_ray && pend_valid && cnt != 0;
-      if (ballot64(is_leaf) != 0) {
-        // the leaf's triangles become pool items; the ray pops its next entry in the following iteration
-        const bool app = is_leaf && (j < cnt);
-        const uint64_t m = ballot64(app);
-        const int pre = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (app) *reinterpret_cast<uint32_t*>(lds + pool0 + (uint32_t)(pool_count + pre) * 4u) = (sid << 27) | ((pend >> 4) + (uint32_t)j);
-        if (is_leaf && j == 0) atomicAdd(reinterpret_cast<int*>(lds + cnt0 + sid * 4u), cnt);
-        pool_count += (int)__popcll(m);
-        pend_valid = pend_valid && !is_leaf;
-        if (STATS) st_leaf += (is_leaf && j == 0);
-      }
-      const bool want_node = has_ray && pend_valid;
-      const uint64_t node_mask = ballot64(want_node);
-      if (pool_count >= A.pool_go) break;                           // drain (pool_go <= 64: one more iteration could add 64 items to the 128-item pool)
-      // stack ran dry: retire or become a zombie, then refill.  (A dry ray whose group still has a zombie cannot leave before a drain;
-      // it must not end the node loop, or the wave would spin without ever filling the pool.)
-      const uint64_t dry_mask = ballot64(has_ray && !pend_valid && sa == sb && !z_valid) & leaders;
-      if (__popcll(dry_mask) >= A.pool_dry) break;
-      if (__popcll(node_mask) < 8 * A.node_min) {
-        if (node_mask == 0 || pool_count > 0 || dry_mask != 0 || !exhausted) break;
-      }
-      // ---- node step (as in k_trace_coop<., 4, .>)
-      const int ref = (int)(pend >> 4);
-      const uint32_t noff = (uint32_t)(want_node ? ref : 0) * (uint32_t)(G * 32) + (uint32_t)j * 16u;
-      const float4 r0 = *reinterpret_cast<const float4*>(nodes_b + noff);
-      const float4 r1 = *reinterpret_cast<const float4*>(nodes_b + noff + (uint32_t)(G * 16));
-      const int cref = __builtin_bit_cast(int, r0.w), ccnt = __builtin_bit_cast(int, r1.w);
-      float tmn, tmx;
-      slab_interval(mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), inv, noi, best_t, tmn, tmx);
-      const bool hit = want_node && (cref >= 0) && (tmn <= tmx);
-      const int key = hit ? (int)((__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j) : 0x7fffffff;
-      const int rank = group_rank_g<G>(key);
-      const int nh = group_count_g<G>(hit, gbase);
-      const uint32_t top = sa + (uint32_t)nh * 8u;
-      const bool ovf = OVF && want_node && (top > slimit);
-      const uint32_t dst_hit = sa + (uint32_t)(nh - rank) * 8u + 8u;
-      const uint32_t dst = (hit && !ovf) ? dst_hit : sink;
-      *reinterpret_cast<uint2*>(lds + dst) = make_uint2((uint32_t)((cref << 4) | ccnt), __builtin_bit_cast(uint32_t, tmn));
-      sa = ovf ? sb : top;
-      if (OVF) {
-        if (ballot64(ovf) != 0) {
-          if (ovf && j == 0) A.ovf_queue[atomicAdd(A.ovf_count, 1)] = ray;
-          dead = dead || ovf;
-        }
-      }
-      pend_valid = pend_valid && !want_node;
-      if (STATS) { st_box += (want_node && cref >= 0); st_node += (want_node && j == 0); st_it_node += (lane == 0); }
-      wave_lds_sync();
-    }
-
-    // ---------------- pooled leaf step: up to 64 (ray, triangle) items, one per lane.  Runs when the pool is full enough, or when
-    // little else is left to do; an outer iteration that only retires / refills rays leaves a small pool alone.
-    const bool drain = pool_count >= A.pool_go ||
-                       (pool_count > 0 && (__popcll(ballot64(has_ray && pend_valid)) < 8 * A.node_min || ballot64(has_ray && !pend_valid && sa == sb && z_valid) != 0));
-    if (drain) {
-      wave_lds_sync();
-      const int n = min(64, pool_count);
-      const bool act = lane < n;
-      const uint32_t item = *reinterpret_cast<const uint32_t*>(lds + pool0 + (uint32_t)(pool_count - n + (act ? lane : 0)) * 4u);
-      const uint32_t is = item >> 27, itri = item & 0x07ffffffu;
-      const float4 ro = *reinterpret_cast<const float4*>(lds + rec0 + is * 32u), rd = *reinterpret_cast<const float4*>(lds + rec0 + is * 32u + 16u);
-      const uint32_t toff = (act ? itri : 0u) * (uint32_t)(kTriFloats * 4);
-      const float4 q0 = *reinterpret_cast<const float4*>(tris_b + toff);
-      const float4 q1 = *reinterpret_cast<const float4*>(tris_b + toff + 16u);
-      const float4 q2 = *reinterpret_cast<const float4*>(tris_b + toff + 32u);
-      float tt, uu, vv;
-      const bool pass = tri_raw(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x), tt, uu, vv);
-      const bool valid = act && pass && (tt > 0.0f) && (tt < 1000000.0f);
-      const uint64_t packed = valid ? pack_tk(__builtin_bit_cast(uint32_t, tt), KEY_TRI | (uint32_t)__builtin_bit_cast(int, q2.y)) : ~0ull;
-      if (act) {
-        atomicMin(reinterpret_cast<unsigned long long*>(lds + slot0 + is * 8u), (unsigned long long)packed);
-        atomicAdd(reinterpret_cast<int*>(lds + cnt0 + is * 4u), -1);
-      }
-      pool_count -= n;
-      wave_lds_sync();
-      // the lane that holds the slot's value found the slot's current best hit: it publishes the barycentrics
-      const uint64_t fin = *reinterpret_cast<const uint64_t*>(lds + slot0 + is * 8u);
-      if (valid && packed == fin) *reinterpret_cast<float2*>(lds + uv0 + is * 8u) = make_float2(uu, vv);
-      // every group folds the slot of its traversing ray into its registers
-      const uint64_t mine = *reinterpret_cast<const uint64_t*>(lds + slot0 + sid * 8u);
-      const bool accept = has_ray && !dead && (mine < cur_packed());
-      const float win_t = __builtin_bit_cast(float, (uint32_t)(mine >> 32));
-      best_t = accept ? win_t : best_t;
-      best_key = accept ? (uint32_t)mine : best_key;
-      const bool sh_hit = accept && (shm >= 0.0f);
-      if (ballot64(sh_hit) != 0) {                         // shadow_rule (art_isect.h), group-uniform
-        const bool near = sh_hit && (win_t <= shm);
-        const bool far = sh_hit && !near;
-        if (far && j == 0) { rayf(7, ray) = win_t; rayf(8, ray) = __builtin_bit_cast(float, (uint32_t)mine); }
-        far_found = far_found || far;
-        best_t = far ? next_up_pos(shm) : best_t;
-        best_key = far ? KEY_MISS : best_key;
-        sa = near ? sb : sa; pend_valid = pend_valid && !near;       // near hit: nothing left to learn
-        if (far && j == 0) *reinterpret_cast<uint64_t*>(lds + slot0 + sid * 8u) = cur_packed();
-      }
-      if (STATS) { st_tri += act; st_it_leaf += (lane == 0); }
-      wave_lds_sync();
-    }
-
-    // ---------------- rays whose stack ran dry: store the result; if triangles of theirs are still pooled they live on as a zombie
-    const bool dry = has_ray && !pend_valid && sa == sb;
-    if (ballot64(dry) != 0) {
-      const int left = *reinterpret_cast<const int*>(lds + cnt0 + sid * 4u);
-      const bool leave = dry && (left == 0 || !z_valid);            // with a zombie already around, the ray has to wait for its own items
-      if (leave) {
-        if (!dead) {
-          const bool keep_far = far_found && best_key == KEY_MISS;
-          if (j == 0 && !keep_far) { rayf(7, ray) = best_t; rayf(8, ray) = __builtin_bit_cast(float, best_key); }
-          if (j == 0 && shm < 0.0f && (best_key & ~KEY_INDEX_MASK) == KEY_TRI) {
-            const float2 uv = *reinterpret_cast<const float2*>(lds + uv0 + sid * 8u);
-            rayf(9, ray) = uv.x; rayf(10, ray) = uv.y;
-          }
-        }
-        const bool zomb = left != 0;
-        z_valid = z_valid || zomb;
-        if (zomb) { z_ray = ray; z_shm = shm; z_dead = dead; z_cur = cur_packed(); sid ^= 16u; }
-        has_ray = false;
-      }
-    }
-  }
-  if (STATS) {
-    atomicAdd(&A.stats[0], (unsigned long long)st_box); atomicAdd(&A.stats[1], (unsigned long long)st_tri);
-    atomicAdd(&A.stats[2], (unsigned long long)st_node); atomicAdd(&A.stats[3], (unsigned long long)st_leaf);
-    if (lane == 0) { atomicAdd(&A.stats[5], (unsigned long long)st_it_node); atomicAdd(&A.stats[6], (unsigned long long)st_it_leaf); atomicAdd(&A.stats[7], (unsigned long long)st_it_all); }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // overflow path of k_trace_coop
 // ------------------------------------------------------------------------------------------------
 // rays k_trace_coop<.., OVF = true> gave up on (capped LDS stack): one ray per lane, full search with the private full-size stack
@@ -813,7 +540,6 @@ void launch_from_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, 
   hipLaunchKernelGGL(k_from_xmajor_f3, dim3(blocks_for(w * h)), dim3(256), 0, st, src, dst, w, h);
 }
 
-size_t trace_pool_lds_bytes(int stack_entries) { return (size_t)4 * (16 * (size_t)(stack_entries + 3) * 8 + kPoolExtraBytes); }
 size_t trace_coop_lds_bytes(int stack_entries, int width) { return (size_t)4 * (64 / width) * (stack_entries + 3) * sizeof(uint2); }   // + 2 guards + sink
 
 void launch_analytic(hipStream_t st, const DevScene* S, const TraceArgs& A, bool stats) {
@@ -830,19 +556,6 @@ void launch_trace(hipStream_t st, const DevScene* S, const TraceArgs& A, int ker
     return;
   }
   if (A.n_tris <= 0) return;                       // no BVH mesh: the analytic pass (launch_analytic) is the whole search
-  if (kernel == TRACE_POOL) {
-    const size_t ldsp = trace_pool_lds_bytes(A.stack_entries);
-    const int v = (stats ? 2 : 0) | (A.stack_overflow ? 1 : 0);
-    if (v == 0) hipLaunchKernelGGL((k_trace_pool<false, false>), dim3(grid_blocks), dim3(256), ldsp, st, S, A);
-    else if (v == 1) hipLaunchKernelGGL((k_trace_pool<false, true>), dim3(grid_blocks), dim3(256), ldsp, st, S, A);
-    else if (v == 2) hipLaunchKernelGGL((k_trace_pool<true, false>), dim3(grid_blocks), dim3(256), ldsp, st, S, A);
-    else hipLaunchKernelGGL((k_trace_pool<true, true>), dim3(grid_blocks), dim3(256), ldsp, st, S, A);
-    if (A.stack_overflow) {
-      if (stats) hipLaunchKernelGGL(k_trace_overflow<true>, dim3(64), dim3(256), 0, st, S, A);
-      else hipLaunchKernelGGL(k_trace_overflow<false>, dim3(64), dim3(256), 0, st, S, A);
-    }
-    return;
-  }
   const size_t lds = trace_coop_lds_bytes(A.stack_entries, A.width);
   const int variant = (stats ? 4 : 0) | (A.width == 4 ? 2 : 0) | (A.stack_overflow ? 1 : 0);
   switch (variant) {
@@ -864,12 +577,6 @@ void launch_trace(hipStream_t st, const DevScene* S, const TraceArgs& A, int ker
 }  // namespace art
 
 namespace art {
-int trace_pool_blocks_per_cu(int stack_entries) {
-  int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_pool<false, true>, 256, trace_pool_lds_bytes(stack_entries)) != hipSuccess || nb < 1) nb = 1;
-  return nb;
-}
-int trace_pool_extra_bytes_per_wave() { return (int)kPoolExtraBytes; }
 int trace_coop_blocks_per_cu(int stack_entries, int width) {
   int nb = 0;
   const size_t lds = trace_coop_lds_bytes(stack_entries, width);
