@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage: sweep.sh "<opts A>" "<opts B>" ...   each a space-separated list of name=value
+# A/B helper for the GPU box (run through gpurun from the repo root): one bench.py run per argument, each argument a
+# space-separated list of art_set_option name=value pairs.  usage: profiles/sweep.sh "<opts A>" "<opts B>" ...   each a space-separated list of name=value
 i=0
 for o in "$@"; do
   args=""; for kv in $o; do args="$args --opt $kv"; done
