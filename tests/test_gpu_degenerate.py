@@ -1,0 +1,50 @@
+"""Degenerate geometry must not hang or break either builder or the trace kernel: many identical triangles (equal centroids and
+boxes: the SAH falls back to median splits, the LBVH to ties on the sorted position), zero-area triangles, and coordinates spread
+over many orders of magnitude.  Hits are compared with the brute-force oracle as everywhere else."""
+import numpy as np
+import pytest
+
+import conv
+import orc
+from test_gpu_parity import _assert_hits_equal, _random_rays
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def _scene(art, pos, idx):
+    from ada_ray_tracer_amd import scenes
+    pos = np.ascontiguousarray(pos, F).reshape(-1, 3); idx = np.ascontiguousarray(idx, np.int32).reshape(-1, 3)
+    mesh = dict(mode=art.MESH_CLOSEST, pos=pos, nrm=np.tile(np.array([0, 1, 0], F), (pos.shape[0], 1)), idx=idx,
+                matid=np.ones(idx.shape[0], np.int32))
+    light = [dict(shape=art.LIGHT_SPHERE, mat=4, center=(0.0, 40.5, 1.0), radius=0.5, intensity=(10.0, 10.0, 10.0), surfaceArea=3.14159)]
+    return art.SceneDesc([], light, scenes.cornell_materials(), [mesh], None, scenes.REFERENCE_CAMERA)
+
+
+@pytest.mark.parametrize("builder", [0, 1])
+@pytest.mark.parametrize("width", [4, 8])
+def test_degenerate_meshes(art, backend, builder, width):
+    rng = np.random.default_rng(5)
+    tri = np.array([[-1, 1, 2], [1, 1, 2], [0, 3, 2.5]], F)
+    cases = {
+        "identical": np.tile(tri, (20000, 1, 1)),                                                   # 20 000 copies of one triangle
+        "zero_area": np.concatenate([np.tile(tri, (50, 1, 1)), np.tile(tri[:1], (3000, 3, 1))]),    # + 3000 triangles collapsed to a point
+        "wide_range": (rng.normal(size=(6000, 1, 3)) * 10.0 ** rng.integers(-3, 3, (6000, 1, 1)) + rng.normal(size=(6000, 3, 3)) * 0.05 + [0, 2, 2]).astype(F),
+    }
+    try:
+        backend.set_option("bvh_builder", builder)
+        backend.set_option("bvh_width", width)
+        for name, tris in cases.items():
+            n = tris.shape[0]
+            sd = _scene(art, tris.reshape(-1, 3), np.arange(3 * n).reshape(-1, 3))
+            osc = conv.OracleScene(sd)
+            backend.upload_scene(sd)
+            o, d = _random_rays(4000, 11)
+            want = orc.closest_hits(osc.scene, o, d)
+            _assert_hits_equal(backend.trace_rays(o, d), want)
+            if name == "identical":
+                hit = [h for h in want if h.is_hit]
+                assert len(hit) > 50 and all(h.prim_index == 0 for h in hit)       # ties on t: the lowest triangle index wins
+    finally:
+        backend.set_option("bvh_builder", 0)
+        backend.set_option("bvh_width", 4)
