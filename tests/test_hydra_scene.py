@@ -82,3 +82,18 @@ def test_instanced_scene_hits_equal_the_oracle_on_the_flattened_mesh(art, backen
         assert np.float32(hits[i].t).view(np.uint32) == np.float32(w.t).view(np.uint32)
     assert nhit > 100
     L.art_host_hydra_destroy()
+
+
+@pytest.mark.parametrize("text,why", [
+    ("<geometry_lib><mesh loc='x.vsgf'></geometry_lib>", "mismatched closing tag"),
+    ("<a b=c/>", "unquoted attribute"),
+    ("<a><!-- never closed", "unterminated comment"),
+    ("<materials_lib/><lights_lib/><geometry_lib/><scenes/>", "no meshes"),
+    ("<materials_lib><material name='m'/></materials_lib><lights_lib/><geometry_lib><mesh loc='missing.vsgf'/></geometry_lib><scenes><scene/></scenes>", "missing vsgf"),
+    ("", "empty file"),
+])
+def test_malformed_scene_libraries_are_refused_not_crashed(art, tmp_path, text, why):
+    L = _host(art)
+    (tmp_path / "statex_00001.xml").write_text(text)
+    counts = (C.c_int * 4)(); diffuse = np.zeros(3, F); mats = np.zeros((64, 16), F)
+    assert L.art_host_hydra_load(str(tmp_path).encode(), counts, diffuse.ctypes.data_as(art.f32p), mats.ctypes.data_as(art.f32p)) != 0, why
