@@ -15,8 +15,13 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def art():
+    """The package.  On a fresh checkout the native libraries are compiled first (hipcc cross-compiles without a GPU); the product
+    itself never builds or falls back on its own -- a missing libart_hip.so is an error there."""
     import __graft_entry__ as ge
-    return ge.load_package()
+    pkg = ge.load_package()
+    if not os.path.exists(pkg.LIB_PATH) or not os.path.exists(os.path.join(pkg.PKG_DIR, "libart_host.so")):
+        ge.build()
+    return pkg
 
 
 @pytest.fixture(scope="session")
