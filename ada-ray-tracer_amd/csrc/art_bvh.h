@@ -24,7 +24,10 @@ struct BvhBuildParams {
   float spatial_alpha = -1.0f;   // try a spatial split where overlap area of the object split > alpha * root area; < 0: off
   float spatial_budget = 0.5f;   // extra references allowed, as a fraction of the triangle count
   int   spatial_bins = 16;
-  int   builder = 0;             // 0: binned SAH on the host (art_bvh.cpp); 1: LBVH on the GPU (art_lbvh.hip), needs >= 2 triangles
+  int   builder = 0;             // 0: binned SAH on the host (art_bvh.cpp); on the GPU (art_lbvh.hip, >= 2 triangles): 1 LBVH, 2 PLOC
+  int   ploc_radius = 8;         // PLOC: neighbours searched on either side
+  int   gpu_max_leaf = 0;        // GPU builders: a subtree of at most this many triangles becomes one leaf; 0 = measured optimum
+                                 // (1 for width 4, 2 for width 8: their trees have no SAH leaf term, small leaves cull better)
   float leaf_cost(int n) const { return leaf_base + (tri_cost >= 0.0f ? tri_cost : (width == 4 ? 0.2f : 0.05f)) * (float)n; }
 };
 

@@ -153,6 +153,105 @@ __global__ __launch_bounds__(256) void k_emit_tris(const float* __restrict__ tri
   o[9] = __int_as_float((int)t); o[10] = 0.0f; o[11] = 0.0f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// PLOC (parallel locally-ordered clustering, Meister & Bittner 2018) as an alternative to the radix tree: the Morton-sorted
+// clusters are merged bottom-up; in every round each cluster picks, among its `radius` neighbours on either side, the one whose
+// union with it has the smallest surface area, and mutual choices merge.  Quality is close to a SAH build at LBVH-like cost.
+// One round = nearest-neighbour kernel, keep flags, one exclusive scan (compaction AND node numbering), merge + scatter kernel.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float union_area(float4 alo, float4 ahi, float4 blo, float4 bhi) {
+  const float dx = fmaxf(ahi.x, bhi.x) - fminf(alo.x, blo.x), dy = fmaxf(ahi.y, bhi.y) - fminf(alo.y, blo.y), dz = fmaxf(ahi.z, bhi.z) - fminf(alo.z, blo.z);
+  return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ __launch_bounds__(256) void k_ploc_init(int n, const float4* __restrict__ llo, const float4* __restrict__ lhi, int* cid, float4* clo, float4* chi) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { cid[i] = ~i; clo[i] = llo[i]; chi[i] = lhi[i]; }
+}
+
+__global__ __launch_bounds__(256) void k_ploc_nn(int m, int radius, const float4* __restrict__ clo, const float4* __restrict__ chi, int* __restrict__ nn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const float4 lo = clo[i], hi = chi[i];
+  // ties go to the partner i ^ 1 (then to the lower index): equal boxes then pair up (0,1), (2,3), ... and every round halves
+  // them, instead of all pointing at the lowest index of their window (one merge per round)
+  int best = (i ^ 1) < m ? (i ^ 1) : i - 1;
+  float best_a = union_area(lo, hi, clo[best], chi[best]);
+  const int j0 = max(0, i - radius), j1 = min(m - 1, i + radius);
+  for (int j = j0; j <= j1; ++j) {
+    if (j == i) continue;
+    const float a = union_area(lo, hi, clo[j], chi[j]);
+    if (a < best_a) { best_a = a; best = j; }
+  }
+  nn[i] = best;
+}
+
+// keep[i] = 0 for the higher-indexed partner of a mutual pair (it creates the merged node and puts it into its partner's place)
+__global__ __launch_bounds__(256) void k_ploc_keep(int m, const int* __restrict__ nn, int* __restrict__ keep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const int j = nn[i];
+  keep[i] = (j >= 0 && nn[j] == i && i > j) ? 0 : 1;
+}
+
+struct PlocOut { int2* child; int* parent; int* count; float4* nlo; float4* nhi; int n; };
+
+__global__ __launch_bounds__(256) void k_ploc_merge(int m, int base, const int* __restrict__ nn, const int* __restrict__ keep, const int* __restrict__ pos,
+                                                    const int* __restrict__ cid, const float4* __restrict__ clo, const float4* __restrict__ chi,
+                                                    int* __restrict__ cid2, float4* __restrict__ clo2, float4* __restrict__ chi2, PlocOut O) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const int j = nn[i];
+  const bool mutual = j >= 0 && nn[j] == i;
+  if (mutual && i < j) return;                            // the partner writes the merged cluster into this slot's new position
+  if (!mutual) { const int p = pos[i]; cid2[p] = cid[i]; clo2[p] = clo[i]; chi2[p] = chi[i]; return; }
+  // i > j: new internal node; every dropped slot before i belongs to exactly one earlier merge, so the merges are numbered by i - pos[i]
+  const int id = base + (i - pos[i]);
+  const int a = cid[j], b = cid[i];                       // left = the lower slot
+  const float4 alo = clo[j], ahi = chi[j], blo = clo[i], bhi = chi[i];
+  const float4 lo = make_float4(fminf(alo.x, blo.x), fminf(alo.y, blo.y), fminf(alo.z, blo.z), 0.f);
+  const float4 hi = make_float4(fmaxf(ahi.x, bhi.x), fmaxf(ahi.y, bhi.y), fmaxf(ahi.z, bhi.z), 0.f);
+  O.child[id] = make_int2(a, b);
+  O.nlo[id] = lo; O.nhi[id] = hi;
+  O.count[id] = (a >= 0 ? O.count[a] : 1) + (b >= 0 ? O.count[b] : 1);
+  if (a >= 0) O.parent[a] = id; else O.parent[O.n - 1 + ~a] = id;
+  if (b >= 0) O.parent[b] = id; else O.parent[O.n - 1 + ~b] = id;
+  const int p = pos[j];
+  cid2[p] = id; clo2[p] = lo; chi2[p] = hi;
+}
+
+// depth-first numbering of the leaves: a node's leaves are contiguous, so a subtree of <= width triangles can become one leaf.
+// start(x) = sum over the ancestors of x reached from their right child of count(left sibling).
+__device__ __forceinline__ int ploc_start(const PlocOut& O, int x /* node id, or ~leaf */) {
+  int start = 0;
+  int p = x >= 0 ? O.parent[x] : O.parent[O.n - 1 + ~x];
+  while (p >= 0) {
+    const int2 c = O.child[p];
+    if (c.y == x) start += (c.x >= 0 ? O.count[c.x] : 1);
+    x = p; p = O.parent[p];
+  }
+  return start;
+}
+
+__global__ __launch_bounds__(256) void k_ploc_number_leaves(PlocOut O, const uint32_t* __restrict__ order_in, const float4* __restrict__ llo, const float4* __restrict__ lhi,
+                                                            int* __restrict__ leaf_pos, uint32_t* __restrict__ order_out, float4* __restrict__ llo2, float4* __restrict__ lhi2) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= O.n) return;
+  const int p = ploc_start(O, ~k);
+  leaf_pos[k] = p; order_out[p] = order_in[k]; llo2[p] = llo[k]; lhi2[p] = lhi[k];
+}
+
+__global__ __launch_bounds__(256) void k_ploc_number_nodes(PlocOut O, const int* __restrict__ leaf_pos, int2* __restrict__ range) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= O.n - 1) return;
+  const int s = ploc_start(O, id);
+  range[id] = make_int2(s, s + O.count[id] - 1);
+  int2 c = O.child[id];
+  if (c.x < 0) c.x = ~leaf_pos[~c.x];
+  if (c.y < 0) c.y = ~leaf_pos[~c.y];
+  O.child[id] = c;                                        // ploc_start of OTHER threads compares child ids: leaves are renamed in a second pass
+}
+
 struct Item { int n2, n8, stack_before; };
 
 __device__ __forceinline__ float next_dn(float v) { return (v == 0.0f) ? -1.401298464e-45f : __int_as_float(__float_as_int(v) + (v > 0.0f ? -1 : 1)); }
@@ -228,7 +327,7 @@ struct Scratch {
 bool build_bvh8_gpu(const float* d_tri9, int n, const BvhBuildParams& prm, hipStream_t st, GpuBvh& out, std::string& err) {
   if (n < 2) { err = "build_bvh8_gpu needs at least 2 triangles"; return false; }
   if (prm.width != 4 && prm.width != 8) { err = "BVH width must be 4 or 8"; return false; }
-  const int max_leaf = std::min(prm.max_leaf, prm.width);
+  const int max_leaf = std::min(prm.gpu_max_leaf > 0 ? prm.gpu_max_leaf : (prm.width == 4 ? 1 : 2), prm.width);
   Scratch S;
   float4 *blo, *bhi, *llo, *lhi, *nlo, *nhi; uint32_t *keys, *keys2, *vals, *vals2; int *scene, *parent, *flag, *counters; int2 *child, *range; Item *qa, *qb;
   if (!S.get(&blo, n, err) || !S.get(&bhi, n, err) || !S.get(&llo, n, err) || !S.get(&lhi, n, err) || !S.get(&nlo, n, err) || !S.get(&nhi, n, err) ||
@@ -252,18 +351,60 @@ bool build_bvh8_gpu(const float* d_tri9, int n, const BvhBuildParams& prm, hipSt
   LB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, n, 0, 30, st));
   hipLaunchKernelGGL(k_gather_boxes, dim3(nb), dim3(256), 0, st, blo, bhi, vals2, n, llo, lhi);
   Lbvh T; T.n = n; T.keys = keys2; T.child = child; T.parent = parent; T.range = range; T.nlo = nlo; T.nhi = nhi; T.llo = llo; T.lhi = lhi; T.flag = flag;
-  hipLaunchKernelGGL(k_karras, dim3(nb), dim3(256), 0, st, T);
-  hipLaunchKernelGGL(k_fit, dim3(nb), dim3(256), 0, st, T);
-  // triangle records in Morton order
+  const uint32_t* tri_order = vals2;          // triangle of every leaf position
+  int root_id = 0;
+  if (prm.builder == 2) {
+    // ---- PLOC: merge the Morton-ordered clusters bottom-up
+    int *cid, *cid2, *nn, *keep, *pos, *count, *leaf_pos; float4 *clo, *chi, *clo2, *chi2, *llo2, *lhi2; uint32_t* order2;
+    if (!S.get(&cid, n, err) || !S.get(&cid2, n, err) || !S.get(&nn, n, err) || !S.get(&keep, n, err) || !S.get(&pos, n, err) || !S.get(&count, n, err) ||
+        !S.get(&leaf_pos, n, err) || !S.get(&clo, n, err) || !S.get(&chi, n, err) || !S.get(&clo2, n, err) || !S.get(&chi2, n, err) ||
+        !S.get(&llo2, n, err) || !S.get(&lhi2, n, err) || !S.get(&order2, n, err))
+      return false;
+    size_t scan_bytes = 0;
+    LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, keep, pos, n, st));
+    void* scan_tmp = nullptr;
+    if (!S.get((char**)&scan_tmp, scan_bytes, err)) return false;
+    LB_TRY(hipMemsetAsync(parent, 0xff, 2 * (size_t)n * sizeof(int), st));          // -1: no parent (the root keeps it)
+    PlocOut O; O.child = child; O.parent = parent; O.count = count; O.nlo = nlo; O.nhi = nhi; O.n = n;
+    hipLaunchKernelGGL(k_ploc_init, dim3(nb), dim3(256), 0, st, n, llo, lhi, cid, clo, chi);
+    const int radius = std::max(1, prm.ploc_radius);
+    int m = n, base = 0, rounds = 0;
+    while (m > 1) {
+      const int mb = (m + 255) / 256;
+      hipLaunchKernelGGL(k_ploc_nn, dim3(mb), dim3(256), 0, st, m, radius, clo, chi, nn);
+      hipLaunchKernelGGL(k_ploc_keep, dim3(mb), dim3(256), 0, st, m, nn, keep);
+      LB_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, keep, pos, m, st));
+      int last[2];
+      LB_TRY(hipMemcpyAsync(&last[0], pos + (m - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+      LB_TRY(hipMemcpyAsync(&last[1], keep + (m - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+      LB_TRY(hipStreamSynchronize(st));
+      const int m_new = last[0] + last[1];
+      if (m_new >= m || m_new < 1) { err = "internal: PLOC round made no progress"; return false; }   // the closest pair is always mutual
+      hipLaunchKernelGGL(k_ploc_merge, dim3(mb), dim3(256), 0, st, m, base, nn, keep, pos, cid, clo, chi, cid2, clo2, chi2, O);
+      base += m - m_new; m = m_new;
+      std::swap(cid, cid2); std::swap(clo, clo2); std::swap(chi, chi2);
+      if (++rounds > 4096) { err = "internal: PLOC did not terminate"; return false; }
+    }
+    if (base != n - 1) { err = "internal: PLOC node count"; return false; }
+    root_id = n - 2;                                                                 // the last merge
+    hipLaunchKernelGGL(k_ploc_number_leaves, dim3(nb), dim3(256), 0, st, O, vals2, llo, lhi, leaf_pos, order2, llo2, lhi2);
+    hipLaunchKernelGGL(k_ploc_number_nodes, dim3(nb), dim3(256), 0, st, O, leaf_pos, range);
+    T.llo = llo2; T.lhi = lhi2; tri_order = order2;
+    out.levels = rounds;
+  } else {
+    hipLaunchKernelGGL(k_karras, dim3(nb), dim3(256), 0, st, T);
+    hipLaunchKernelGGL(k_fit, dim3(nb), dim3(256), 0, st, T);
+  }
+  // triangle records in leaf order
   const size_t tri_bytes = (size_t)n * kTriFloats * sizeof(float);
   LB_TRY(hipMalloc(&out.tris, tri_bytes));
-  hipLaunchKernelGGL(k_emit_tris, dim3(nb), dim3(256), 0, st, d_tri9, vals2, n, out.tris);
+  hipLaunchKernelGGL(k_emit_tris, dim3(nb), dim3(256), 0, st, d_tri9, tri_order, n, out.tris);
   // collapse, one launch per level of the wide tree; at most n/2+1 nodes can appear (every inner node has >= 2 children)
   const size_t node_cap = (size_t)n / 2 + 2;
   LB_TRY(hipMalloc(&out.nodes, node_cap * (size_t)node_floats(prm.width) * sizeof(float)));
   const int h_cnt[4] = {0, 1, 1, 0};    // [0] next-queue length, [1] node count (root = 0 taken), [2] max stack
   LB_TRY(hipMemcpyAsync(counters, h_cnt, sizeof h_cnt, hipMemcpyHostToDevice, st));
-  const Item root = {0, 0, 0};
+  const Item root = {root_id, 0, 0};
   LB_TRY(hipMemcpyAsync(qa, &root, sizeof root, hipMemcpyHostToDevice, st));
   int n_in = 1, levels = 0;
   Item *in = qa, *nx = qb;
@@ -285,7 +426,7 @@ bool build_bvh8_gpu(const float* d_tri9, int n, const BvhBuildParams& prm, hipSt
   LB_TRY(hipEventElapsedTime(&ms, e0, e1));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   LB_TRY(hipGetLastError());
-  out.n_tris = n; out.build_ms = ms; out.levels = levels;
+  out.n_tris = n; out.build_ms = ms; if (prm.builder != 2) out.levels = levels;
   return true;
 }
 

@@ -21,7 +21,7 @@ def _scene(art, pos, idx):
     return art.SceneDesc([], light, scenes.cornell_materials(), [mesh], None, scenes.REFERENCE_CAMERA)
 
 
-@pytest.mark.parametrize("builder", [0, 1])
+@pytest.mark.parametrize("builder", [0, 1, 2])
 @pytest.mark.parametrize("width", [4, 8])
 def test_degenerate_meshes(art, backend, builder, width):
     rng = np.random.default_rng(5)

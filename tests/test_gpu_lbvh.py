@@ -13,11 +13,11 @@ from test_gpu_parity import _assert_hits_equal, _random_rays, bits
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[4, 8])
+@pytest.fixture(params=[(1, 4), (1, 8), (2, 4), (2, 8)], ids=["lbvh-w4", "lbvh-w8", "ploc-w4", "ploc-w8"])
 def gpu_builder(backend, request):
-    """GPU builder for both node widths (4 = default kernel layout, 8 = the 8-lanes-per-ray layout)"""
-    backend.set_option("bvh_builder", 1)
-    backend.set_option("bvh_width", request.param)
+    """Both GPU builders (1 = LBVH radix tree, 2 = PLOC clustering) for both node widths"""
+    backend.set_option("bvh_builder", request.param[0])
+    backend.set_option("bvh_width", request.param[1])
     yield backend
     backend.set_option("bvh_builder", 0)
     backend.set_option("bvh_width", 4)
@@ -137,7 +137,7 @@ def test_image_does_not_depend_on_the_builder(art, backend, config):
     p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=21)
     out = []
     try:
-        for builder in (0, 1):
+        for builder in (0, 1, 2):
             backend.set_option("bvh_builder", builder)
             backend.upload_scene(sd)
             backend.resize(160, 90)
@@ -145,7 +145,8 @@ def test_image_does_not_depend_on_the_builder(art, backend, config):
             out.append((accum.copy(), screen.copy(), backend.stats().rays))
     finally:
         backend.set_option("bvh_builder", 0)
-    assert np.array_equal(bits(out[0][0]), bits(out[1][0])) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+    for k in (1, 2):
+        assert np.array_equal(bits(out[0][0]), bits(out[k][0])) and np.array_equal(out[0][1], out[k][1]) and out[0][2] == out[k][2]
 
 
 def test_spatial_split_builder_same_image(art, backend):
