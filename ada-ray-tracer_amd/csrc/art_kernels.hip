@@ -23,8 +23,6 @@ namespace art {
 // ------------------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }   // old = 0 + bound_ctrl: no tie to v, so no copy and the move can fold into its user (v_min_u32_dpp)
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
 
 constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
@@ -33,7 +31,6 @@ constexpr int DPP_HALF_MIRROR = 0x141;  // lane i <- lane 7-i  (= xor 7 inside a
 
 // value of lane (j ^ 4) of the same group: half mirror (xor 7) followed by quad reverse (xor 3)
 __device__ __forceinline__ int xor4_i(int v) { return dpp_i<DPP_XOR3>(dpp_i<DPP_HALF_MIRROR>(v)); }
-__device__ __forceinline__ float xor4_f(float v) { return dpp_f<DPP_XOR3>(dpp_f<DPP_HALF_MIRROR>(v)); }
 
 // number of lanes in my 8-lane group whose key is smaller than mine (keys are < 2^31).  (A hand-scheduled
 // v_sub_co_u32_dpp / v_addc chain has fewer instructions but measured 4 % slower: its carry chain serialises.)
@@ -56,22 +53,6 @@ __device__ __forceinline__ int group_rank(int key) {
   r += (dpp_i<DPP_XOR2>(m) < key);
   r += (dpp_i<DPP_XOR3>(m) < key);
   return r;
-}
-
-// lexicographic (t, key) minimum across the group; every lane ends with the winner (float compares: handles -0.0)
-__device__ __forceinline__ void group_min_tk(float& t, uint32_t& key) {
-  {
-    const float ot = dpp_f<DPP_XOR1>(t); const uint32_t ok = (uint32_t)dpp_i<DPP_XOR1>((int)key);
-    if (ot < t || (ot == t && ok < key)) { t = ot; key = ok; }
-  }
-  {
-    const float ot = dpp_f<DPP_XOR2>(t); const uint32_t ok = (uint32_t)dpp_i<DPP_XOR2>((int)key);
-    if (ot < t || (ot == t && ok < key)) { t = ot; key = ok; }
-  }
-  {
-    const float ot = xor4_f(t); const uint32_t ok = (uint32_t)xor4_i((int)key);
-    if (ot < t || (ot == t && ok < key)) { t = ot; key = ok; }
-  }
 }
 
 __device__ __forceinline__ uint64_t pack_tk(uint32_t tbits, uint32_t key) { return ((uint64_t)tbits << 32) | key; }
@@ -117,9 +98,6 @@ __device__ __forceinline__ void wave_lds_sync() {
 // ------------------------------------------------------------------------------------------------
 #ifndef ART_COOP_WAVES_PER_SIMD
 #define ART_COOP_WAVES_PER_SIMD 8   // <= 64 VGPRs: 8 waves per SIMD = 256 rays in flight per CU
-#endif
-#ifndef ART_COOP_LEAF_MIN
-#define ART_COOP_LEAF_MIN 3          // a wave runs its leaf phase once this many of its 8 ray groups wait on a leaf
 #endif
 
 // G = lanes per ray = children per node = triangles per leaf (8 or 4); 64 / G rays per wave.  OVF: the LDS stack holds fewer entries
