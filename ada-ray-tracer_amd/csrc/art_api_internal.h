@@ -38,7 +38,8 @@ struct Ctx {
   uint64_t camera_rays = 0;
   // options
   int trace_kernel = TRACE_COOP;
-  int64_t batch_paths = 32ll << 20;   // path slots per batch (328 B each at depth 8 -> 11 GB of the 288 GB HBM): big batches keep late bounces wide
+  int64_t batch_paths = 128ll << 20;  // path slots per batch (328 B each at depth 8 -> up to 44 GB of the 288 GB HBM; buffers are sized to the frame,
+                                      // so a small render takes less): big batches keep late bounces wide (8M -> 32M: +7 %, -> 128M: +1.7 %)
   int opt_blocks_per_cu = 0, blocks_per_cu = 0;
   bool count_tests = false;
   int node_min = 4;

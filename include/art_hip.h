@@ -155,7 +155,7 @@ int  art_trace_rays(const float* origins, const float* dirs, const float* tfar, 
 
 int  art_export_bvh(float* nodes, int64_t node_floats_cap, float* tris, int64_t tri_floats_cap, ArtBvhInfo* info);
 int  art_get_stats(ArtStats* out);
-/* Tuning / test options (defaults in brackets):  "trace_kernel" [0] 0 cooperative, 1 one ray per lane;  "batch_paths" [32M];
+/* Tuning / test options (defaults in brackets):  "trace_kernel" [0] 0 cooperative, 1 one ray per lane;  "batch_paths" [128M];
  * "blocks_per_cu" [occupancy];  "count_tests" [0];  "node_min" [4];  "ray_chunk" [16];  "queue_segments" [8];  "shadow_anyhit" [1];
  * "lds_stack_cap" [0 = automatic];  BVH build (take effect at the next art_upload_scene): "bvh_width" [4] lanes per ray = children
  * per node, 4 or 8;  "bvh_builder" [0] 0 binned SAH on the host, 1 LBVH on the GPU, 2 PLOC on the GPU;  "bvh_ploc_radius" [8];  "bvh_spatial_splits" [0];  "bvh_max_leaf" [width];
