@@ -237,8 +237,8 @@ def test_mixed_scene_bit_exact(art, backend):
     assert_radiance_equal(accum, ref, spp)
 
 
-@pytest.mark.parametrize("config", ["c3", "c4", "c5"])
-def test_baseline_scenes_at_full_triangle_count(art, backend, config):
+@pytest.mark.parametrize("config,rt", [("c3", "PT_MIS"), ("c4", "PT_MIS"), ("c5", "PT_MIS"), ("c5", "PT_SHADOW"), ("c5", "PT_STUPID"), ("c3", "PT_SHADOW")])
+def test_baseline_scenes_at_full_triangle_count(art, backend, config, rt):
     """BASELINE configs C3 (100k triangles), C4 (1M) and C5 (mixed 20k) at their real scene size, reduced frame: the oracle's
     mesh search walks the exported BVH (proven equal to its brute-force scan in test_host_sim_parity / the <=20k cases above),
     everything else is the oracle's own recursion.  Radiance bit-exact, ray counts equal."""
@@ -251,9 +251,9 @@ def test_baseline_scenes_at_full_triangle_count(art, backend, config):
     osc.attach_bvh(nodes, tris, info.node_width)
     W, H = (96, 54)
     backend.resize(W, H)
-    p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=1)
+    p = art.Backend.pass_params(getattr(art, rt), True, 8, 2, seed=1)
     accum, _, spp = backend.render_pass(p, 0)
-    ref, rspp, cnt = orc.render(osc.scene, orc.make_params(W, H, orc.PT_MIS, True, 8, 2, seed=1))
+    ref, rspp, cnt = orc.render(osc.scene, orc.make_params(W, H, getattr(orc, rt), True, 8, 2, seed=1))
     assert spp == rspp == 8
     assert_radiance_equal(accum, ref, spp)
     assert backend.stats().rays == cnt.rays and np.isfinite(ref).all()
