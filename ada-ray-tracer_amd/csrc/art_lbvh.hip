@@ -257,8 +257,11 @@ struct Item { int n2, n8, stack_before; };
 __device__ __forceinline__ float next_dn(float v) { return (v == 0.0f) ? -1.401298464e-45f : __int_as_float(__float_as_int(v) + (v > 0.0f ? -1 : 1)); }
 __device__ __forceinline__ float next_up(float v) { return (v == 0.0f) ? 1.401298464e-45f : __int_as_float(__float_as_int(v) + (v > 0.0f ? 1 : -1)); }
 
+// node_cap: capacity of `nodes` in wide nodes.  A child that would need node >= node_cap is written as an empty slot and *overflow is set
+// (the host then fails the build): the kernel never writes outside its allocation.
 __global__ __launch_bounds__(128) void k_collapse(Lbvh T, const Item* __restrict__ in, int n_in, Item* __restrict__ out, int* out_count, int* node_count,
-                                                  int* max_stack, float* __restrict__ nodes, int width, int max_leaf, float inflate_rel, float inflate_abs) {
+                                                  int* max_stack, int* overflow, int node_cap, float* __restrict__ nodes, int width, int max_leaf,
+                                                  float inflate_rel, float inflate_abs) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n_in) return;
   const Item it = in[q];
@@ -302,8 +305,10 @@ __global__ __launch_bounds__(128) void k_collapse(Lbvh T, const Item* __restrict
       if (c <= max_leaf) { ref = first_of(id); cnt = c; }
       else {
         ref = atomicAdd(node_count, 1); cnt = 0;
-        Item nx; nx.n2 = id; nx.n8 = ref; nx.stack_before = stack_here;
-        out[atomicAdd(out_count, 1)] = nx;
+        if (ref < node_cap) {
+          Item nx; nx.n2 = id; nx.n8 = ref; nx.stack_before = stack_here;
+          out[atomicAdd(out_count, 1)] = nx;
+        } else { ref = -1; atomicExch(overflow, 1); }
       }
     }
     nd[4 * j + 0] = lo[0]; nd[4 * j + 1] = lo[1]; nd[4 * j + 2] = lo[2]; nd[4 * j + 3] = __int_as_float(ref);
@@ -335,8 +340,9 @@ bool build_bvh8_gpu(const float* d_tri9, int n, const BvhBuildParams& prm, hipSt
       !S.get(&parent, 2 * (size_t)n, err) || !S.get(&flag, n, err) || !S.get(&counters, 8, err) || !S.get(&child, n, err) || !S.get(&range, n, err) ||
       !S.get(&qa, n, err) || !S.get(&qb, n, err))
     return false;
-  hipEvent_t e0, e1;
-  LB_TRY(hipEventCreate(&e0)); LB_TRY(hipEventCreate(&e1));
+  struct Events { hipEvent_t a = nullptr, b = nullptr; ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } ev;   // released on every return path
+  LB_TRY(hipEventCreate(&ev.a)); LB_TRY(hipEventCreate(&ev.b));
+  const hipEvent_t e0 = ev.a, e1 = ev.b;
   LB_TRY(hipEventRecord(e0, st));
   const int h_scene[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
   LB_TRY(hipMemcpyAsync(scene, h_scene, sizeof h_scene, hipMemcpyHostToDevice, st));
@@ -399,23 +405,24 @@ bool build_bvh8_gpu(const float* d_tri9, int n, const BvhBuildParams& prm, hipSt
   const size_t tri_bytes = (size_t)n * kTriFloats * sizeof(float);
   LB_TRY(hipMalloc(&out.tris, tri_bytes));
   hipLaunchKernelGGL(k_emit_tris, dim3(nb), dim3(256), 0, st, d_tri9, tri_order, n, out.tris);
-  // collapse, one launch per level of the wide tree; at most n/2+1 nodes can appear (every inner node has >= 2 children)
-  const size_t node_cap = (size_t)n / 2 + 2;
+  // collapse, one launch per level of the wide tree.  Every wide node opens at least one inner node of the binary tree (n - 1 of them), so
+  // at most n - 1 wide nodes can appear; with max_leaf = 1 a balanced tree really needs ~2n/3 (n/2 + 2 was too small: ADVICE r1).
+  const size_t node_cap = (size_t)n;
   LB_TRY(hipMalloc(&out.nodes, node_cap * (size_t)node_floats(prm.width) * sizeof(float)));
-  const int h_cnt[4] = {0, 1, 1, 0};    // [0] next-queue length, [1] node count (root = 0 taken), [2] max stack
+  const int h_cnt[4] = {0, 1, 1, 0};    // [0] next-queue length, [1] node count (root = 0 taken), [2] max stack, [3] node capacity overflow
   LB_TRY(hipMemcpyAsync(counters, h_cnt, sizeof h_cnt, hipMemcpyHostToDevice, st));
   const Item root = {root_id, 0, 0};
   LB_TRY(hipMemcpyAsync(qa, &root, sizeof root, hipMemcpyHostToDevice, st));
   int n_in = 1, levels = 0;
   Item *in = qa, *nx = qb;
   while (n_in > 0) {
-    hipLaunchKernelGGL(k_collapse, dim3((n_in + 127) / 128), dim3(128), 0, st, T, in, n_in, nx, counters, counters + 1, counters + 2, out.nodes,
-                       prm.width, max_leaf, prm.inflate_rel, prm.inflate_abs);
-    int h[3];
+    hipLaunchKernelGGL(k_collapse, dim3((n_in + 127) / 128), dim3(128), 0, st, T, in, n_in, nx, counters, counters + 1, counters + 2, counters + 3, (int)node_cap,
+                       out.nodes, prm.width, max_leaf, prm.inflate_rel, prm.inflate_abs);
+    int h[4];
     LB_TRY(hipMemcpyAsync(h, counters, sizeof h, hipMemcpyDeviceToHost, st));
     LB_TRY(hipStreamSynchronize(st));
     n_in = h[0]; out.n_nodes = h[1]; out.max_stack = h[2];
-    if ((size_t)out.n_nodes > node_cap) { err = "internal: LBVH node capacity exceeded"; return false; }
+    if (h[3] != 0 || (size_t)out.n_nodes > node_cap) { err = "internal: LBVH node capacity exceeded"; return false; }
     LB_TRY(hipMemsetAsync(counters, 0, sizeof(int), st));
     std::swap(in, nx);
     if (++levels > 64) { err = "internal: LBVH collapse did not terminate"; return false; }
@@ -424,7 +431,6 @@ bool build_bvh8_gpu(const float* d_tri9, int n, const BvhBuildParams& prm, hipSt
   LB_TRY(hipEventSynchronize(e1));
   float ms = 0.0f;
   LB_TRY(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   LB_TRY(hipGetLastError());
   out.n_tris = n; out.build_ms = ms; if (prm.builder != 2) out.levels = levels;
   return true;

@@ -61,6 +61,24 @@ def random_triangles(n_tris, seed):
     return dict(mode=MESH_CLOSEST, pos=pos, nrm=nrm, idx=idx, matid=matid)
 
 
+def grid_mesh(m, y0=1.0, tilt=0.35):
+    """Regular tessellation: m x m quads = 2 m^2 equal triangles on a tilted plane inside the Cornell box, front faces towards
+    the camera.  With m a power of two the Morton-sorted radix tree is perfectly balanced -- the worst case for the node count of a
+    wide tree with 1-triangle leaves (about 2n/3 nodes), which random soups never reach."""
+    g = np.linspace(0.0, 1.0, m + 1, dtype=np.float64)
+    X, Z = np.meshgrid(-2.0 + 4.0 * g, 0.5 + 4.0 * g, indexing="ij")
+    Y = y0 + tilt * (Z - 0.5)
+    pos = np.stack([X, Y, Z], -1).reshape(-1, 3).astype(F)
+    i, j = np.meshgrid(np.arange(m), np.arange(m), indexing="ij")
+    a = (i * (m + 1) + j).ravel(); b = a + 1; c = a + (m + 1); d = c + 1
+    idx = np.stack([np.stack([a, b, c], 1), np.stack([b, d, c], 1)], 1).reshape(-1, 3).astype(np.int32)   # normal = +y-ish
+    e1 = pos[idx[:, 1]] - pos[idx[:, 0]]; e2 = pos[idx[:, 2]] - pos[idx[:, 0]]
+    fn = np.cross(e1, e2); fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+    nrm = np.zeros_like(pos); nrm[idx[:, 0]] = fn; nrm[idx[:, 1]] = fn; nrm[idx[:, 2]] = fn
+    matid = (1 + (np.arange(idx.shape[0]) % 3)).astype(np.int32)
+    return dict(mode=MESH_CLOSEST, pos=pos, nrm=nrm.astype(F), idx=idx, matid=matid)
+
+
 def rect_light(cx, mat, intensity=(20.0, 20.0, 20.0), y=4.98, half_x=0.25, cz=2.25, half_z=0.33):
     bmin = (F(cx - half_x), F(y), F(cz - half_z)); bmax = (F(cx + half_x), F(y), F(cz + half_z))
     area = F(F(bmax[0] - bmin[0]) * F(bmax[2] - bmin[2]))
@@ -109,4 +127,17 @@ def mixed_scene(n_tris=20000, config_id=5, extra_spheres=8):
         p = (float(-2.0 + 4.0 * u[i, 0]), float(2.4 + 1.6 * u[i, 1]), float(0.6 + 3.6 * u[i, 2]))
         spheres.append((p, 0.4, (0, 1, 2, 3)[i % 4]))
     mesh = random_triangles(n_tris, 0xADA5EED0 + config_id)
+    return SceneDesc(spheres=spheres, lights=lights, materials=mats, meshes=[mesh], cornell=CORNELL_BOX, cam_pos=REFERENCE_CAMERA)
+
+
+def mirror_scene(n_tris=600, seed=0xADA5EED0 + 17):
+    """Every material of materials.adb in one scene, MaterialMirror (scene.adb:168: materials(5), which no primitive of the reference's
+    own scene carries) on a sphere AND on mesh triangles: a mirror sphere, a Phong sphere, a glass sphere, the sphere light, and a
+    triangle soup whose material ids cycle white / green / red / mirror."""
+    mats = cornell_materials()
+    area = float(F(4.0) * F(np.pi) * F(0.5) * F(0.5))
+    lights = [dict(shape=LIGHT_SPHERE, mat=4, center=(0.0, 4.5, 1.0), radius=0.5, intensity=(10.0, 10.0, 10.0), surfaceArea=area)]
+    spheres = [((-1.3, 1.0, 1.8), 1.0, 5), ((1.4, 1.0, 3.0), 1.0, 0), ((0.1, 0.6, 3.9), 0.6, 8), ((0.0, 4.5, 1.0), 0.5, 4)]
+    mesh = random_triangles(n_tris, seed)
+    mesh["matid"] = np.array([(1, 2, 3, 5)[i % 4] for i in range(n_tris)], np.int32)
     return SceneDesc(spheres=spheres, lights=lights, materials=mats, meshes=[mesh], cornell=CORNELL_BOX, cam_pos=REFERENCE_CAMERA)

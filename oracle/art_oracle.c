@@ -579,6 +579,29 @@ static float mat_eval_pdf(const orc_material* m, f3 l, f3 v, f3 n) {
   }
 }
 
+/* ---- per-function known-answer entry points (tests/test_oracle_kat.py compares them with an independent numpy-float32
+   transcription of lights.adb / materials.adb; the uniforms are the ones the render draws for (seed, pixel, sample, bounce)) ---- */
+void orc_kat_light_sample(const orc_light* l, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, const float p[3], float out10[10]) {
+  rng_ctx g = { seed, pixel, sample, bounce };
+  shadow_sample r = light_sample(l, &g, ld3(p));
+  out10[0] = r.pos.x; out10[1] = r.pos.y; out10[2] = r.pos.z; out10[3] = r.dir.x; out10[4] = r.dir.y; out10[5] = r.dir.z;
+  out10[6] = r.intensity.x; out10[7] = r.intensity.y; out10[8] = r.intensity.z; out10[9] = r.pdf;
+}
+float orc_kat_light_eval_pdf(const orc_light* l, const float p[3], const float ray_dir[3], float hit_dist) {
+  return light_eval_pdf(l, ld3(p), ld3(ray_dir), hit_dist);
+}
+void orc_kat_mat_sample(const orc_material* m, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, const float ray_dir[3],
+                        const float normal[3], float out8[8]) {
+  rng_ctx g = { seed, pixel, sample, bounce };
+  mat_sample r = mat_sample_and_eval(m, &g, ld3(ray_dir), ld3(normal));
+  out8[0] = r.color.x; out8[1] = r.color.y; out8[2] = r.color.z; out8[3] = r.direction.x; out8[4] = r.direction.y; out8[5] = r.direction.z;
+  out8[6] = r.pdf; out8[7] = (float)r.pureSpecular;
+}
+void orc_kat_mat_eval(const orc_material* m, const float l[3], const float v[3], const float n[3], float out4[4]) {
+  f3 b = mat_eval_bxdf(m, ld3(l), ld3(v), ld3(n));
+  out4[0] = b.x; out4[1] = b.y; out4[2] = b.z; out4[3] = mat_eval_pdf(m, ld3(l), ld3(v), ld3(n));
+}
+
 /* ======================================================================================== */
 /* geometry.adb                                                                             */
 /* ======================================================================================== */

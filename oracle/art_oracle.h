@@ -122,6 +122,13 @@ float    orc_powf(float x, float y);          /* restates Ada "**" + vector_math
 void     orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 float    orc_rng_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t slot);
 
+/* ---- per-function KAT entry points: lights.adb Sample / EvalPDF, materials.adb SampleAndEvalBxDF / EvalBxDF / EvalPDF ---- */
+void  orc_kat_light_sample(const orc_light* l, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, const float p[3], float out10[10]);
+float orc_kat_light_eval_pdf(const orc_light* l, const float p[3], const float ray_dir[3], float hit_dist);
+void  orc_kat_mat_sample(const orc_material* m, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, const float ray_dir[3],
+                         const float normal[3], float out8[8]);
+void  orc_kat_mat_eval(const orc_material* m, const float l[3], const float v[3], const float n[3], float out4[4]);
+
 /* ---- scene construction helpers ---- */
 /* scene.adb:89-217.  Fills caller-provided storage; mesh arrays must come from orc_load_vsgf. */
 typedef struct {

@@ -8,6 +8,9 @@ Ada and cannot be built in this image):
   vsgf_decode.json            header + decoded arrays of that file, by an independent numpy decoder
   reference_image_patches.json  mean LDR colour of five mid-surface patches of the reference's own output
                               picture image.png (README.md:2) -- the statistical pin of the oracle
+  reference_image_blocks.npz  the same picture reduced to 128x128 block means (8x8 pixels each, value * 64 as uint16) and the
+                              per-block standard deviation -- the whole-picture pin: the picture turned out to be the HEAD scene
+                              seen from (0, 2.55, 11) instead of scene.adb:212's (0, 2.55, 12.5)
   cornell_debug_64.npz        RT_DEBUG ids of the internal scene at 64x64 from the oracle (regression pin)
   cornell_mis_32.npz          PT_MIS accum of the internal scene, 32x32, 2 passes x 4 spp, seed 1 (regression pin)
 """
@@ -51,6 +54,10 @@ def main():
     json.dump(dict(source="image.png (1024x1024), README.md:2", note="camera of this picture differs from scene.adb:212 at HEAD; "
                    "diffuse-wall radiance is view independent, so mid-wall patches are compared", patches=patches),
               open(os.path.join(HERE, "reference_image_patches.json"), "w"), indent=1)
+
+    blk = ref.reshape(128, 8, 128, 8, 3)
+    np.savez_compressed(os.path.join(HERE, "reference_image_blocks.npz"), mean64=np.round(blk.mean((1, 3)) * 64.0).astype(np.uint16),
+                        std64=np.round(blk.std((1, 3)) * 64.0).astype(np.uint16))
 
     import orc
     cs = orc.CornellScene()

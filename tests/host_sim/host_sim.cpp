@@ -109,3 +109,30 @@ extern "C" int hs_bvh(const ArtSceneDesc* sd, float* nodes, long long node_cap, 
   if (tris) { if (tri_cap < (long long)hs.bvh.tris.size()) return 2; std::memcpy(tris, hs.bvh.tris.data(), hs.bvh.tris.size() * 4); }
   return 0;
 }
+
+// ---- per-function known-answer entry points of the PRODUCT's device code (csrc/art_shade.h compiled for the host): the same four
+// functions the oracle exports as orc_kat_*, with the uniforms passed in.  tests/test_oracle_kat.py checks both against the
+// independent numpy-float32 transcription of lights.adb / materials.adb.
+static_assert(sizeof(ArtLight) == sizeof(DevLight) && sizeof(ArtMaterial) == sizeof(DevMaterial), "ABI records are the device records");
+extern "C" void hs_kat_light_sample(const ArtLight* l, float u1, float u2, const float p[3], float out10[10]) {
+  DevLight d; std::memcpy(&d, l, sizeof d);
+  const LightSample r = light_sample(d, u1, u2, ld3(p));
+  out10[0] = r.pos.x; out10[1] = r.pos.y; out10[2] = r.pos.z; out10[3] = r.dir.x; out10[4] = r.dir.y; out10[5] = r.dir.z;
+  out10[6] = r.intensity.x; out10[7] = r.intensity.y; out10[8] = r.intensity.z; out10[9] = r.pdf;
+}
+extern "C" float hs_kat_light_eval_pdf(const ArtLight* l, const float p[3], const float ray_dir[3], float hit_dist) {
+  DevLight d; std::memcpy(&d, l, sizeof d);
+  return light_eval_pdf(d, ld3(p), ld3(ray_dir), hit_dist);
+}
+extern "C" void hs_kat_mat_sample(const ArtMaterial* m, float xi1, float xi2, const float ray_dir[3], const float normal[3], float out8[8]) {
+  DevMaterial d; std::memcpy(&d, m, sizeof d);
+  const BsdfSample r = bsdf_sample(d, xi1, xi2, ld3(ray_dir), ld3(normal));
+  out8[0] = r.color.x; out8[1] = r.color.y; out8[2] = r.color.z; out8[3] = r.dir.x; out8[4] = r.dir.y; out8[5] = r.dir.z;
+  out8[6] = r.pdf; out8[7] = r.specular ? 1.0f : 0.0f;
+}
+extern "C" void hs_kat_mat_eval(const ArtMaterial* m, const float l[3], const float v[3], const float n[3], float out4[4]) {
+  DevMaterial d; std::memcpy(&d, m, sizeof d);
+  f3 b; float pdf;
+  bsdf_eval(d, ld3(l), ld3(v), ld3(n), b, pdf);
+  out4[0] = b.x; out4[1] = b.y; out4[2] = b.z; out4[3] = pdf;
+}

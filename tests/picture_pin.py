@@ -1,0 +1,80 @@
+"""Whole-picture pin against the reference's only output: image.png (README.md:2), reduced to 128x128 block means in
+tests/golden/reference_image_blocks.npz by tests/golden/make_golden.py.
+
+The picture is the HEAD scene (scene.adb:89-217: Phong sphere, glass sphere, sphere light, pyramid2.vsgf, Phong back wall) seen
+from (0, 2.55, 11.0) -- scene.adb:212 at HEAD says z = 12.5; with fov = pi/2 and z' = -w / tan(fov/2) over x' in [-w/2, w/2]
+(ray_tracer.adb:61-69) the front opening of the box then spans 0.833 of the frame and the back wall 0.455, which is what the
+picture shows (85..938 and 280..745 of 1024).  Everything else is as at HEAD: PT_MIS, AA on, depth 8, gamma 2.
+
+Used by the CPU test of the oracle (tests/test_oracle_image_pin.py) and by the GPU test of the product
+(tests/test_gpu_reference_picture.py): both are compared with the same fixture, block by block and region by region.
+A Monte Carlo picture can only be pinned statistically; the tolerances below are a few LDR levels on 16x16-pixel block means."""
+import numpy as np
+
+import orc
+
+PICTURE_CAMERA = (0.0, 2.55, 11.0)
+
+# named regions in the picture's own pixel coordinates (1024x1024, origin top-left): centre x, centre y, half size
+REGIONS = dict(
+    light_core=(512, 340, 24),                # sphere light seen directly: saturated
+    ceiling_under_light=(512, 258, 16),       # halo on the ceiling above the light: saturated
+    back_wall_centre=(512, 530, 24),          # Phong back wall, away from every lobe: black
+    back_wall_left=(330, 450, 16),            # Phong back wall reflecting the green wall
+    back_wall_right=(690, 450, 16),           # ... and the red wall
+    phong_highlight=(384, 598, 8),            # light reflected in the Phong sphere: saturated
+    phong_body_dark=(345, 670, 16),           # Phong sphere reflecting the dark back of the room
+    phong_green_reflection=(290, 660, 16),    # Phong sphere reflecting the green wall
+    glass_interior=(700, 690, 32),            # through the glass sphere (Fresnel reflect/refract, ior 1.75)
+    glass_red_refraction=(640, 760, 16),      # red wall refracted through the glass sphere
+    caustic=(762, 862, 24),                   # light focused on the floor by the glass sphere
+    pyramid_left_face=(390, 810, 12),         # pyramid2.vsgf through IntersectMeshBF
+    pyramid_right_face=(455, 815, 8),
+    pyramid_shadow=(400, 850, 8),
+    green_wall=(180, 520, 24), red_wall=(845, 520, 24), floor_front=(512, 900, 24), ceiling_front=(512, 130, 16),
+    outside=(40, 40, 24))                     # Cornell box face 5 is open, nothing behind: background
+
+
+def reference_blocks():
+    g = np.load(orc.GOLDEN + "/reference_image_blocks.npz")
+    return g["mean64"].astype(np.float64) / 64.0, g["std64"].astype(np.float64) / 64.0
+
+
+def ldr_rgb_top_left(screen_u32):
+    """packed R | G<<8 | B<<16 rows bottom-up (y ascending, like Bitmap) -> float rgb[H, W, 3] with the origin top-left like the PNG"""
+    s = np.asarray(screen_u32)
+    return np.stack([s & 255, (s >> 8) & 255, (s >> 16) & 255], -1).astype(np.float64)[::-1]
+
+
+def compare_with_reference_picture(rgb, what):
+    """rgb: square LDR render [N, N, 3] (top-left origin), N in {256, 512, 1024}, of the HEAD scene from PICTURE_CAMERA.
+    Returns a dict of the measured statistics; raises AssertionError when the render is not the reference's picture."""
+    N = rgb.shape[0]
+    assert rgb.shape == (N, N, 3) and 1024 % N == 0 and N >= 256
+    mean, std = reference_blocks()
+    # 64 x 64 grid of blocks, each 16x16 pixels of the picture
+    ref = mean.reshape(64, 2, 64, 2, 3).mean((1, 3))
+    spread = mean.reshape(64, 2, 64, 2, 3).max((1, 3)) - mean.reshape(64, 2, 64, 2, 3).min((1, 3))
+    noise = std.reshape(64, 2, 64, 2, 3).max((1, 3))
+    smooth = (spread.max(-1) < 8.0) & (noise.max(-1) < 16.0)          # no silhouette / highlight edge inside the block
+    b = N // 64
+    mine = rgb.reshape(64, b, 64, b, 3).mean((1, 3))
+    d = np.abs(mine - ref)
+    stats = dict(smooth_blocks=int(smooth.sum()), smooth_mean=float(d[smooth].mean()), smooth_max=float(d[smooth].max()),
+                 all_mean=float(d.mean()), all_max=float(d.max()), brightness_ratio=float(mine.sum() / ref.sum()))
+    assert stats["smooth_blocks"] > 2500
+    assert stats["smooth_mean"] < 0.8, (what, stats)       # measured 0.33 (oracle 512^2 x 256 spp)
+    assert stats["smooth_max"] < 9.0, (what, stats)        # measured 6.0
+    assert stats["all_mean"] < 1.2, (what, stats)
+    assert stats["all_max"] < (45.0 if N < 512 else 25.0), (what, stats)   # blocks cut by a silhouette: resolution dependent
+    assert abs(stats["brightness_ratio"] - 1.0) < 0.01, (what, stats)      # measured 1.0015
+    s = 1024 // N
+    for name, (x, y, r) in REGIONS.items():
+        want = mean[(y - r) // 8:(y + r) // 8, (x - r) // 8:(x + r) // 8].mean((0, 1))
+        got = rgb[(y - r) // s:(y + r) // s, (x - r) // s:(x + r) // s].mean((0, 1))
+        tol = np.maximum(0.07 * want, 2.5)
+        if name == "caustic":
+            tol = np.maximum(0.15 * want, 2.5)             # a sharp peak: sensitive to the half-pixel shift between resolutions
+        assert np.all(np.abs(got - want) <= tol), (what, name, got.round(2), want.round(2))
+        stats[name] = (got.round(2).tolist(), want.round(2).tolist())
+    return stats

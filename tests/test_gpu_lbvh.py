@@ -78,6 +78,31 @@ def test_lbvh_tree_is_well_formed(art, gpu_builder, ntris):
     _check_tree(nodes, tris, info, pos, idx)
 
 
+@pytest.mark.parametrize("m", [4, 16, 128])
+def test_lbvh_regular_grid_with_one_triangle_leaves(art, gpu_builder, m):
+    """A regular tessellation with n = 2 m^2 = 2^k triangles gives a perfectly balanced radix tree; with 1-triangle leaves the wide
+    tree then needs about 2n/3 nodes (21 for n = 32 at width 4, 21845 for n = 32768) -- more than the n/2 + 2 the builder
+    used to allocate.  The tree must be complete and sound, and the hits equal the brute-force scan."""
+    from ada_ray_tracer_amd import scenes
+    mesh = scenes.grid_mesh(m)
+    mats = scenes.cornell_materials()
+    lights = [dict(shape=art.LIGHT_SPHERE, mat=4, center=(0.0, 4.5, 1.0), radius=0.5, intensity=(10.0, 10.0, 10.0), surfaceArea=3.14159)]
+    sd = art.SceneDesc([], lights, mats, [mesh], None, scenes.REFERENCE_CAMERA)
+    gpu_builder.set_option("bvh_max_leaf", 1)
+    try:
+        gpu_builder.upload_scene(sd)
+    finally:
+        gpu_builder.set_option("bvh_max_leaf", 0)
+    nodes, tris, info = gpu_builder.export_bvh()
+    n = 2 * m * m
+    assert info.n_tris == n
+    _check_tree(nodes, tris, info, np.asarray(mesh["pos"], np.float32), np.asarray(mesh["idx"], np.int32))
+    if info.node_width == 4 and m >= 16:
+        assert info.n_nodes > n // 2 + 2, "this case is meant to exceed the old capacity (got %d nodes for %d triangles)" % (info.n_nodes, n)
+    o, d = _random_rays(4000, m)
+    _assert_hits_equal(gpu_builder.trace_rays(o, d), orc.closest_hits(conv.OracleScene(sd).scene, o, d))
+
+
 @pytest.mark.parametrize("kernel", ["TRACE_COOP", "TRACE_SIMPLE"])
 @pytest.mark.parametrize("ntris", [2, 9, 300, 20000])
 def test_lbvh_hits_match_brute_force(art, gpu_builder, kernel, ntris):

@@ -237,6 +237,36 @@ def test_mixed_scene_bit_exact(art, backend):
     assert_radiance_equal(accum, ref, spp)
 
 
+@pytest.mark.parametrize("rt", ["PT_MIS", "PT_SHADOW", "PT_STUPID"])
+def test_mirror_material_on_sphere_and_mesh_bit_exact(art, backend, rt):
+    """MaterialMirror (materials.adb:232-264) on a sphere and on mesh triangles, next to every other material, all three integrators."""
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.mirror_scene()
+    osc = conv.OracleScene(sd)
+    backend.upload_scene(sd)
+    backend.resize(80, 64)
+    p = art.Backend.pass_params(getattr(art, rt), True, 8, 2, seed=12)
+    accum, _, spp = backend.render_pass(p, 0)
+    ref, rspp, cnt = orc.render(osc.scene, orc.make_params(80, 64, getattr(orc, rt), True, 8, 2, seed=12))
+    assert spp == rspp
+    assert_radiance_equal(accum, ref, spp)
+    assert backend.stats().rays == cnt.rays
+    # the mirror really is in the picture: primary hits on material 5 (sphere: matId 0 / mat 5; triangles: matId 5)
+    _, _, prim, mat, ptype = backend.debug_hit_pass(art.Backend.pass_params(art.RT_DEBUG, False, 8, 1))
+    hits = backend.trace_rays(*_camera_rays(80, 64))
+    mats = np.array([h.mat for h in hits])
+    assert (mats == 5).sum() > 200 and ((mats == 5) & (np.array([h.prim_type for h in hits]) == 2)).sum() > 5
+
+
+def _camera_rays(w, h):
+    """primary rays of the reference camera (ray_tracer.adb:61-69: z' = -w / tan(pi/4), pixel centres)"""
+    x, y = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    d = np.stack([x + 0.5 - w / 2.0, y + 0.5 - h / 2.0, np.full_like(x, -float(w))], -1).reshape(-1, 3)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    o = np.tile(np.array([0.0, 2.55, 12.5], np.float32), (d.shape[0], 1))
+    return o, d
+
+
 @pytest.mark.parametrize("config,rt", [("c3", "PT_MIS"), ("c4", "PT_MIS"), ("c5", "PT_MIS"), ("c5", "PT_SHADOW"), ("c5", "PT_STUPID"), ("c3", "PT_SHADOW")])
 def test_baseline_scenes_at_full_triangle_count(art, backend, config, rt):
     """BASELINE configs C3 (100k triangles), C4 (1M) and C5 (mixed 20k) at their real scene size, reduced frame: the oracle's
@@ -257,6 +287,23 @@ def test_baseline_scenes_at_full_triangle_count(art, backend, config, rt):
     assert spp == rspp == 8
     assert_radiance_equal(accum, ref, spp)
     assert backend.stats().rays == cnt.rays and np.isfinite(ref).all()
+
+
+@pytest.mark.parametrize("config", ["c3", "c4"])
+def test_bench_scale_tree_is_sound_and_hits_equal_brute_force(art, backend, config):
+    """Independent of the product's tree (the test above lets the oracle walk it): the uploaded C3 / C4 tree is checked structurally
+    (tests/bvh_check.py) and the trace kernel's hits are compared with the oracle's O(N) scan over all 100 k / 1 M triangles."""
+    import bvh_check
+    from ada_ray_tracer_amd import scenes
+    ntris = 100000 if config == "c3" else 1000000
+    sd = scenes.synthetic_scene(ntris, 3 if config == "c3" else 4)
+    backend.upload_scene(sd)
+    nodes, tris, info = backend.export_bvh()
+    pos, _, idx, _, _ = [a for a, m in zip(sd._mesh_arrays, sd.meshes) if m.mode == art.MESH_CLOSEST][0]
+    r = bvh_check.check_tree(nodes, tris, info.n_nodes, info.max_stack, info.node_width, pos, idx)
+    assert r["records"] == ntris
+    o, d = _random_rays(6000 if config == "c3" else 2500, ntris)
+    _assert_hits_equal(backend.trace_rays(o, d), orc.closest_hits(conv.OracleScene(sd).scene, o, d))
 
 
 def test_pixel_tile_shards_sum_to_the_full_frame(art, backend, cornell):

@@ -1,0 +1,161 @@
+"""Known-answer tests of light sampling and the five BSDFs against an INDEPENDENT numpy-float32 transcription of the Ada text
+(tests/ada_transcription.py: lights.adb:42-255, materials.adb:18-410, vector_math.adb:64-82,175-326).  Both the oracle
+(oracle/art_oracle.c, orc_kat_*) and the product's device code (csrc/art_shade.h compiled for the host by tests/host_sim, hs_kat_*)
+must reproduce the transcription BIT FOR BIT on seeded random inputs -- a misreading of the Ada source shared by oracle and product
+would have to be made a third time, in a third language, to pass."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ada_transcription as ada
+import hostsim
+import orc
+
+f = np.float32
+SEED = 0x5EED
+
+
+def bits(x):
+    return np.asarray(x, np.float32).view(np.uint32)
+
+
+def unit(rng):
+    v = rng.normal(size=3)
+    return tuple(f(c) for c in ada.normalize(tuple(f(c) for c in v)))
+
+
+def c3(v):
+    return (C.c_float * 3)(*[float(c) for c in v])
+
+
+@pytest.fixture(scope="module")
+def libs(art):
+    L = orc.lib()
+    L.orc_kat_light_sample.argtypes = [C.POINTER(orc.Light), C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, orc.f32p, orc.f32p]
+    L.orc_kat_light_eval_pdf.argtypes = [C.POINTER(orc.Light), orc.f32p, orc.f32p, C.c_float]; L.orc_kat_light_eval_pdf.restype = C.c_float
+    L.orc_kat_mat_sample.argtypes = [C.POINTER(orc.Material), C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, orc.f32p, orc.f32p, orc.f32p]
+    L.orc_kat_mat_eval.argtypes = [C.POINTER(orc.Material), orc.f32p, orc.f32p, orc.f32p, orc.f32p]
+    H = hostsim.lib(art)
+    H.hs_kat_light_sample.argtypes = [C.POINTER(art.ArtLight), C.c_float, C.c_float, orc.f32p, orc.f32p]
+    H.hs_kat_light_eval_pdf.argtypes = [C.POINTER(art.ArtLight), orc.f32p, orc.f32p, C.c_float]; H.hs_kat_light_eval_pdf.restype = C.c_float
+    H.hs_kat_mat_sample.argtypes = [C.POINTER(art.ArtMaterial), C.c_float, C.c_float, orc.f32p, orc.f32p, orc.f32p]
+    H.hs_kat_mat_eval.argtypes = [C.POINTER(art.ArtMaterial), orc.f32p, orc.f32p, orc.f32p, orc.f32p]
+    return L, H
+
+
+def uniforms(L, k, bounce=0):
+    """the four uniforms the render draws at (seed, pixel k, sample 0, bounce): light x2, BSDF x2"""
+    return [f(L.orc_rng_uniform(SEED, k, 0, bounce, s)) for s in range(4)]
+
+
+def both_lights(art, l):
+    a, b = orc.Light(), art.ArtLight()
+    for x in (a, b):
+        x.shape = l["shape"]; x.mat = 4
+        for key in ("boxMin", "boxMax", "normal", "center", "intensity"):
+            setattr(x, key, c3(l[key]))
+        x.radius = float(l["radius"]); x.surfaceArea = float(l["surfaceArea"])
+    return a, b
+
+
+def both_mats(art, mtype, p):
+    a, b = orc.Material(), art.ArtMaterial()
+    for x in (a, b):
+        x.type = mtype; x.light = 0
+        x.p = (C.c_float * 8)(*([float(v) for v in p] + [0.0] * (8 - len(p))))
+    return a, b
+
+
+SPHERE_LIGHT = dict(shape=1, boxMin=ada.V(0, 0, 0), boxMax=ada.V(0, 0, 0), normal=ada.V(0, -1, 0), center=ada.V(0.0, 4.5, 1.0), radius=f(0.5),
+                    intensity=ada.V(10, 10, 10), surfaceArea=f(f(4.0) * f(np.pi) * f(0.5) * f(0.5)))                       # scene.adb:104-122
+RECT_LIGHT = dict(shape=0, boxMin=ada.V(-0.75, 4.98, 1.25), boxMax=ada.V(0.75, 4.98, 3.25), normal=ada.V(0, -1, 0), center=ada.V(0, 0, 0), radius=f(0),
+                  intensity=ada.V(20, 20, 20), surfaceArea=f(f(1.5) * f(2.0)))
+
+
+@pytest.mark.parametrize("light", [SPHERE_LIGHT, RECT_LIGHT], ids=["SphereLight", "AreaLight"])
+def test_light_sample_and_eval_pdf(art, libs, light):
+    L, H = libs
+    lo, lp = both_lights(art, light)
+    rng = np.random.default_rng(1)
+    n_inside = 0
+    for k in range(400):
+        p = tuple(f(v) for v in (rng.random(3) * [5.0, 4.9, 5.0] + [-2.5, 0.0, 0.0]))
+        if k % 25 == 0 and light is SPHERE_LIGHT:                      # points on / inside the light sphere: the uniform-sphere branch
+            d = unit(rng)
+            p = ada.add(light["center"], ada.scale(f(0.5 * (k % 50 == 0) + 0.25), d))
+            n_inside += 1
+        u = uniforms(L, k)
+        want = ada.sphere_light_sample(light, u[0], u[1], p) if light is SPHERE_LIGHT else ada.area_light_sample(light, u[0], u[1], p)
+        want10 = np.array(list(want["pos"]) + list(want["dir"]) + list(want["intensity"]) + [want["pdf"]], np.float32)
+        o10 = np.zeros(10, np.float32); h10 = np.zeros(10, np.float32)
+        L.orc_kat_light_sample(C.byref(lo), SEED, k, 0, 0, orc.fp(np.array(p, np.float32)), orc.fp(o10))
+        H.hs_kat_light_sample(C.byref(lp), float(u[0]), float(u[1]), orc.fp(np.array(p, np.float32)), orc.fp(h10))
+        assert np.array_equal(bits(o10), bits(want10)), ("oracle", k, o10, want10)
+        assert np.array_equal(bits(h10), bits(want10)), ("product", k, h10, want10)
+        rd = unit(rng); dist = f(rng.random() * 6 + 0.1)
+        wpdf = ada.sphere_light_eval_pdf(light, p) if light is SPHERE_LIGHT else ada.area_light_eval_pdf(light, p, rd, dist)
+        pa, ra = np.array(p, np.float32), np.array(rd, np.float32)
+        assert bits(L.orc_kat_light_eval_pdf(C.byref(lo), orc.fp(pa), orc.fp(ra), float(dist))) == bits(wpdf)
+        assert bits(H.hs_kat_light_eval_pdf(C.byref(lp), orc.fp(pa), orc.fp(ra), float(dist))) == bits(wpdf)
+    assert light is not SPHERE_LIGHT or n_inside >= 10
+
+
+MATERIALS = {   # scene.adb:155-180
+    "Lambert": (orc.MAT_LAMBERT, [0.25, 0.5, 0.0]),
+    "Mirror": (orc.MAT_MIRROR, [0.75, 0.75, 0.75]),
+    "FresnelDielectric": (orc.MAT_GLASS, [0.75, 0.75, 0.75, 0.85, 0.85, 0.85, 1.75]),
+    "Phong": (orc.MAT_PHONG, [0.75, 0.75, 0.75, 80.0]),
+    "PhongWide": (orc.MAT_PHONG, [0.5, 0.6, 0.7, 3.0]),
+}
+
+
+@pytest.mark.parametrize("name", list(MATERIALS))
+def test_bsdf_sample_and_eval(art, libs, name):
+    L, H = libs
+    mtype, p = MATERIALS[name]
+    mo, mp = both_mats(art, mtype, p)
+    pf = [f(v) for v in p]
+    rng = np.random.default_rng(2)
+    n_spec_branches = set()
+    for k in range(500):
+        n = unit(rng); d = unit(rng)
+        if k % 3 and ada.dot(d, n) > 0:                                 # mostly rays arriving from outside; every third left as drawn (inside / grazing)
+            d = ada.scale(f(-1), d)
+        if k % 17 == 0:                                                 # grazing incidence
+            t = ada.normalize(ada.cross(n, unit(rng)))
+            d = ada.normalize(ada.add(t, ada.scale(f(-1e-3 * (k % 5)), n)))
+        u = uniforms(L, k)
+        if name == "Lambert":
+            want = ada.lambert_sample(tuple(pf[:3]), u[2], u[3], d, n)
+        elif name == "Mirror":
+            want = ada.mirror_sample(tuple(pf[:3]), d, n)
+        elif name == "FresnelDielectric":
+            want = ada.glass_sample(tuple(pf[:3]), tuple(pf[3:6]), pf[6], u[2], d, n)
+            n_spec_branches.add((bool(ada.dot(d, n) < 0), bool(ada.dot(want["dir"], n) * ada.dot(d, n) > 0)))
+        else:
+            want = ada.phong_sample(tuple(pf[:3]), pf[3], u[2], u[3], d, n)
+        want8 = np.array(list(want["color"]) + list(want["dir"]) + [want["pdf"], 1.0 if want["specular"] else 0.0], np.float32)
+        o8 = np.zeros(8, np.float32); h8 = np.zeros(8, np.float32)
+        da, na = np.array(d, np.float32), np.array(n, np.float32)
+        L.orc_kat_mat_sample(C.byref(mo), SEED, k, 0, 0, orc.fp(da), orc.fp(na), orc.fp(o8))
+        H.hs_kat_mat_sample(C.byref(mp), float(u[2]), float(u[3]), orc.fp(da), orc.fp(na), orc.fp(h8))
+        assert np.array_equal(bits(o8), bits(want8)), ("oracle", name, k, o8, want8)
+        assert np.array_equal(bits(h8), bits(want8)), ("product", name, k, h8, want8)
+        # EvalBxDF / EvalPDF for a light direction l and view direction v = -d
+        l = unit(rng); v = ada.scale(f(-1), d)
+        if name == "Lambert":
+            wb, wp = ada.lambert_eval(tuple(pf[:3]), l, v, n)
+        elif name.startswith("Phong"):
+            wb, wp = ada.phong_eval(tuple(pf[:3]), pf[3], l, v, n)
+        else:
+            wb, wp = ada.V(0, 0, 0), f(1)                               # materials.adb:256-264, 333-341: no direct sampling of specular materials
+        want4 = np.array(list(wb) + [wp], np.float32)
+        o4 = np.zeros(4, np.float32); h4 = np.zeros(4, np.float32)
+        la, va = np.array(l, np.float32), np.array(v, np.float32)
+        L.orc_kat_mat_eval(C.byref(mo), orc.fp(la), orc.fp(va), orc.fp(na), orc.fp(o4))
+        H.hs_kat_mat_eval(C.byref(mp), orc.fp(la), orc.fp(va), orc.fp(na), orc.fp(h4))
+        assert np.array_equal(bits(o4), bits(want4)), ("oracle eval", name, k, o4, want4)
+        assert np.array_equal(bits(h4), bits(want4)), ("product eval", name, k, h4, want4)
+    if name == "FresnelDielectric":
+        assert len(n_spec_branches) == 4, "reflection and refraction, entering and leaving, must all occur: %s" % n_spec_branches
