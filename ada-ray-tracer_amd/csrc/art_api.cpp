@@ -82,7 +82,7 @@ static int upload_scene_arrays(HostScene& hs) {
   Ctx& c = g_ctx;
   if (upload(c.b_spheres, hs.spheres) || upload(c.b_sphere_mat, hs.sphere_mat) || upload(c.b_lights, hs.lights) ||
       upload(c.b_materials, hs.materials) || upload(c.b_bf_pos, hs.bf_pos) || upload(c.b_bf_nrm, hs.bf_nrm) ||
-      upload(c.b_bf_uv, hs.bf_uv) || upload(c.b_bf_idx, hs.bf_idx) || (!hs.gpu_built && upload(c.b_nodes, hs.bvh.nodes)) ||
+      upload(c.b_bf_uv, hs.bf_uv) || upload(c.b_bf_idx, hs.bf_idx) || (!hs.gpu_built && upload(c.b_nodes, hs.bvh.nodes)) || (!hs.gpu_built && upload(c.b_qnodes, hs.bvh.qnodes)) ||
       (!hs.gpu_built && upload(c.b_tris, hs.bvh.tris)) || upload(c.b_m_nrm, hs.m_nrm) || upload(c.b_m_uv, hs.m_uv) ||
       upload(c.b_m_idx, hs.m_idx) || upload(c.b_m_matid, hs.m_matid))
     return 1;
@@ -111,8 +111,9 @@ int upload_scene(const ArtSceneDesc* d) {
     GpuBvh g;
     const bool ok = build_bvh8_gpu((const float*)tri9.p, (int)(hs.deferred_tri9.size() / 9), c.bvh_params, c.stream, g, err);
     tri9.release();
-    if (!ok) { if (g.nodes) (void)hipFree(g.nodes); if (g.tris) (void)hipFree(g.tris); return fail("GPU BVH build: " + err); }
-    c.b_nodes.release(); c.b_tris.release();
+    if (!ok) { if (g.nodes) (void)hipFree(g.nodes); if (g.tris) (void)hipFree(g.tris); if (g.qnodes) (void)hipFree(g.qnodes); return fail("GPU BVH build: " + err); }
+    c.b_nodes.release(); c.b_tris.release(); c.b_qnodes.release();
+    c.b_qnodes.p = g.qnodes; c.b_qnodes.bytes = g.qnodes ? (size_t)g.n_nodes * kQNodeBytes : 0;
     c.b_nodes.p = g.nodes; c.b_nodes.bytes = (size_t)g.n_nodes * node_floats(c.bvh_params.width) * 4;
     hs.bvh.width = c.bvh_params.width;
     c.b_tris.p = g.tris; c.b_tris.bytes = (size_t)g.n_tris * kTriFloats * 4;
@@ -121,8 +122,11 @@ int upload_scene(const ArtSceneDesc* d) {
     hs.bvh_build_ms = g.build_ms; hs.gpu_built = true;
     std::vector<float>().swap(hs.deferred_tri9);
   }
-  if ((uint64_t)hs.bvh.n_nodes * node_floats(hs.hdr.node_width) * 4 >= (1ull << 32) || (uint64_t)hs.bvh.n_tris * kTriFloats * 4 >= (1ull << 32))
-    return fail("mesh too large: the trace kernel addresses nodes and triangles with 32-bit byte offsets (max ~89M triangles)");
+  // the trace kernel addresses nodes and triangles with 32-bit byte offsets; the 4-wide entry word keeps bit 31 for the leaf flag
+  const uint64_t off_limit = (hs.hdr.node_width == 4) ? (1ull << 31) : (1ull << 32);
+  if ((uint64_t)hs.bvh.n_nodes * node_floats(hs.hdr.node_width) * 4 >= (1ull << 32) || (uint64_t)hs.bvh.n_tris * kTriFloats * 4 >= off_limit)
+    return fail("mesh too large: the trace kernel addresses nodes and triangles with 32-bit byte offsets (max ~44M triangles at width 4, ~89M at width 8)");
+  if (hs.hdr.node_width == 4 && hs.bvh.n_nodes > 0 && !c.b_qnodes.p && hs.gpu_built) return fail("internal: GPU build returned no quantised nodes");
   if (hs.bvh.max_stack > kStackEntries) return fail("BVH traversal stack bound " + std::to_string(hs.bvh.max_stack) + " exceeds " + std::to_string(kStackEntries));
   if (upload_scene_arrays(hs)) return 1;
   c.bvh_stack_bound = std::max(8, hs.bvh.max_stack);
@@ -185,6 +189,7 @@ static void stack_plan(int kernel, int& entries, bool& overflow) {
   (void)kernel;
   int cap = per_block / (4 * groups * 8) - 3;     // entries per ray (+ 2 guard entries + the sink of masked pushes)
   if (c.lds_stack_cap > 0) cap = c.lds_stack_cap;
+  cap = std::min(cap, 64 * 1024 / (4 * groups * 8) - 3);      // one workgroup's dynamic LDS stays within the 64 KB a launch may ask for by default
   entries = std::min(c.bvh_stack_bound, cap);
   overflow = c.bvh_stack_bound > entries;
 }
@@ -203,7 +208,7 @@ static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
   a.node_min = c.node_min; a.segments = c.queue_segments; a.chunk = c.ray_chunk;
   a.ray_ox = q.ray_ox; a.ray_oy = q.ray_oy; a.ray_oz = q.ray_oz; a.ray_dx = q.ray_dx; a.ray_dy = q.ray_dy; a.ray_dz = q.ray_dz; a.ray_tfar = q.ray_tfar;
   a.hit_t = q.hit_t; a.hit_key = q.hit_key; a.hit_u = q.hit_u; a.hit_v = q.hit_v;
-  a.nodes = c.scene.nodes; a.tris = c.scene.tris; a.n_tris = c.scene.n_tris;
+  a.nodes = c.scene.nodes; a.qnodes = (const uint32_t*)c.b_qnodes.p; a.tris = c.scene.tris; a.n_tris = c.scene.n_tris;
   a.sh_min = (c.shadow_anyhit && q.sh_min_t && n_rays > q.P) ? q.sh_min_t : nullptr; a.shadow_begin = q.P;
   a.cursor = c.d_cursor; a.stats = c.d_counters + 3; a.live_rays = c.d_counters;
   a.queue = (int*)c.b_queue.p; a.queue_count = c.d_cursor + 1;
@@ -451,7 +456,7 @@ void shutdown() {
   if (c.device_ready) {
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c.b_spheres, &c.b_sphere_mat, &c.b_lights, &c.b_materials, &c.b_bf_pos, &c.b_bf_nrm, &c.b_bf_uv, &c.b_bf_idx,
-                      &c.b_nodes, &c.b_tris, &c.b_m_nrm, &c.b_m_uv, &c.b_m_idx, &c.b_m_matid, &c.b_accum, &c.b_screen, &c.b_stage,
+                      &c.b_nodes, &c.b_qnodes, &c.b_tris, &c.b_m_nrm, &c.b_m_uv, &c.b_m_idx, &c.b_m_matid, &c.b_accum, &c.b_screen, &c.b_stage,
                       &c.b_pixmap, &c.b_paths, &c.b_rays, &c.b_ids, &c.b_queue, &c.b_ovf};
     for (DevBuf* b : bufs) b->release();
     if (c.d_cursor) (void)hipFree(c.d_cursor);

@@ -4,6 +4,7 @@
 // in art_scene.h.  Boxes are inflated by a few ulps so that the kernel's slab test can never cull a
 // triangle that the reference's Moeller-Trumbore arithmetic would accept.
 #include "art_bvh.h"
+#include "art_qnode.h"
 
 #include <algorithm>
 #include <atomic>
@@ -346,6 +347,14 @@ bool build_bvh8(const float* tri9, const int32_t* prim_ids, int32_t n, const Bvh
   }
   out.n_nodes = (int32_t)(N.size() / NF);
   out.n_tris = (int32_t)(out.tris.size() / kTriFloats);
+  if (W == 4 && prm.quantise) {                     // 64-byte form for k_trace_coop; N becomes the tree with the dequantised boxes
+    out.qnodes.resize((size_t)out.n_nodes * (kQNodeBytes / 4));
+    for (int32_t i = 0; i < out.n_nodes; ++i) {
+      QNode q;
+      quantise_node(&N[(size_t)i * NF], q);
+      std::memcpy(&out.qnodes[(size_t)i * (kQNodeBytes / 4)], &q, sizeof q);
+    }
+  }
   out.max_stack = max_stack;
   if (out.n_tris != (int32_t)B.leaf_ids.size() || out.n_tris < n) { err = "internal: triangle count mismatch after collapse"; return false; }
   return true;

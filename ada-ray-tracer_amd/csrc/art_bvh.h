@@ -28,12 +28,15 @@ struct BvhBuildParams {
   int   ploc_radius = 8;         // PLOC: neighbours searched on either side
   int   gpu_max_leaf = 0;        // GPU builders: a subtree of at most this many triangles becomes one leaf; 0 = measured optimum
                                  // (1 for width 4, 2 for width 8: their trees have no SAH leaf term, small leaves cull better)
+  int   quantise = 1;            // width 4: child boxes snapped outwards to the 8-bit grid of the 64-byte node (art_qnode.h); 0 keeps binary32 boxes
+                                 // (then the trace kernel cannot run the tree: test-only, to measure what the snapping costs in visits)
   float leaf_cost(int n) const { return leaf_base + (tri_cost >= 0.0f ? tri_cost : (width == 4 ? 0.2f : 0.05f)) * (float)n; }
 };
 
 struct Bvh8 {
   std::vector<float> nodes;      // node_floats(width) per node, node 0 = root
   int32_t width = 8;
+  std::vector<uint32_t> qnodes;  // width 4: the same nodes in the 64-byte quantised form (art_qnode.h), 16 words per node
   std::vector<float> tris;       // kTriFloats per triangle, in leaf order
   int32_t n_nodes = 0, n_tris = 0;
   int32_t max_stack = 1;         // worst-case traversal stack entries for this tree

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "art_shade.h"
+#include "art_qnode.h"
 
 namespace art {
 
@@ -22,7 +23,7 @@ struct TraceArgs {
   // sh_min[i - shadow_begin] = 10*eps.  nullptr: every ray is a closest-hit query.
   const float* sh_min; int32_t shadow_begin;
   float* hit_t; uint32_t* hit_key; float* hit_u; float* hit_v;
-  const float* nodes; const float* tris; int32_t n_tris;   // BVH of the closest-hit mesh (hot-loop operands)
+  const float* nodes; const uint32_t* qnodes; const float* tris; int32_t n_tris;   // qnodes: 64-byte quantised nodes (width 4, art_qnode.h)   // BVH of the closest-hit mesh (hot-loop operands)
   int32_t chunk;                // rays a wave claims per atomic on the cursor
   int* cursor;                  // work cursors, zeroed before every launch: segment k's cursor is cursor[32 * (k + 1)] (cursor[0] serves the
                                 // kernels with a single cursor)

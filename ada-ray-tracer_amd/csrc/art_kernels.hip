@@ -74,13 +74,17 @@ template <> __device__ __forceinline__ uint32_t group_min_u32_g<4>(uint32_t k) {
   return k;
 }
 
-// number of lanes of my group for which p holds
-template <int G> __device__ __forceinline__ int group_count_g(bool p, int gbase);
-template <> __device__ __forceinline__ int group_count_g<8>(bool p, int gbase) { return __popcll((__builtin_amdgcn_ballot_w64(p) >> gbase) & 0xffull); }
-template <> __device__ __forceinline__ int group_count_g<4>(bool p, int) {       // two DPP adds inside the quad
-  int h = p ? 1 : 0;
+// sum of h over the lanes of my group (every lane gets it): DPP adds inside the quad / the 8-lane group
+template <int G> __device__ __forceinline__ int group_sum_g(int h);
+template <> __device__ __forceinline__ int group_sum_g<4>(int h) {
   h += dpp_i<DPP_XOR1>(h);
   h += dpp_i<DPP_XOR2>(h);
+  return h;
+}
+template <> __device__ __forceinline__ int group_sum_g<8>(int h) {
+  h += dpp_i<DPP_XOR1>(h);
+  h += dpp_i<DPP_XOR2>(h);
+  h += xor4_i(h);
   return h;
 }
 
@@ -94,33 +98,95 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // ------------------------------------------------------------------------------------------------
+// lane masks as explicit 64-bit scalars.  The step code below is branch-free and runs with all 64 lanes enabled, so a per-lane
+// boolean IS a 64-bit mask in an SGPR pair.  Written with the compiler's i1 values, every `ballot` of a combined predicate costs a
+// v_cndmask + v_cmp round trip through a VGPR; written as masks, compares produce them (v_cmp -> SGPR pair), the logic is s_and /
+// s_andn2, a population count is s_bcnt1, and a select takes the mask as its SGPR operand.
+// ------------------------------------------------------------------------------------------------
+using mask_t = uint64_t;
+__device__ __forceinline__ mask_t vcmp(bool direct_compare) { return __builtin_amdgcn_ballot_w64(direct_compare); }   // argument: ONE compare
+__device__ __forceinline__ uint32_t sel(mask_t m, uint32_t if_set, uint32_t if_clear) {
+  uint32_t r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+  return r;
+}
+__device__ __forceinline__ float self(mask_t m, float if_set, float if_clear) {
+  return __builtin_bit_cast(float, sel(m, __builtin_bit_cast(uint32_t, if_set), __builtin_bit_cast(uint32_t, if_clear)));
+}
+__device__ __forceinline__ bool lane_of(mask_t m) { return sel(m, 1u, 0u) != 0u; }        // mask -> this lane's bit (off the hot path)
+
+// the three DPP rank compares of a quad as one borrow chain starting from `start`: returns start - #{other lanes of my quad whose
+// key is smaller than mine}.  (The compiler builds the first compare as a 0 / -1 select and adds `start` afterwards.)
+__device__ __forceinline__ int quad_sub_rank(int key, int start) {
+  int r, t;
+  asm("s_nop 1\n\t"
+      "v_mov_b32_dpp %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cmp_lt_i32 vcc, %1, %2\n\t"
+      "v_subbrev_co_u32 %0, vcc, 0, %3, vcc\n\t"
+      "v_mov_b32_dpp %1, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cmp_lt_i32 vcc, %1, %2\n\t"
+      "v_subbrev_co_u32 %0, vcc, 0, %0, vcc\n\t"
+      "v_mov_b32_dpp %1, %2 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cmp_lt_i32 vcc, %1, %2\n\t"
+      "v_subbrev_co_u32 %0, vcc, 0, %0, vcc"
+      : "=&v"(r), "=&v"(t) : "v"(key), "v"(start) : "vcc");
+  return r;
+}
+
+// interval of a box given by its NEAR and FAR planes per axis (already chosen by the ray's direction signs), clipped to [0, tbest]:
+// the same values slab_interval() gets from min / max of the two plane distances, in 4 instead of 10 min / max instructions
+__device__ __forceinline__ void slab_near_far(f3 tn, f3 tf, float tbest, float& tmn, float& tmx) {
+  float a, b;
+  asm("v_max_f32 %0, 0, %1" : "=v"(a) : "v"(tn.z));
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmn) : "v"(tn.x), "v"(tn.y), "v"(a));
+  asm("v_min_f32 %0, %1, %2" : "=v"(b) : "v"(tf.z), "v"(tbest));
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tmx) : "v"(tf.x), "v"(tf.y), "v"(b));
+}
+
+// LDS by 32-bit address (the stack pointer is kept as an LDS byte address: no base + offset add per access)
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+__device__ __forceinline__ uint2 lds_load(uint32_t addr) { const u32x2 v = *reinterpret_cast<lds_u32x2*>(addr); return make_uint2(v.x, v.y); }
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ void lds_store(uint32_t addr, uint2 v) {       // two dwords from any two registers (ds_write2_b32): no pair to assemble
+  asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" :: "v"(addr), "v"(v.x), "v"(v.y) : "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
 // cooperative persistent trace kernel
 // ------------------------------------------------------------------------------------------------
 #ifndef ART_COOP_WAVES_PER_SIMD
-#define ART_COOP_WAVES_PER_SIMD 8   // <= 64 VGPRs: 8 waves per SIMD = 256 rays in flight per CU
+#define ART_COOP_WAVES_PER_SIMD 8   // <= 64 VGPRs: 8 waves per SIMD = 512 rays in flight per CU at 4 lanes per ray
 #endif
 
-// G = lanes per ray = children per node = triangles per leaf (8 or 4); 64 / G rays per wave.  OVF: the LDS stack holds fewer entries
+// G = lanes per ray = children per node = triangles per leaf (4 or 8); 64 / G rays per wave.  OVF: the LDS stack holds fewer entries
 // than the tree's worst-case bound, so a push is checked and a ray that would not fit is handed to k_trace_overflow.
+//
+// G = 4 walks the 64-byte quantised nodes (art_qnode.h): the kernel is bound by the bytes that miss in L2, and they halve.  A stack
+// entry is { child entry word, bits(tmin) }: the entry word is the node's byte offset (inner child) or 0x80000000 | triangle byte
+// offset | count (leaf), exactly as stored in the node, so a pop needs no decoding.  G = 8 walks the binary32 256-byte nodes; its
+// entry word is (ref << 4) | count.
 template <bool STATS, int G, bool OVF>
 __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(const DevScene* __restrict__ Sp, const TraceArgs A) {
   extern __shared__ uint2 lds_stack[];
-  char* const lds = reinterpret_cast<char*>(lds_stack);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int NG = 64 / G;                                   // ray groups per wave
   const int j = lane & (G - 1), g = lane / G;
   const int gbase = lane & ~(G - 1);
-  // Stack of one ray in LDS (bytes from sb):  0, 8: two guard entries | 16 + 8 i: entry i | 16 + 8 entries: sink of masked pushes.
-  // The stack pointer is kept as the LDS address `sa = sb + 8 sp`: the top entry is then always at sa + 8 (no clamping: an empty
-  // stack reads a guard), and a push goes to sa + 8 (nh - rank) + 8.
-  const uint32_t sb = (uint32_t)(wave * NG + g) * (uint32_t)(A.stack_entries + 3) * 8u;
+  // Stack of one ray in LDS (bytes from sb):  0, 8: guard entries | 16 + 8 i: entry i | 16 + 8 entries: sink of masked pushes.
+  // The stack pointer is the LDS address `sa = sb + 8 sp`: the top entry is at sa + 8 (an empty stack reads a guard, no clamping),
+  // and a push goes to sa + 8 (nh - rank) + 8.
+  const uint32_t lds0 = (uint32_t)(uintptr_t)lds_stack;
+  const uint32_t sb = lds0 + (uint32_t)(wave * NG + g) * (uint32_t)(A.stack_entries + 3) * 8u;
   const uint32_t sink = sb + 16u + (uint32_t)A.stack_entries * 8u;
   const uint32_t slimit = sb + (uint32_t)A.stack_entries * 8u;      // sa + 8 nh > slimit: the push does not fit
-  const uint64_t leaders = (G == 8) ? 0x0101010101010101ull : 0x1111111111111111ull;
+  const mask_t leaders = (G == 8) ? 0x0101010101010101ull : 0x1111111111111111ull;
   // kernel-argument bases stay in SGPRs; per-lane addressing is a 32-bit byte offset (scalar base + vector offset loads).
-  // art_upload_scene guarantees n_nodes * 256 and n_tris * 48 fit in 32 bits.
-  const char* const nodes_b = reinterpret_cast<const char*>(A.nodes);
+  // art_upload_scene guarantees that node and triangle byte offsets fit (31 bits for G = 4, 32 for G = 8).
+  const char* const nodes_b = reinterpret_cast<const char*>(G == 4 ? (const void*)A.qnodes : (const void*)A.nodes);
   const char* const tris_b = reinterpret_cast<const char*>(A.tris);
+  const uint32_t jrec = (G == 4) ? 16u + 12u * (uint32_t)j : 16u * (uint32_t)j;     // this lane's child record inside a node
+  const uint32_t jtri = (uint32_t)j * (uint32_t)kTriBytes;
   const int n_queue = *A.queue_count;
 
   int chunk_pos = 0, chunk_end = 0;   // wave-uniform
@@ -130,11 +196,12 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
   // the same part of the tree then share an L2.  A wave whose segment is drained helps with the next one.
   const int n_seg = A.segments;
   int seg = (int)blockIdx.x & (n_seg - 1), segs_left = n_seg;   // wave-uniform
-  bool has_ray = false;               // group-uniform from here on
+  mask_t has_ray = 0, pend_valid = 0;                 // group-uniform bits: the group holds a ray / a popped entry waiting for its phase
   uint32_t sa = sb; int ray = 0;
   f3 o = mk3(0, 0, 0), d = o, inv = o, noi = o;
   float best_t = 0.0f; uint32_t best_key = KEY_MISS;
-  uint32_t pend = 0; bool pend_valid = false;        // popped entry waiting for its phase
+  uint32_t pend = 0;                                  // the popped entry word
+  uint32_t sel_near = 0, sel_far = 0;                 // G = 4: v_perm selectors that pick each axis' near / far plane byte by the ray's direction sign
   uint32_t held_key = KEY_MISS; float held_u = 0.0f, held_v = 0.0f;   // lane-local: barycentrics of the hit this lane found
   float shm = -1.0f; bool far_found = false;          // shadow-ray visibility rule (art_isect.h shadow_rule)
   uint64_t st_box = 0, st_tri = 0, st_node = 0, st_leaf = 0, st_it_node = 0, st_it_leaf = 0, st_it_all = 0;
@@ -142,9 +209,8 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
   for (;;) {
     if (STATS) st_it_all += (lane == 0);
     // ---------------- refill idle groups from the wave's chunk of the live-ray queue
-    bool need = !has_ray;
     while (!exhausted) {
-      const uint64_t need_mask = ballot64(need) & leaders;
+      const mask_t need_mask = ~has_ray & leaders;
       if (need_mask == 0) break;
       if (chunk_pos == chunk_end) {
         const int seg_lo = (int)(((int64_t)n_queue * seg) / n_seg), seg_hi = (int)(((int64_t)n_queue * (seg + 1)) / n_seg);
@@ -162,101 +228,122 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       const int avail = chunk_end - chunk_pos;
       const int n_need = __popcll(need_mask);
       const int my_rank = __popcll(need_mask & ((1ull << gbase) - 1ull));
-      const bool got = need && (my_rank < avail);
+      const bool got = !lane_of(has_ray) && (my_rank < avail);
       if (got) {
         // the analytic primitives were intersected by k_analytic: (hit_t, hit_key) is the starting bound
         ray = A.queue[chunk_pos + my_rank];
         o = mk3(A.ray_ox[ray], A.ray_oy[ray], A.ray_oz[ray]);
         d = mk3(A.ray_dx[ray], A.ray_dy[ray], A.ray_dz[ray]);
         slab_setup(o, d, inv, noi);
+        if (G == 4) {   // child bytes: c0 = { lo.x lo.y lo.z hi.x } (selector values 0..3), c1 = { hi.y hi.z - - } (4, 5); 0x0c = constant 0
+          const uint32_t sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+          sel_near = (sx ? 3u : 0u) | ((sy ? 4u : 1u) << 8) | ((sz ? 5u : 2u) << 16) | 0x0c000000u;
+          sel_far = (sx ? 0u : 3u) | ((sy ? 1u : 4u) << 8) | ((sz ? 2u : 5u) << 16) | 0x0c000000u;
+        }
         best_t = A.hit_t[ray]; best_key = A.hit_key[ray];
         shm = (A.sh_min != nullptr && ray >= A.shadow_begin) ? A.sh_min[ray - A.shadow_begin] : -1.0f;
         far_found = (shm >= 0.0f) && (best_key != KEY_MISS);     // a queued shadow ray with a hit has a far hit (near ones are not queued)
         best_t = far_found ? next_up_pos(shm) : best_t;
         best_key = far_found ? KEY_MISS : best_key;
         held_key = KEY_MISS;
-        sa = sb; pend = 0u; pend_valid = true;                    // entry 0 = root node
-        has_ray = true; need = false;
+        sa = sb; pend = 0u;                                       // entry word 0 = root node (both encodings)
       }
+      const mask_t got_mask = __builtin_amdgcn_ballot_w64(got);
+      has_ray |= got_mask; pend_valid |= got_mask;
       chunk_pos += min(avail, n_need);
     }
-    if (ballot64(has_ray) == 0) break;
+    if (has_ray == 0) break;
 
-    // The step code below is written branch-free on purpose: on CDNA a divergent `if` costs three scalar
-    // instructions (save/restore exec + skip branch) and the first version of this kernel was SALU-bound.  Inactive
-    // lanes compute on clamped operands and are masked by selects; LDS pushes of non-hit lanes go to the group's
-    // spare (padding) slot.  The kernel is now VALU-issue-bound, so bookkeeping (retire / refill / leaf vote) is kept
-    // out of the inner node loop.
+    // The step code below is branch-free on purpose: on CDNA a divergent `if` costs three scalar instructions (save/restore exec +
+    // skip branch).  Inactive lanes compute on clamped operands and are masked by selects; LDS pushes of non-hit lanes go to the
+    // group's sink slot.  Bookkeeping (retire / refill / leaf vote) is kept out of the inner node loop.
 
     // ---------------- inner loop: pop + node phase, as long as enough of the wave's groups have a node to expand
-    bool want_leaf = false;
+    mask_t want_leaf = 0;
     for (;;) {
       // next stack entry; an entry culled by the current hit is dropped (its group then sits this step out).  Popping two entries
       // per iteration to skip a culled one costs 12 more instructions in every iteration and saves 0.6 % of the steps: slower.
       {
-        const bool need = has_ray && !pend_valid;
-        const uint2 e1 = *reinterpret_cast<const uint2*>(lds + sa + 8u);
-        const bool v1 = need && sa > sb;
-        const bool ok1 = v1 && !(__builtin_bit_cast(float, e1.y) > best_t);
-        pend = ok1 ? e1.x : pend;
-        pend_valid = pend_valid || ok1;
-        sa = v1 ? sa - 8u : sa;
+        const uint2 e1 = lds_load(sa + 8u);
+        const mask_t v1 = has_ray & ~pend_valid & vcmp(sa > sb);
+        const mask_t ok1 = v1 & vcmp(!(__builtin_bit_cast(float, e1.y) > best_t));
+        pend = sel(ok1, e1.x, pend);
+        sa = sel(v1, sa - 8u, sa);
+        pend_valid |= ok1;
       }
-      const int cnt = (int)(pend & 15u);
-      const bool active = has_ray && pend_valid;
-      want_leaf = active && cnt != 0;
-      const bool want_node = active && cnt == 0;
-      const uint64_t node_mask = ballot64(want_node);
+      const mask_t active = has_ray & pend_valid;
+      const mask_t is_leaf = (G == 4) ? vcmp((int)pend < 0) : vcmp((pend & 15u) != 0u);
+      want_leaf = active & is_leaf;
+      const mask_t want_node = active & ~is_leaf;
       // leave when fewer than node_min groups still expand nodes (the others wait on a leaf, are finished, or idle)
-      if (__popcll(node_mask) < 8 * A.node_min) {
-        if (node_mask == 0 || ballot64(want_leaf || (has_ray && !active && sa == sb)) != 0 || !exhausted) break;
+      if (__popcll(want_node) < 8 * A.node_min) {
+        if (want_node == 0 || !exhausted || (want_leaf | (has_ray & ~active & vcmp(sa == sb))) != 0) break;
       }
-      // ---- node phase: lane j slab-tests child j; groups not taking part read the root node and discard the result
-      const int ref = (int)(pend >> 4);
-      const uint32_t noff = (uint32_t)(want_node ? ref : 0) * (uint32_t)(G * 32) + (uint32_t)j * 16u;
-      const float4 r0 = *reinterpret_cast<const float4*>(nodes_b + noff);
-      const float4 r1 = *reinterpret_cast<const float4*>(nodes_b + noff + (uint32_t)(G * 16));
-      const int cref = __builtin_bit_cast(int, r0.w), ccnt = __builtin_bit_cast(int, r1.w);
-      float tmn, tmx;
-      slab_interval(mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), inv, noi, best_t, tmn, tmx);
-      const bool hit = want_node && (cref >= 0) && (tmn <= tmx);
-      const int key = hit ? (int)((__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j) : 0x7fffffff;
-      const int rank = group_rank_g<G>(key);
-      const int nh = group_count_g<G>(hit, gbase);
+      // ---- node phase: lane j tests child j; groups not taking part read the root node and discard the result
+      float tmn, tmx; uint32_t entry; mask_t valid;
+      if (G == 4) {
+        const uint32_t noff = sel(want_node, pend, 0u);
+        const float4 h = *reinterpret_cast<const float4*>(nodes_b + noff);                 // origin, scale: same address in the 4 lanes
+        const uint32_t* cp = reinterpret_cast<const uint32_t*>(nodes_b + (noff + jrec));
+        const uint32_t c0 = cp[0], c1 = cp[1]; entry = cp[2];
+        // near / far plane bytes by direction sign (one v_perm each), dequantised (one fma per plane: the very binary32 boxes of the
+        // exported tree), then the slab distances.  An empty slot holds lo = 255, hi = 0 on every axis: its near plane lies behind
+        // its far plane for every ray, so it can never be hit and needs no validity test.
+        const uint32_t nb = __builtin_amdgcn_perm(c1, c0, sel_near), fb = __builtin_amdgcn_perm(c1, c0, sel_far);
+        const f3 pn = mk3(__builtin_fmaf((float)(nb & 255u), h.w, h.x), __builtin_fmaf((float)((nb >> 8) & 255u), h.w, h.y), __builtin_fmaf((float)((nb >> 16) & 255u), h.w, h.z));
+        const f3 pf = mk3(__builtin_fmaf((float)(fb & 255u), h.w, h.x), __builtin_fmaf((float)((fb >> 8) & 255u), h.w, h.y), __builtin_fmaf((float)((fb >> 16) & 255u), h.w, h.z));
+        slab_near_far(mk3(__builtin_fmaf(pn.x, inv.x, noi.x), __builtin_fmaf(pn.y, inv.y, noi.y), __builtin_fmaf(pn.z, inv.z, noi.z)),
+                      mk3(__builtin_fmaf(pf.x, inv.x, noi.x), __builtin_fmaf(pf.y, inv.y, noi.y), __builtin_fmaf(pf.z, inv.z, noi.z)), best_t, tmn, tmx);
+        valid = ~0ull;
+        if (STATS) valid = vcmp(entry != kQEntryEmpty);
+      } else {
+        const uint32_t noff = sel(want_node, pend >> 4, 0u) * (uint32_t)(G * 32) + jrec;
+        const float4 r0 = *reinterpret_cast<const float4*>(nodes_b + noff);
+        const float4 r1 = *reinterpret_cast<const float4*>(nodes_b + noff + (uint32_t)(G * 16));
+        const int cref = __builtin_bit_cast(int, r0.w);
+        entry = (uint32_t)((cref << 4) | __builtin_bit_cast(int, r1.w));
+        slab_interval(mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), inv, noi, best_t, tmn, tmx);
+        valid = vcmp(cref >= 0);
+      }
+      const mask_t hit = (G == 4 && !STATS) ? (want_node & vcmp(tmn <= tmx)) : (want_node & valid & vcmp(tmn <= tmx));
+      const int key = (int)sel(hit, (__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j, 0x7fffffffu);
+      const int nh = group_sum_g<G>((int)sel(hit, 1u, 0u));
+      const int nh_minus_rank = (G == 4) ? quad_sub_rank(key, nh) : nh - group_rank_g<G>(key);
       const uint32_t top = sa + (uint32_t)nh * 8u;
-      const bool ovf = OVF && want_node && (top > slimit);                  // the ray moves to k_trace_overflow
-      const uint32_t dst_hit = sa + (uint32_t)(nh - rank) * 8u + 8u;
-      const uint32_t dst = (hit && !ovf) ? dst_hit : sink;
-      *reinterpret_cast<uint2*>(lds + dst) = make_uint2((uint32_t)((cref << 4) | ccnt), __builtin_bit_cast(uint32_t, tmn));
-      sa = ovf ? sb : top;
+      const mask_t ovf = OVF ? (want_node & vcmp(top > slimit)) : 0;        // the ray moves to k_trace_overflow
+      const uint32_t dst_hit = (sa + 8u) + (uint32_t)nh_minus_rank * 8u;
+      lds_store(sel(hit & ~ovf, dst_hit, sink), make_uint2(entry, __builtin_bit_cast(uint32_t, tmn)));
+      sa = OVF ? sel(ovf, sb, top) : top;
       if (OVF) {
-        if (ballot64(ovf) != 0) {
-          if (ovf && j == 0) A.ovf_queue[atomicAdd(A.ovf_count, 1)] = ray;
-          has_ray = has_ray && !ovf;
+        if (ovf != 0) {
+          if (lane_of(ovf) && j == 0) A.ovf_queue[atomicAdd(A.ovf_count, 1)] = ray;
+          has_ray &= ~ovf;
         }
       }
-      pend_valid = pend_valid && !want_node;
-      if (STATS) { st_box += (want_node && cref >= 0); st_node += (want_node && j == 0); st_it_node += (lane == 0); }
+      pend_valid &= ~want_node;
+      if (STATS) { st_box += lane_of(want_node & valid); st_node += (lane_of(want_node) && j == 0); st_it_node += (lane == 0); }
       wave_lds_sync();
     }
 
     // ---------------- retire rays whose stack ran dry
-    const bool done = has_ray && !pend_valid && sa == sb;
-    if (ballot64(done) != 0) {
-      if (done) {
+    const mask_t done = has_ray & ~pend_valid & vcmp(sa == sb);
+    if (done != 0) {
+      if (lane_of(done)) {
         const bool keep_far = far_found && best_key == KEY_MISS;      // shadow ray whose far hit is already stored
         if (j == 0 && !keep_far) { A.hit_t[ray] = best_t; A.hit_key[ray] = best_key; }
         // barycentrics: only a BVH triangle found by this kernel needs storing (analytic / brute-force hits were stored by k_analytic)
         if (shm < 0.0f && best_key != KEY_MISS && held_key == best_key) { A.hit_u[ray] = held_u; A.hit_v[ray] = held_v; }
-        has_ray = false;
       }
+      has_ray &= ~done;
     }
 
     // ---------------- leaf phase for every group holding a leaf: lane j < cnt tests triangle j; others test triangle 0, masked
-    if (ballot64(want_leaf) != 0) {
-      const int cnt = (int)(pend & 15u), ref = (int)(pend >> 4);
-      const bool tri_lane = want_leaf && (j < cnt);
-      const uint32_t toff = (uint32_t)(tri_lane ? (ref + j) : 0) * (uint32_t)(kTriFloats * 4);
+    if (want_leaf != 0) {
+      const bool wl = lane_of(want_leaf);
+      const int cnt = (int)(pend & 15u);
+      const bool tri_lane = wl && (j < cnt);
+      const uint32_t tbase = (G == 4) ? (pend & 0x7ffffff0u) : (pend >> 4) * (uint32_t)kTriBytes;
+      const uint32_t toff = tri_lane ? (tbase + jtri) : 0u;
       const float4 q0 = *reinterpret_cast<const float4*>(tris_b + toff);
       const float4 q1 = *reinterpret_cast<const float4*>(tris_b + toff + 16u);
       const float4 q2 = *reinterpret_cast<const float4*>(tris_b + toff + 32u);
@@ -272,7 +359,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       // cand_wins for t > 0:  (t, key) < (best_t, best_key), where an equal t never displaces the initial bound
       const uint32_t bt = (best_t == 0.0f) ? 0u : __builtin_bit_cast(uint32_t, best_t);
       const uint64_t cur = pack_tk(bt, best_key == KEY_MISS ? 0u : best_key);
-      const bool accept = want_leaf && ((uint32_t)win != KEY_MISS) && (win < cur);
+      const bool accept = wl && ((uint32_t)win != KEY_MISS) && (win < cur);
       const float win_t = __builtin_bit_cast(float, (uint32_t)(win >> 32));
       best_t = accept ? win_t : best_t;
       best_key = accept ? (uint32_t)win : best_key;
@@ -288,8 +375,8 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       }
       const bool mine = accept && valid && (key == (uint32_t)win);
       held_key = mine ? key : held_key; held_u = mine ? uu : held_u; held_v = mine ? vv : held_v;
-      pend_valid = pend_valid && !want_leaf;
-      if (STATS) { st_tri += tri_lane; st_leaf += (want_leaf && j == 0); st_it_leaf += (lane == 0); }
+      pend_valid &= ~want_leaf;
+      if (STATS) { st_tri += tri_lane; st_leaf += (wl && j == 0); st_it_leaf += (lane == 0); }
     }
   }
   if (STATS) {

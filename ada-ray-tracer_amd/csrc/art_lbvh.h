@@ -7,7 +7,8 @@
 namespace art {
 
 struct GpuBvh {
-  float* nodes = nullptr;       // device, kNodeFloats per node (capacity n/2+2 nodes), owned by the caller after success
+  float* nodes = nullptr;       // device, kNodeFloats per node (capacity n nodes), owned by the caller after success
+  void* qnodes = nullptr;       // device, width 4: 64-byte quantised nodes (art_qnode.h), owned by the caller after success
   float* tris = nullptr;        // device, kTriFloats per triangle, Morton order
   int32_t n_nodes = 0, n_tris = 0, max_stack = 1, levels = 0;
   float build_ms = 0.0f;        // HIP events around the whole build

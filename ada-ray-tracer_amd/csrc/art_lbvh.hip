@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "art_lbvh.h"
+#include "art_qnode.h"
 
 namespace art {
 namespace {
@@ -316,6 +317,18 @@ __global__ __launch_bounds__(128) void k_collapse(Lbvh T, const Item* __restrict
   }
 }
 
+// width 4: the 64-byte quantised form of every node for k_trace_coop; the binary32 packets become the dequantised tree (art_qnode.h)
+__global__ __launch_bounds__(256) void k_quantise_nodes(float* __restrict__ nodes, int n_nodes, QNode* __restrict__ qnodes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  float nd[32];
+  for (int k = 0; k < 32; ++k) nd[k] = nodes[(size_t)i * 32 + k];
+  QNode q;
+  quantise_node(nd, q);
+  for (int k = 0; k < 32; ++k) nodes[(size_t)i * 32 + k] = nd[k];
+  qnodes[i] = q;
+}
+
 struct Scratch {
   std::vector<void*> ptrs;
   ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
@@ -426,6 +439,10 @@ bool build_bvh8_gpu(const float* d_tri9, int n, const BvhBuildParams& prm, hipSt
     LB_TRY(hipMemsetAsync(counters, 0, sizeof(int), st));
     std::swap(in, nx);
     if (++levels > 64) { err = "internal: LBVH collapse did not terminate"; return false; }
+  }
+  if (prm.width == 4 && prm.quantise) {
+    LB_TRY(hipMalloc(&out.qnodes, (size_t)out.n_nodes * kQNodeBytes));
+    hipLaunchKernelGGL(k_quantise_nodes, dim3((out.n_nodes + 255) / 256), dim3(256), 0, st, out.nodes, out.n_nodes, (QNode*)out.qnodes);
   }
   LB_TRY(hipEventRecord(e1, st));
   LB_TRY(hipEventSynchronize(e1));

@@ -21,6 +21,7 @@ extern "C" void hs_set_bvh_param(const char* name, double v) {
   else if (n == "spatial_bins") g_bp.spatial_bins = (int)v;
   else if (n == "max_leaf") g_bp.max_leaf = (int)v;
   else if (n == "width") g_bp.width = (int)v;
+  else if (n == "quantise") g_bp.quantise = (int)v;
   else if (n == "node_cost") g_bp.node_cost = (float)v;
   else if (n == "leaf_base") g_bp.leaf_base = (float)v;
   else if (n == "tri_cost") g_bp.tri_cost = (float)v;

@@ -12,7 +12,7 @@ import picture_pin
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("size,vthreads", [(1024, 32), (512, 64)])
+@pytest.mark.parametrize("size,vthreads", [(1024, 256), (512, 64)])
 def test_product_reproduces_the_reference_picture(art, backend, size, vthreads):
     cs = orc.CornellScene()                       # only used to read pyramid2.vsgf and the scene constants into an ArtSceneDesc
     sd = conv.desc_from_oracle(art, cs)
