@@ -95,7 +95,7 @@ class HitCpp(C.Structure):
 
 
 EXPORTED_SYMBOLS = [
-    "art_init", "art_set_stream", "art_upload_scene", "art_resize", "art_set_shard", "art_render_pass",
+    "art_init", "art_init_devices", "art_device_count", "art_reduce", "art_set_stream", "art_upload_scene", "art_resize", "art_set_shard", "art_render_pass",
     "art_debug_hit_pass", "art_bind_accum", "art_accum_device", "art_download", "art_synchronize", "art_trace_rays",
     "art_export_bvh", "art_get_stats", "art_set_option", "art_last_error", "art_shutdown",
     "gcore_init_and_clear", "gcore_destroy", "gcore_add_mesh_3f", "gcore_instance_meshes", "gcore_commit_scene",
@@ -125,6 +125,7 @@ def load_library():
     L.art_last_error.restype = C.c_char_p
     L.art_accum_device.restype = C.c_void_p
     L.art_set_stream.argtypes = [C.c_void_p]
+    L.art_init_devices.argtypes = [C.c_int32, i32p]
     L.art_upload_scene.argtypes = [C.POINTER(ArtSceneDesc)]
     L.art_resize.argtypes = [C.c_int32, C.c_int32]
     L.art_set_shard.argtypes = [C.c_int32, C.c_int32, C.c_int32]
@@ -217,9 +218,20 @@ class SceneDesc:
 class Backend:
     """One process-wide backend instance (the C library is a singleton, like g_data / ray_tracer.ads globals)."""
 
-    def __init__(self, device=-1):
+    def __init__(self, device=-1, devices=None):
+        """device: one GPU (art_init).  devices: a list of ordinals, or a count n for 0..n-1 -> one process drives them all
+        (art_init_devices): pixel tiles sharded inside the library, RCCL reduce to the first device."""
         self.lib = load_library()
-        _check(self.lib.art_init(device))
+        if devices is None:
+            _check(self.lib.art_init(device))
+        elif isinstance(devices, int):
+            _check(self.lib.art_init_devices(devices, None))
+        else:
+            arr = (C.c_int32 * len(devices))(*devices)
+            _check(self.lib.art_init_devices(len(devices), arr))
+
+    def reduce(self):
+        _check(self.lib.art_reduce())
 
     def set_stream(self, hip_stream):
         _check(self.lib.art_set_stream(hip_stream))

@@ -10,6 +10,7 @@
 // There is no CPU fallback: every entry point that needs the GPU fails with art_last_error() set when
 // HIP reports no usable device.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -25,8 +26,13 @@
 
 namespace art {
 
-Ctx g_ctx;
+Ctx g_devs[kMaxDevices];
+int g_ndev = 1;
+Ctx* g_cur = &g_devs[0];
 std::mutex g_mu;
+static ncclComm_t g_comms[kMaxDevices];
+static bool g_comms_ready = false;     // distinct GPUs: the framebuffer reduce goes through RCCL
+static bool g_same_gpu = false;        // rehearsal: several contexts on ONE physical GPU, the reduce is a local sum (no collective possible)
 static thread_local std::string t_err;
 static std::string g_err;
 
@@ -37,6 +43,15 @@ int fail(const std::string& msg) { g_err = msg; return 1; }
     hipError_t _e = (expr);                                                                 \
     if (_e != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(_e));   \
   } while (0)
+
+// make device k's context the current one (g_ctx) and its GPU the current HIP device
+static int use_dev(int k) {
+  g_cur = &g_devs[k];
+  if (g_cur->device >= 0) HIP_TRY(hipSetDevice(g_cur->device));
+  return 0;
+}
+// multi-device loops leave device 0 current on every exit path
+struct Dev0Guard { ~Dev0Guard() { g_cur = &g_devs[0]; if (g_devs[0].device >= 0) (void)hipSetDevice(g_devs[0].device); } };
 
 template <typename T>
 static int upload(DevBuf& b, const std::vector<T>& v) {
@@ -99,40 +114,50 @@ static int upload_scene_arrays(HostScene& hs) {
 }
 
 int upload_scene(const ArtSceneDesc* d) {
-  Ctx& c = g_ctx;
   if (!d) return fail("art_upload_scene: null scene");
   std::string err;
   HostScene hs;
-  if (!flatten_scene(*d, c.bvh_params, hs, err)) return fail(err);      // validation + BVH build need no GPU
-  if (ensure_device()) return 1;
-  if (!hs.deferred_tri9.empty()) {            // option bvh_builder = 1: LBVH built in HBM
-    DevBuf tri9;
-    if (upload(tri9, hs.deferred_tri9)) return 1;
-    GpuBvh g;
-    const bool ok = build_bvh8_gpu((const float*)tri9.p, (int)(hs.deferred_tri9.size() / 9), c.bvh_params, c.stream, g, err);
-    tri9.release();
-    if (!ok) { if (g.nodes) (void)hipFree(g.nodes); if (g.tris) (void)hipFree(g.tris); if (g.qnodes) (void)hipFree(g.qnodes); return fail("GPU BVH build: " + err); }
-    c.b_nodes.release(); c.b_tris.release(); c.b_qnodes.release();
-    c.b_qnodes.p = g.qnodes; c.b_qnodes.bytes = g.qnodes ? (size_t)g.n_nodes * kQNodeBytes : 0;
-    c.b_nodes.p = g.nodes; c.b_nodes.bytes = (size_t)g.n_nodes * node_floats(c.bvh_params.width) * 4;
-    hs.bvh.width = c.bvh_params.width;
-    c.b_tris.p = g.tris; c.b_tris.bytes = (size_t)g.n_tris * kTriFloats * 4;
-    hs.bvh.n_nodes = g.n_nodes; hs.bvh.n_tris = g.n_tris; hs.bvh.max_stack = g.max_stack;
-    hs.hdr.n_nodes = g.n_nodes; hs.hdr.n_tris = g.n_tris;
-    hs.bvh_build_ms = g.build_ms; hs.gpu_built = true;
-    std::vector<float>().swap(hs.deferred_tri9);
+  if (!flatten_scene(*d, g_devs[0].bvh_params, hs, err)) return fail(err);      // validation + host BVH build: once, no GPU needed
+  const std::vector<float> tri9 = std::move(hs.deferred_tri9);                    // option bvh_builder >= 1: every device builds its own tree
+  hs.deferred_tri9.clear();
+  Dev0Guard guard;
+  for (int k = 0; k < g_ndev; ++k) {                                              // scene + BVH replicated on every GPU
+    if (use_dev(k)) return 1;
+    Ctx& c = g_ctx;
+    c.bvh_params = g_devs[0].bvh_params;
+    if (ensure_device()) return 1;
+    int dev_stack = hs.bvh.max_stack;
+    if (!tri9.empty()) {
+      DevBuf t9;
+      if (upload(t9, tri9)) return 1;
+      GpuBvh g;
+      const bool ok = build_bvh8_gpu((const float*)t9.p, (int)(tri9.size() / 9), c.bvh_params, c.stream, g, err);
+      t9.release();
+      if (!ok) { if (g.nodes) (void)hipFree(g.nodes); if (g.tris) (void)hipFree(g.tris); if (g.qnodes) (void)hipFree(g.qnodes); return fail("GPU BVH build: " + err); }
+      c.b_nodes.release(); c.b_tris.release(); c.b_qnodes.release();
+      c.b_qnodes.p = g.qnodes; c.b_qnodes.bytes = g.qnodes ? (size_t)g.n_nodes * kQNodeBytes : 0;
+      c.b_nodes.p = g.nodes; c.b_nodes.bytes = (size_t)g.n_nodes * node_floats(c.bvh_params.width) * 4;
+      c.b_tris.p = g.tris; c.b_tris.bytes = (size_t)g.n_tris * kTriFloats * 4;
+      dev_stack = g.max_stack;
+      if (k == 0) {
+        hs.bvh.width = c.bvh_params.width;
+        hs.bvh.n_nodes = g.n_nodes; hs.bvh.n_tris = g.n_tris; hs.bvh.max_stack = g.max_stack;
+        hs.bvh_build_ms = g.build_ms; hs.gpu_built = true;
+      }
+      hs.hdr.n_nodes = g.n_nodes; hs.hdr.n_tris = g.n_tris;                       // node numbering may differ between devices (atomics), sizes do not
+    }
+    // the trace kernel addresses nodes and triangles with 32-bit byte offsets; the 4-wide entry word keeps bit 31 for the leaf flag
+    const uint64_t off_limit = (hs.hdr.node_width == 4) ? (1ull << 31) : (1ull << 32);
+    if ((uint64_t)hs.hdr.n_nodes * node_floats(hs.hdr.node_width) * 4 >= (1ull << 32) || (uint64_t)hs.hdr.n_tris * kTriFloats * 4 >= off_limit)
+      return fail("mesh too large: the trace kernel addresses nodes and triangles with 32-bit byte offsets (max ~44M triangles at width 4, ~89M at width 8)");
+    if (hs.hdr.node_width == 4 && hs.hdr.n_nodes > 0 && hs.gpu_built && !c.b_qnodes.p) return fail("internal: GPU build returned no quantised nodes");
+    if (dev_stack > kStackEntries) return fail("BVH traversal stack bound " + std::to_string(dev_stack) + " exceeds " + std::to_string(kStackEntries));
+    if (upload_scene_arrays(hs)) return 1;
+    c.bvh_stack_bound = std::max(8, dev_stack);
+    c.blocks_per_cu = 0;   // re-query occupancy
+    c.scene_ready = true;
   }
-  // the trace kernel addresses nodes and triangles with 32-bit byte offsets; the 4-wide entry word keeps bit 31 for the leaf flag
-  const uint64_t off_limit = (hs.hdr.node_width == 4) ? (1ull << 31) : (1ull << 32);
-  if ((uint64_t)hs.bvh.n_nodes * node_floats(hs.hdr.node_width) * 4 >= (1ull << 32) || (uint64_t)hs.bvh.n_tris * kTriFloats * 4 >= off_limit)
-    return fail("mesh too large: the trace kernel addresses nodes and triangles with 32-bit byte offsets (max ~44M triangles at width 4, ~89M at width 8)");
-  if (hs.hdr.node_width == 4 && hs.bvh.n_nodes > 0 && !c.b_qnodes.p && hs.gpu_built) return fail("internal: GPU build returned no quantised nodes");
-  if (hs.bvh.max_stack > kStackEntries) return fail("BVH traversal stack bound " + std::to_string(hs.bvh.max_stack) + " exceeds " + std::to_string(kStackEntries));
-  if (upload_scene_arrays(hs)) return 1;
-  c.bvh_stack_bound = std::max(8, hs.bvh.max_stack);
-  c.blocks_per_cu = 0;   // re-query occupancy
-  c.host_scene = std::move(hs);
-  c.scene_ready = true;
+  g_devs[0].host_scene = std::move(hs);
   return 0;
 }
 
@@ -144,9 +169,15 @@ static int build_shard() {
   return upload(c.b_pixmap, pm);
 }
 
+static int resize_one(int w, int h);
 int resize(int w, int h) {
-  Ctx& c = g_ctx;
   if (w <= 0 || h <= 0 || (int64_t)w * h > (1ll << 30)) return fail("art_resize: bad size");
+  Dev0Guard guard;
+  for (int k = 0; k < g_ndev; ++k) { if (use_dev(k) || resize_one(w, h)) return 1; }
+  return 0;
+}
+static int resize_one(int w, int h) {
+  Ctx& c = g_ctx;
   if (ensure_device()) return 1;
   c.width = w; c.height = h;
   const size_t n = (size_t)w * h;
@@ -161,6 +192,7 @@ int resize(int w, int h) {
 }
 
 static float* accum_ptr() { return g_ctx.ext_accum ? g_ctx.ext_accum : (float*)g_ctx.b_accum.p; }
+static int download_from(const float* acc_dev, float* accum_host, uint32_t* screen_host, int layout, int spp);
 
 // path arrays for P slots and `depth` fold levels, carved out of one allocation
 static size_t path_floats(size_t P, int depth) { return (14 + 8 + 3 + 3 + 6 * (size_t)depth + 3 + 3) * P; }
@@ -278,7 +310,22 @@ static void make_frame(const ArtPassParams* p, DevFrame& f) {
   f.cam_z = -(float)c.width / safe_tan(fov / 2.0f);            // ray_tracer.adb:67
 }
 
+static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout);
+// One Render_Pass on every device of the process: each GPU renders the pixel tiles it owns into its own accum buffer, asynchronously on
+// its own stream (the host only enqueues: ~100 calls per device and pass).  The buffers meet in reduce_accum() when somebody asks
+// for the image.
 int render_pass_device(const ArtPassParams* p, int32_t* spp_inout) {
+  Dev0Guard guard;
+  int32_t spp_out = spp_inout ? *spp_inout : 0;
+  for (int k = 0; k < g_ndev; ++k) {
+    int32_t spp_k = spp_inout ? *spp_inout : 0;
+    if (use_dev(k) || render_pass_one(p, spp_inout ? &spp_k : nullptr)) return 1;
+    if (k == 0) spp_out = spp_k;
+  }
+  if (spp_inout) *spp_inout = spp_out;
+  return 0;
+}
+static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
   Ctx& c = g_ctx;
   if (check_pass(p)) return 1;
   if (p->render_type == ART_RT_DEBUG || p->render_type == ART_RT_WHITTED) return fail("debug render types go through art_debug_hit_pass");
@@ -289,15 +336,31 @@ int render_pass_device(const ArtPassParams* p, int32_t* spp_inout) {
   const int S = p->vthreads * per;           // samples this pass
   const int npix = c.npix_local;
   DevFrame F; make_frame(p, F);
-  hipEvent_t p0, p1;
-  HIP_TRY(hipEventCreate(&p0)); HIP_TRY(hipEventCreate(&p1));
-  HIP_TRY(hipEventRecord(p0, c.stream));
+  // batch = pixel chunk x sample chunk with pc * sc <= batch_paths.  The result does not depend on the batching (the RNG is keyed by
+  // pixel, sample and bounce), so when HBM is short (a shared GPU, a caller holding memory) the batch is halved until it fits.
+  int pc = 0, sc = 0;
   if (npix > 0) {
-    // batch = pixel chunk x sample chunk with pc * sc <= batch_paths
-    const int64_t cap = std::max<int64_t>(c.batch_paths, per);
-    int pc = (int)std::min<int64_t>(npix, std::max<int64_t>(1, cap / per));
-    int sc = (int)std::min<int64_t>(S, std::max<int64_t>(per, (cap / pc) / per * per));
-    if (ensure_paths((size_t)pc * sc, p->max_depth)) return 1;
+    int64_t cap = std::max<int64_t>(c.batch_paths, per);
+    for (;;) {
+      pc = (int)std::min<int64_t>(npix, std::max<int64_t>(1, cap / per));
+      sc = (int)std::min<int64_t>(S, std::max<int64_t>(per, (cap / pc) / per * per));
+      if (g_ctx.b_paths.p && g_ctx.b_paths.bytes >= path_floats((size_t)pc * sc, p->max_depth) * 4 + 256) break;
+      g_ctx.b_paths.release();
+      const hipError_t e = hipMalloc(&g_ctx.b_paths.p, path_floats((size_t)pc * sc, p->max_depth) * 4 + 256);
+      if (e == hipSuccess) { g_ctx.b_paths.bytes = path_floats((size_t)pc * sc, p->max_depth) * 4 + 256; break; }
+      g_ctx.b_paths.p = nullptr;
+      (void)hipGetLastError();
+      if (e != hipErrorOutOfMemory || cap <= 65536) return fail(std::string("path buffers: ") + hipGetErrorString(e));
+      cap /= 2;
+    }
+  }
+  struct PassEvents {             // destroyed on every error return; handed to the context on success
+    hipEvent_t a = nullptr, b = nullptr;
+    ~PassEvents() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } ev;
+  HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b));
+  HIP_TRY(hipEventRecord(ev.a, c.stream));
+  if (npix > 0) {
     for (int px0 = 0; px0 < npix; px0 += pc) {
       const int pn = std::min(pc, npix - px0);
       for (int s0 = 0; s0 < S; s0 += sc) {
@@ -318,7 +381,8 @@ int render_pass_device(const ArtPassParams* p, int32_t* spp_inout) {
       }
     }
   }
-  HIP_TRY(hipEventRecord(p1, c.stream));
+  HIP_TRY(hipEventRecord(ev.b, c.stream));
+  const hipEvent_t p0 = ev.a, p1 = ev.b; ev.a = ev.b = nullptr;
   c.pass_events.push_back(p0); c.pass_events.push_back(p1);
   c.spp += S;
   c.stats.samples += (uint64_t)npix * S;
@@ -326,7 +390,13 @@ int render_pass_device(const ArtPassParams* p, int32_t* spp_inout) {
   return 0;
 }
 
+static int synchronize_one();
 int synchronize() {
+  Dev0Guard guard;
+  for (int k = 0; k < g_ndev; ++k) { if (use_dev(k) || synchronize_one()) return 1; }
+  return 0;
+}
+static int synchronize_one() {
   Ctx& c = g_ctx;
   if (!c.device_ready) return 0;
   HIP_TRY(hipStreamSynchronize(c.stream));
@@ -340,15 +410,56 @@ int synchronize() {
   return collect_timing();
 }
 
+// every pixel has one owner, so the other devices hold exact zeros there and the sum over devices is exact: ONE
+// ncclReduce(sum, float32, W*H*3, root = device 0) over xGMI, grouped over the process' communicators, each on its device's stream
+// (ordered after that device's render kernels).  The per-device buffers stay as they are (they keep accumulating over passes); the
+// sum lands in device 0's b_reduced.  Several contexts on ONE physical GPU (rehearsal on a 1-GPU box) cannot form a communicator:
+// there the sum is a chain of local adds in device order, which is the same exact sum.
+static int reduce_accum(const float** out) {
+  Ctx& c0 = g_devs[0];
+  if (g_ndev == 1) { *out = c0.ext_accum ? c0.ext_accum : (const float*)c0.b_accum.p; return 0; }
+  const size_t count = (size_t)c0.width * c0.height * 3;
+  Dev0Guard guard;
+  if (use_dev(0) || ensure(c0.b_reduced, count * 4)) return 1;
+  if (g_comms_ready) {
+    if (ncclGroupStart() != ncclSuccess) return fail("ncclGroupStart failed");
+    for (int k = 0; k < g_ndev; ++k) {
+      const ncclResult_t r = ncclReduce(g_devs[k].b_accum.p, k == 0 ? c0.b_reduced.p : nullptr, count, ncclFloat32, ncclSum, 0, g_comms[k], g_devs[k].stream);
+      if (r != ncclSuccess) { (void)ncclGroupEnd(); return fail(std::string("ncclReduce: ") + ncclGetErrorString(r)); }
+    }
+    const ncclResult_t r = ncclGroupEnd();
+    if (r != ncclSuccess) return fail(std::string("ncclGroupEnd: ") + ncclGetErrorString(r));
+  } else if (g_same_gpu) {
+    HIP_TRY(hipMemcpyAsync(c0.b_reduced.p, c0.b_accum.p, count * 4, hipMemcpyDeviceToDevice, c0.stream));
+    for (int k = 1; k < g_ndev; ++k) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(e, g_devs[k].stream));
+      HIP_TRY(hipStreamWaitEvent(c0.stream, e, 0));
+      (void)hipEventDestroy(e);
+      launch_add_f32(c0.stream, (const float*)g_devs[k].b_accum.p, (float*)c0.b_reduced.p, count);
+    }
+  } else return fail("internal: multi-device mode without a reduce path");
+  *out = (const float*)c0.b_reduced.p;
+  return 0;
+}
+
 int download(float* accum_host, uint32_t* screen_host, int layout, int spp) {
   Ctx& c = g_ctx;
   if (c.width <= 0) return fail("no viewport");
+  const float* acc = nullptr;
+  if (reduce_accum(&acc)) return 1;
+  return download_from(acc, accum_host, screen_host, layout, spp);
+}
+
+static int download_from(const float* acc_dev, float* accum_host, uint32_t* screen_host, int layout, int spp) {
+  Ctx& c = g_ctx;
   const int W = c.width, H = c.height; const size_t n = (size_t)W * H;
-  if (screen_host) launch_resolve(c.stream, accum_ptr(), (int)n, 1.0f / (float)spp, (uint32_t*)c.b_screen.p);
+  if (screen_host) launch_resolve(c.stream, acc_dev, (int)n, 1.0f / (float)spp, (uint32_t*)c.b_screen.p);
   if (layout == ART_LAYOUT_ADA_XY) {
     if (ensure(c.b_stage, n * 12)) return 1;
     if (accum_host) {
-      launch_to_xmajor_f3(c.stream, accum_ptr(), (float*)c.b_stage.p, W, H);
+      launch_to_xmajor_f3(c.stream, acc_dev, (float*)c.b_stage.p, W, H);
       HIP_TRY(hipMemcpyAsync(accum_host, c.b_stage.p, n * 12, hipMemcpyDeviceToHost, c.stream));
       HIP_TRY(hipStreamSynchronize(c.stream));
     }
@@ -357,7 +468,7 @@ int download(float* accum_host, uint32_t* screen_host, int layout, int spp) {
       HIP_TRY(hipMemcpyAsync(screen_host, c.b_stage.p, n * 4, hipMemcpyDeviceToHost, c.stream));
     }
   } else {
-    if (accum_host) HIP_TRY(hipMemcpyAsync(accum_host, accum_ptr(), n * 12, hipMemcpyDeviceToHost, c.stream));
+    if (accum_host) HIP_TRY(hipMemcpyAsync(accum_host, acc_dev, n * 12, hipMemcpyDeviceToHost, c.stream));
     if (screen_host) HIP_TRY(hipMemcpyAsync(screen_host, c.b_screen.p, n * 4, hipMemcpyDeviceToHost, c.stream));
   }
   HIP_TRY(hipStreamSynchronize(c.stream));
@@ -365,7 +476,23 @@ int download(float* accum_host, uint32_t* screen_host, int layout, int spp) {
   return 0;
 }
 
+static int debug_pass_one(const ArtPassParams* p, float* accum_host, uint32_t* screen_host, int32_t* prim_index, int32_t* mat_id, int32_t* prim_type);
+// Debug_Ray_Tracing is one primary ray per pixel: in multi-device mode device 0 takes the whole frame for it (its tile ownership is
+// restored afterwards) -- there is nothing to shard.
 int debug_pass(const ArtPassParams* p, float* accum_host, uint32_t* screen_host, int32_t* prim_index, int32_t* mat_id, int32_t* prim_type) {
+  if (g_ndev == 1) return debug_pass_one(p, accum_host, screen_host, prim_index, mat_id, prim_type);
+  Dev0Guard guard;
+  if (use_dev(0)) return 1;
+  Ctx& c = g_ctx;
+  const int rank = c.rank, nranks = c.nranks;
+  c.rank = 0; c.nranks = 1;
+  int rc = (c.width > 0) ? build_shard() : 0;
+  if (!rc) rc = debug_pass_one(p, accum_host, screen_host, prim_index, mat_id, prim_type);
+  c.rank = rank; c.nranks = nranks;
+  if (c.width > 0 && build_shard()) return 1;
+  return rc;
+}
+static int debug_pass_one(const ArtPassParams* p, float* accum_host, uint32_t* screen_host, int32_t* prim_index, int32_t* mat_id, int32_t* prim_type) {
   Ctx& c = g_ctx;
   if (check_pass(p)) return 1;
   ArtPassParams pp = *p; pp.aa_on = 0;
@@ -388,7 +515,7 @@ int debug_pass(const ArtPassParams* p, float* accum_host, uint32_t* screen_host,
   }
   HIP_TRY(hipGetLastError());
   // ray_tracer.adb:249-257: the debug image is resolved without dividing by spp
-  if (download(accum_host, screen_host, p->layout, 1)) return 1;
+  if (download_from(accum_ptr(), accum_host, screen_host, p->layout, 1)) return 1;
   auto copy_ids = [&](int32_t* host, const int32_t* dev) -> int {
     if (!host) return 0;
     if (p->layout == ART_LAYOUT_ADA_XY) {
@@ -400,7 +527,7 @@ int debug_pass(const ArtPassParams* p, float* accum_host, uint32_t* screen_host,
     return 0;
   };
   if (copy_ids(prim_index, d_pi) || copy_ids(mat_id, d_mi) || copy_ids(prim_type, d_pt)) return 1;
-  return synchronize();
+  return synchronize_one();
 }
 
 int trace_rays(const float* origins, const float* dirs, const float* tfar, int64_t n, ArtHit* out, int kernel, ArtStats* st) {
@@ -452,8 +579,13 @@ int trace_rays(const float* origins, const float* dirs, const float* tfar, int64
 }
 
 void shutdown() {
+  if (g_comms_ready) { for (int k = 0; k < g_ndev; ++k) (void)ncclCommDestroy(g_comms[k]); g_comms_ready = false; }
+  g_same_gpu = false;
+  for (int k = g_ndev - 1; k >= 0; --k) {
+  g_cur = &g_devs[k];
   Ctx& c = g_ctx;
   if (c.device_ready) {
+    if (c.device >= 0) (void)hipSetDevice(c.device);
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c.b_spheres, &c.b_sphere_mat, &c.b_lights, &c.b_materials, &c.b_bf_pos, &c.b_bf_nrm, &c.b_bf_uv, &c.b_bf_idx,
                       &c.b_nodes, &c.b_qnodes, &c.b_tris, &c.b_m_nrm, &c.b_m_uv, &c.b_m_idx, &c.b_m_matid, &c.b_accum, &c.b_screen, &c.b_stage,
@@ -464,8 +596,12 @@ void shutdown() {
     if (c.d_counters) (void)hipFree(c.d_counters);
     for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : c.pass_events) (void)hipEventDestroy(e);
+    c.b_reduced.release();
+    if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
   }
   c = Ctx();
+  }
+  g_ndev = 1; g_cur = &g_devs[0];
 }
 
 }  // namespace art
@@ -484,7 +620,55 @@ int art_init(int device_ordinal) {
   return ensure_device();
 }
 
-int art_set_stream(void* hip_stream) { std::lock_guard<std::mutex> lk(g_mu); g_ctx.stream = (hipStream_t)hip_stream; return 0; }
+// One process, n GPUs (SURVEY 8e / 8b "Threading": the Ada host calls Render_Pass from its environment task, test.adb:50, so the
+// fan-out over the node's GPUs has to happen below the C ABI).  ordinals == NULL: devices 0..n-1.  Every device gets its own
+// context, stream, replicated scene and path buffers; device k owns the 32x32 pixel tiles with tile_id mod n == k; art_render_pass /
+// art_download add the float3 framebuffers into device 0 with ONE RCCL reduce over xGMI.  Listing the same ordinal several times puts
+// several contexts on one GPU (a rehearsal of the whole path on a 1-GPU box; the reduce is then a local sum).
+int art_init_devices(int32_t n, const int32_t* ordinals) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (n < 1 || n > kMaxDevices) return fail("art_init_devices: 1.." + std::to_string(kMaxDevices) + " devices");
+  for (int k = 0; k < kMaxDevices; ++k) if (g_devs[k].device_ready) return fail("art_init_devices: already initialised; call art_shutdown first");
+  int avail = 0;
+  hipError_t e = hipGetDeviceCount(&avail);
+  if (e != hipSuccess || avail <= 0) return fail("no HIP device available (this library has no CPU path): " + std::string(hipGetErrorString(e)));
+  int ord[kMaxDevices]; bool distinct = true, same = true;
+  for (int k = 0; k < n; ++k) {
+    ord[k] = ordinals ? ordinals[k] : k;
+    if (ord[k] < 0 || ord[k] >= avail) return fail("art_init_devices: device " + std::to_string(ord[k]) + " does not exist (" + std::to_string(avail) + " visible)");
+    for (int i = 0; i < k; ++i) { if (ord[i] == ord[k]) distinct = false; else same = false; }
+  }
+  if (n > 1 && !distinct && !same) return fail("art_init_devices: the ordinals must be all different (one context per GPU) or all equal (rehearsal on one GPU)");
+  const Ctx opts = g_devs[0];                       // options set before initialisation apply to every device
+  Dev0Guard guard;
+  g_ndev = n;
+  for (int k = 0; k < n; ++k) {
+    Ctx& c = g_devs[k];
+    c = Ctx();
+    c.trace_kernel = opts.trace_kernel; c.batch_paths = opts.batch_paths; c.bvh_params = opts.bvh_params; c.node_min = opts.node_min;
+    c.queue_segments = opts.queue_segments; c.ray_chunk = opts.ray_chunk; c.shadow_anyhit = opts.shadow_anyhit; c.lds_stack_cap = opts.lds_stack_cap;
+    c.opt_blocks_per_cu = opts.opt_blocks_per_cu; c.count_tests = opts.count_tests;
+    c.device = ord[k]; c.rank = k; c.nranks = n; c.tile = 32;
+    if (use_dev(k) || ensure_device()) { shutdown(); return 1; }
+    if (n > 1) {
+      if (hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking) != hipSuccess) { shutdown(); return fail("hipStreamCreate failed"); }
+      c.stream = c.own_stream;
+    }
+  }
+  if (n > 1 && distinct) {
+    const ncclResult_t r = ncclCommInitAll(g_comms, n, ord);
+    if (r != ncclSuccess) { shutdown(); return fail(std::string("ncclCommInitAll: ") + ncclGetErrorString(r)); }
+    g_comms_ready = true;
+  }
+  g_same_gpu = (n > 1 && !distinct);
+  return 0;
+}
+
+int32_t art_device_count(void) { std::lock_guard<std::mutex> lk(g_mu); return g_ndev; }
+
+#define SINGLE_DEVICE_ONLY(name) if (g_ndev > 1) return fail(name ": not available after art_init_devices(n > 1); the library shards and reduces by itself")
+
+int art_set_stream(void* hip_stream) { std::lock_guard<std::mutex> lk(g_mu); SINGLE_DEVICE_ONLY("art_set_stream"); g_ctx.stream = (hipStream_t)hip_stream; return 0; }
 
 int art_upload_scene(const ArtSceneDesc* scene) { std::lock_guard<std::mutex> lk(g_mu); return upload_scene(scene); }
 
@@ -492,6 +676,7 @@ int art_resize(int32_t w, int32_t h) { std::lock_guard<std::mutex> lk(g_mu); ret
 
 int art_set_shard(int32_t rank, int32_t nranks, int32_t tile) {
   std::lock_guard<std::mutex> lk(g_mu);
+  SINGLE_DEVICE_ONLY("art_set_shard");
   if (nranks < 1 || rank < 0 || rank >= nranks || tile < 1) return fail("art_set_shard: bad arguments");
   g_ctx.rank = rank; g_ctx.nranks = nranks; g_ctx.tile = tile;
   if (g_ctx.width > 0) return build_shard();
@@ -510,8 +695,18 @@ int art_debug_hit_pass(const ArtPassParams* p, float* accum_host, uint32_t* scre
   return debug_pass(p, accum_host, screen_host, prim_index, mat_id, prim_type);
 }
 
-int art_bind_accum(void* device_accum_rowmajor) { std::lock_guard<std::mutex> lk(g_mu); g_ctx.ext_accum = (float*)device_accum_rowmajor; return 0; }
-void* art_accum_device(void) { return accum_ptr(); }
+int art_bind_accum(void* device_accum_rowmajor) { std::lock_guard<std::mutex> lk(g_mu); SINGLE_DEVICE_ONLY("art_bind_accum"); g_ctx.ext_accum = (float*)device_accum_rowmajor; return 0; }
+void* art_accum_device(void) {          // device 0; in multi-device mode the reduced framebuffer (valid after a reduce: art_reduce / art_download)
+  std::lock_guard<std::mutex> lk(g_mu);
+  return (g_ndev > 1) ? g_devs[0].b_reduced.p : (void*)accum_ptr();
+}
+
+// multi-device: enqueue the framebuffer reduce to device 0 (bench.py times it inside its step loop); no-op with one device
+int art_reduce(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const float* acc = nullptr;
+  return reduce_accum(&acc);
+}
 
 int art_download(float* accum_host, uint32_t* screen_host, int32_t layout, int32_t spp) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -522,7 +717,7 @@ int art_download(float* accum_host, uint32_t* screen_host, int32_t layout, int32
 int art_synchronize(void) { std::lock_guard<std::mutex> lk(g_mu); return synchronize(); }
 
 int art_trace_rays(const float* origins, const float* dirs, const float* tfar, int64_t n, ArtHit* out, int32_t kernel, ArtStats* stats) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> lk(g_mu);          // ray queries run on device 0
   return trace_rays(origins, dirs, tfar, n, out, kernel, stats);
 }
 
@@ -545,14 +740,28 @@ int art_get_stats(ArtStats* out) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!out) return fail("null stats");
   if (synchronize()) return 1;
-  *out = g_ctx.stats;
+  *out = g_devs[0].stats;                 // trace_ms / trace_launches / wave counters: device 0's (per-device quantities)
+  for (int k = 1; k < g_ndev; ++k) {      // work counters: the whole job
+    const ArtStats& t = g_devs[k].stats;
+    out->rays += t.rays; out->samples += t.samples; out->box_tests += t.box_tests; out->tri_tests += t.tri_tests;
+    out->node_visits += t.node_visits; out->leaf_visits += t.leaf_visits; out->traced_rays += t.traced_rays;
+    out->pass_ms = std::max(out->pass_ms, t.pass_ms);
+  }
   return 0;
 }
 
-int art_set_option(const char* name, int64_t value) {
+static int set_option_one(const std::string& n, int64_t value);
+int art_set_option(const char* name, int64_t value) {      // applies to every device of the process
   std::lock_guard<std::mutex> lk(g_mu);
   if (!name) return fail("null option");
   const std::string n(name);
+  Ctx* const saved = g_cur;
+  int rc = 0;
+  for (int k = 0; k < g_ndev && !rc; ++k) { g_cur = &g_devs[k]; rc = set_option_one(n, value); }
+  g_cur = saved;
+  return rc;
+}
+static int set_option_one(const std::string& n, int64_t value) {
   if (n == "trace_kernel") { if (value != TRACE_COOP && value != TRACE_SIMPLE) return fail("trace_kernel: 0 (cooperative) or 1 (simple)"); g_ctx.trace_kernel = (int)value; }
   else if (n == "queue_segments") { if (value != 1 && value != 2 && value != 4 && value != 8) return fail("queue_segments: 1, 2, 4 or 8"); g_ctx.queue_segments = (int)value; }
   else if (n == "batch_paths") { if (value < 1024 || value > (1ll << 29)) return fail("batch_paths: 1024..2^29 (ray indices are 32-bit: 2 rays per path slot)"); g_ctx.batch_paths = value; }

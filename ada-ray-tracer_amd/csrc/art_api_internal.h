@@ -11,6 +11,7 @@
 
 namespace art {
 
+constexpr int kMaxDevices = 16;       // art_init_devices: GPUs one process may drive (an MI355X node has 8)
 constexpr int kCursorInts = 32 * 9;   // d_cursor: 3 scalars + one work cursor per queue segment, each on its own 128-byte line
 
 struct DevBuf { void* p = nullptr; size_t bytes = 0; void release(); };
@@ -18,6 +19,7 @@ struct DevBuf { void* p = nullptr; size_t bytes = 0; void release(); };
 struct Ctx {
   int device = -1; bool device_ready = false; int num_cus = 0; std::string arch;
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;            // multi-device mode: the stream this context created (stream == own_stream)
   // scene
   bool scene_ready = false;
   HostScene host_scene;
@@ -31,6 +33,7 @@ struct Ctx {
   int width = 0, height = 0, spp = 0;
   int rank = 0, nranks = 1, tile = 32, npix_local = 0;
   DevBuf b_accum, b_screen, b_stage, b_pixmap, b_paths, b_rays, b_ids, b_queue, b_ovf;
+  DevBuf b_reduced;                            // device 0, multi-device mode: sum of every device's accum (the RCCL reduce target)
   float* ext_accum = nullptr;
   // work distribution / counters
   int* d_cursor = nullptr;
@@ -52,7 +55,12 @@ struct Ctx {
   ArtStats stats = ArtStats();
 };
 
-extern Ctx g_ctx;
+// One context per GPU.  A single-GPU process only ever uses g_devs[0]; art_init_devices(n) fills n of them.  Every entry point holds
+// g_mu, so "the current context" is a plain global that the multi-device loops repoint.
+extern Ctx g_devs[kMaxDevices];
+extern int g_ndev;
+extern Ctx* g_cur;
+#define g_ctx (*::art::g_cur)
 extern std::mutex g_mu;
 
 int fail(const std::string& msg);

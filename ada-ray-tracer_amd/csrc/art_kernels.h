@@ -42,6 +42,7 @@ void launch_debug(hipStream_t st, const DevFrame& F, const DevScene& S, const De
 void launch_to_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, int h);
 void launch_to_xmajor_u32(hipStream_t st, const uint32_t* src, uint32_t* dst, int w, int h);
 void launch_from_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, int h);
+void launch_add_f32(hipStream_t st, const float* src, float* dst, size_t n);
 size_t trace_coop_lds_bytes(int stack_entries, int width);
 void launch_trace(hipStream_t st, const DevScene* d_scene, const TraceArgs& A, int kernel, bool stats, int grid_blocks);
 void launch_analytic(hipStream_t st, const DevScene* d_scene, const TraceArgs& A, bool stats);

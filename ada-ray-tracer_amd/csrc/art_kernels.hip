@@ -571,6 +571,13 @@ __global__ __launch_bounds__(256) void k_from_xmajor_f3(const float* src_xmajor,
   dst_rowmajor[3 * s] = src_xmajor[3 * (size_t)i]; dst_rowmajor[3 * s + 1] = src_xmajor[3 * (size_t)i + 1]; dst_rowmajor[3 * s + 2] = src_xmajor[3 * (size_t)i + 2];
 }
 
+// dst[i] += src[i]: the framebuffer sum between two contexts that live on the same physical GPU (multi-device rehearsal; distinct
+// GPUs use the RCCL reduce).  Written as src + dst: adding exact zeros in any order gives the same bits anyway.
+__global__ __launch_bounds__(256) void k_add_f32(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i] + dst[i];
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers (the only symbols art_api.cpp needs from this translation unit)
 // ------------------------------------------------------------------------------------------------
@@ -602,6 +609,10 @@ void launch_to_xmajor_u32(hipStream_t st, const uint32_t* src, uint32_t* dst, in
 }
 void launch_from_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, int h) {
   hipLaunchKernelGGL(k_from_xmajor_f3, dim3(blocks_for(w * h)), dim3(256), 0, st, src, dst, w, h);
+}
+
+void launch_add_f32(hipStream_t st, const float* src, float* dst, size_t n) {
+  hipLaunchKernelGGL(k_add_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
 }
 
 size_t trace_coop_lds_bytes(int stack_entries, int width) { return (size_t)4 * (64 / width) * (stack_entries + 3) * sizeof(uint2); }   // + 2 guards + sink

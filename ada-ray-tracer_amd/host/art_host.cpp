@@ -190,3 +190,13 @@ extern "C" int art_host_cornell_scene(const char* vsgf_path, float* spheres5 /*3
   counts4[0] = (int)sc.spheres.size(); counts4[1] = (int)sc.materials.size(); counts4[2] = (int)nv; counts4[3] = (int)(sc.mymesh.triangles.size() / 3);
   return 0;
 }
+
+// The internal scene (Scene.Init, scene.adb:24-27 -> Init_Cornell_Box) as an ArtSceneDesc for callers that drive the C ABI directly
+// (the Python layer, bench.py --scene c2): the product describes its own workload, no test code involved.  Returns nullptr on failure
+// (message on stderr).  The descriptor and everything it points to stay valid until the next call.
+extern "C" const ArtSceneDesc* art_host_scene_init(const char* vsgf_path) {
+  static art_host::Scene sc;
+  std::string err;
+  if (!vsgf_path || !sc.Init(vsgf_path, err)) { std::fprintf(stderr, "art_host_scene_init: %s\n", err.c_str()); return nullptr; }
+  return &sc.desc;
+}

@@ -7,6 +7,7 @@ from . import (LIGHT_RECT, LIGHT_SPHERE, MAT_GLASS, MAT_LAMBERT, MAT_LIGHT, MAT_
                MESH_CLOSEST, SceneDesc)
 
 F = np.float32
+PYRAMID_VSGF = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "data", "pyramid2.vsgf")
 
 CORNELL_BOX = dict(min=(-2.5, 0.0, 0.0), max=(2.5, 5.0, 5.0), mat=(2, 3, 1, 1, 8, 1),            # scene.ads:75-80
                    nrm=((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)))
@@ -141,3 +142,44 @@ def mirror_scene(n_tris=600, seed=0xADA5EED0 + 17):
     mesh = random_triangles(n_tris, seed)
     mesh["matid"] = np.array([(1, 2, 3, 5)[i % 4] for i in range(n_tris)], np.int32)
     return SceneDesc(spheres=spheres, lights=lights, materials=mats, meshes=[mesh], cornell=CORNELL_BOX, cam_pos=REFERENCE_CAMERA)
+
+
+class HostSceneDesc:
+    """ArtSceneDesc built by the product's own host layer (host/art_host.cpp, Scene.Init = scene.adb:24-27, 89-217): the reference's
+    internal Cornell scene with data/pyramid2.vsgf.  `.desc` is what Backend.upload_scene takes."""
+
+    def __init__(self, vsgf_path=None, cam_pos=None):
+        import ctypes as C
+        import os
+        from . import PKG_DIR, ArtError, ArtSceneDesc
+        lib = C.CDLL(os.path.join(PKG_DIR, "libart_host.so"))
+        lib.art_host_scene_init.restype = C.POINTER(ArtSceneDesc)
+        lib.art_host_scene_init.argtypes = [C.c_char_p]
+        p = lib.art_host_scene_init((vsgf_path or PYRAMID_VSGF).encode())
+        if not p:
+            raise ArtError("art_host_scene_init failed (is %s there?)" % (vsgf_path or PYRAMID_VSGF))
+        self._lib = lib
+        self.desc = ArtSceneDesc()
+        C.memmove(C.byref(self.desc), p, C.sizeof(ArtSceneDesc))      # pointers stay those of the host layer's static scene
+        if cam_pos is not None:
+            self.desc.cam_pos = (C.c_float * 3)(*cam_pos)
+
+
+def reference_scene(cam_pos=None):
+    """C2 (and, with eight spheres, C1): Scene.Init through the product's host mirror."""
+    return HostSceneDesc(cam_pos=cam_pos)
+
+
+def eight_sphere_scene(seed=0xADA5EED0 + 1):
+    """C1 'Cornell-box-style 8-sphere scene' (BASELINE.json configs[0]): the internal scene has 3 spheres (scene.adb:139-144,182-192:
+    Phong, glass, the light); SURVEY 8(d) completes it to 8 with five spheres of radius 0.4 at seeded positions inside the box,
+    materials cycling Lambert white / Phong / glass / Lambert green / Lambert red.  No mesh: plumbing only, as BASELINE says."""
+    mats = cornell_materials()
+    area = float(F(4.0) * F(np.pi) * F(0.5) * F(0.5))
+    lights = [dict(shape=LIGHT_SPHERE, mat=4, center=(0.0, 4.5, 1.0), radius=0.5, intensity=(10.0, 10.0, 10.0), surfaceArea=area)]
+    spheres = [((-1.5, 1.0, 1.5), 1.0, 8), ((1.4, 1.0, 3.0), 1.0, 0), ((0.0, 4.5, 1.0), 0.5, 4)]
+    u = uniform01(seed, 15).reshape(5, 3)
+    for i in range(5):
+        p = (float(F(-2.0) + F(4.0) * u[i, 0]), float(F(2.3) + F(1.4) * u[i, 1]), float(F(0.6) + F(3.8) * u[i, 2]))
+        spheres.append((p, 0.4, (1, 8, 0, 2, 3)[i]))
+    return SceneDesc(spheres=spheres, lights=lights, materials=mats, meshes=[], cornell=CORNELL_BOX, cam_pos=REFERENCE_CAMERA)

@@ -128,6 +128,15 @@ typedef struct ArtHit {          /* geometry.ads:57-67 flattened */
 typedef struct ArtBvhInfo { int32_t n_nodes, n_tris, max_stack, node_width; double build_ms; } ArtBvhInfo;   /* nodes: 8*node_width floats each */
 
 int  art_init(int device_ordinal);                       /* -1: keep the current HIP device */
+/* One process, n GPUs of the node (the Ada host calls Render_Pass from one task: ray_tracer.adb:240-293, test.adb:50).  ordinals ==
+ * NULL: devices 0..n-1.  Scene and BVH are replicated, device k owns the 32x32 pixel tiles with tile_id mod n == k, and the float3
+ * framebuffers are added into device 0 by ONE RCCL reduce over xGMI whenever the image is asked for (art_render_pass with host
+ * pointers, art_download, art_reduce).  The image is bit-identical for any n.  Call INSTEAD of art_init; art_set_stream /
+ * art_set_shard / art_bind_accum are single-device calls and fail afterwards.  Repeating one ordinal n times rehearses the whole
+ * path on a single GPU (the reduce is then a local sum). */
+int  art_init_devices(int32_t n, const int32_t* ordinals);
+int32_t art_device_count(void);
+int  art_reduce(void);                                   /* enqueue the framebuffer reduce now (no-op with one device) */
 int  art_set_stream(void* hip_stream);                   /* hipStream_t; NULL = default stream */
 int  art_upload_scene(const ArtSceneDesc* scene);        /* Scene.Init: flatten + BVH build + copy to HBM */
 int  art_resize(int32_t width, int32_t height);          /* Resize_Viewport (ray_tracer.adb:297-320): zero accum, spp := 0 */

@@ -994,6 +994,52 @@ void orc_render_pass(const orc_scene* scn, const orc_params* prm, float* accum, 
   if (cnt) { cnt->rays += rays; cnt->tri_tests += tris; cnt->samples += (uint64_t)W * H * prm->vthreads * per; }
 }
 
+/* The same pass organised the way the reference runs it (ray_tracer.adb:142-194, 264-277): Threads_Num tasks, each renders the WHOLE
+ * frame once (DoPass) with its own samples; here every task adds into a private frame instead of g_accBuff under GNAT.Task_Lock
+ * (integrators.adb:50-52), and the private frames are added in task order afterwards -- bit-identical to orc_render_pass.
+ * `nthreads` OS threads share the vthreads tasks.  Used as the reference-faithful CPU baseline (bench.py, cpu_baseline.mode_a).   */
+int orc_render_pass_tasks(const orc_scene* scn, const orc_params* prm, float* accum, int32_t* spp, orc_counters* cnt) {
+  const int W = prm->width, H = prm->height, T = prm->vthreads;
+  const int per = prm->aa_on ? 4 : 1;
+  const uint32_t base = (uint32_t)*spp;
+  const size_t npx = (size_t)W * H;
+  float* priv = (float*)malloc((size_t)T * npx * 3 * sizeof(float));
+  if (!priv) return 1;
+  uint64_t rays = 0, tris = 0;
+#ifdef _OPENMP
+  if (prm->nthreads > 0) omp_set_num_threads(prm->nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, tris)
+  for (int t = 0; t < T; ++t) {                                                       /* one Path_Trace_Thread */
+    local_counters lc = { 0, 0 };
+    float* f = priv + (size_t)t * npx * 3;
+    for (int y = 0; y < H; ++y)                                                        /* integrators.adb:32-33: for y, for x */
+      for (int x = 0; x < W; ++x) {
+        f3 color;
+        if (prm->aa_on) {
+          color = ld3(prm->background);
+          for (int i = 0; i < 4; ++i) color = add(color, camera_sample(scn, prm, x, y, base + (uint32_t)(t * 4 + i), &lc));
+        } else {
+          color = camera_sample(scn, prm, x, y, base + (uint32_t)t, &lc);
+        }
+        float* o = f + 3 * ((size_t)y * W + x);
+        o[0] = color.x; o[1] = color.y; o[2] = color.z;
+      }
+    rays += lc.rays; tris += lc.tri_tests;
+  }
+  for (int t = 0; t < T; ++t) {
+    const float* f = priv + (size_t)t * npx * 3;
+    for (size_t i = 0; i < npx; ++i) {
+      f3 cb = add(ld3(f + 3 * i), ld3(accum + 3 * i));                                 /* colBuff(x,y) := color + colBuff(x,y) */
+      accum[3 * i] = cb.x; accum[3 * i + 1] = cb.y; accum[3 * i + 2] = cb.z;
+    }
+  }
+  free(priv);
+  *spp += T * per;
+  if (cnt) { cnt->rays += rays; cnt->tri_tests += tris; cnt->samples += (uint64_t)npx * T * per; }
+  return 0;
+}
+
 void orc_debug_pass(const orc_scene* scn, const orc_params* prm, float* accum, int32_t* prim_index, int32_t* mat_id, int32_t* prim_type) { /* ray_tracer.adb:208-238 */
   static const float palette[8][3] = { { 0.5f, 0.0f, 0.0f }, { 0.0f, 0.5f, 0.0f }, { 0.0f, 0.0f, 0.5f }, { 0.5f, 0.5f, 0.5f },
                                        { 0.5f, 0.5f, 0.0f }, { 0.5f, 0.0f, 0.5f }, { 0.0f, 0.5f, 0.5f }, { 0.75f, 0.75f, 0.75f } };

@@ -153,6 +153,8 @@ void orc_build_cornell(orc_cornell_storage* st, const orc_mesh* pyramid, int use
 void orc_render_pass(const orc_scene* scn, const orc_params* prm, float* accum, int32_t* spp, orc_counters* cnt);
 
 /* Radiance of one camera sample (for debugging mismatches). */
+/* same result, organised as the reference's task pool: vthreads tasks, each a whole-frame DoPass into a private frame (returns 0 on success) */
+int  orc_render_pass_tasks(const orc_scene* scn, const orc_params* prm, float* accum, int32_t* spp, orc_counters* cnt);
 void orc_sample_radiance(const orc_scene* scn, const orc_params* prm, int32_t x, int32_t y,
                          uint32_t sample_index, float out_rgb[3]);
 

@@ -12,6 +12,7 @@ Ada and cannot be built in this image):
                               per-block standard deviation -- the whole-picture pin: the picture turned out to be the HEAD scene
                               seen from (0, 2.55, 11) instead of scene.adb:212's (0, 2.55, 12.5)
   cornell_debug_64.npz        RT_DEBUG ids of the internal scene at 64x64 from the oracle (regression pin)
+  c1_debug_64.npz             RT_DEBUG ids of the C1 eight-sphere scene (scenes.eight_sphere_scene) at 64x64 from the oracle
   cornell_mis_32.npz          PT_MIS accum of the internal scene, 32x32, 2 passes x 4 spp, seed 1 (regression pin)
 """
 import json
@@ -24,6 +25,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 REF = "/root/reference"
 
 
@@ -63,6 +65,13 @@ def main():
     cs = orc.CornellScene()
     _, prim, mat, ptype = orc.debug_pass(cs.scene, orc.make_params(64, 64, orc.RT_DEBUG, False))
     np.savez_compressed(os.path.join(HERE, "cornell_debug_64.npz"), prim=prim, mat=mat, ptype=ptype)
+    import __graft_entry__ as ge
+    import conv
+    art = ge.load_package()
+    from ada_ray_tracer_amd import scenes
+    c1 = conv.OracleScene(scenes.eight_sphere_scene())
+    _, prim, mat, ptype = orc.debug_pass(c1.scene, orc.make_params(64, 64, orc.RT_DEBUG, False))
+    np.savez_compressed(os.path.join(HERE, "c1_debug_64.npz"), prim=prim, mat=mat, ptype=ptype)
     acc, spp, cnt = orc.render(cs.scene, orc.make_params(32, 32, orc.PT_MIS, True, 8, 1, seed=1), passes=2)
     np.savez_compressed(os.path.join(HERE, "cornell_mis_32.npz"), accum_bits=acc.view(np.uint32), spp=spp, rays=cnt.rays)
     print("golden fixtures written")

@@ -110,6 +110,8 @@ def lib():
     L.orc_cornell_mesh_transform.argtypes = [f32p]
     L.orc_build_cornell.argtypes = [C.POINTER(CornellStorage), C.POINTER(Mesh), C.c_int]
     L.orc_render_pass.argtypes = [C.POINTER(Scene), C.POINTER(Params), f32p, i32p, C.POINTER(Counters)]
+    L.orc_render_pass_tasks.argtypes = [C.POINTER(Scene), C.POINTER(Params), f32p, i32p, C.POINTER(Counters)]
+    L.orc_render_pass_tasks.restype = C.c_int
     L.orc_sample_radiance.argtypes = [C.POINTER(Scene), C.POINTER(Params), C.c_int32, C.c_int32, C.c_uint32, f32p]
     L.orc_debug_pass.argtypes = [C.POINTER(Scene), C.POINTER(Params), f32p, i32p, i32p, i32p]
     L.orc_resolve.argtypes = [f32p, C.c_int32, C.c_int32, C.c_int32, u32p]
@@ -187,6 +189,17 @@ def render(scene, params, passes=1, accum=None, spp0=0):
     cnt = Counters()
     for _ in range(passes):
         L.orc_render_pass(C.byref(scene), C.byref(params), fp(accum), C.byref(spp), C.byref(cnt))
+    return accum, spp.value, cnt
+
+
+def render_tasks(scene, params, accum=None, spp0=0):
+    """One pass organised like the reference's task pool (orc_render_pass_tasks): same bits as render()."""
+    if accum is None:
+        accum = np.zeros((params.height, params.width, 3), np.float32)
+    spp = C.c_int32(spp0)
+    cnt = Counters()
+    if lib().orc_render_pass_tasks(C.byref(scene), C.byref(params), fp(accum), C.byref(spp), C.byref(cnt)):
+        raise MemoryError("orc_render_pass_tasks")
     return accum, spp.value, cnt
 
 

@@ -88,3 +88,43 @@ def test_scene_validation_errors_are_reported_without_a_gpu(art):
     p = art.Backend.pass_params()
     assert L.art_render_pass(C.byref(p), None, None, None) != 0 and "no scene" in L.art_last_error().decode()
     assert L.art_set_option(b"no_such_option", 1) != 0 and L.art_set_shard(3, 2, 32) != 0
+
+
+def test_product_host_layer_builds_the_reference_scene(art):
+    """scenes.reference_scene(): Scene.Init (scene.adb:24-27, 89-217) by host/art_host.cpp -- what bench.py --scene c2 and the
+    reference-picture GPU test upload -- equals the oracle's construction byte for byte (spheres, light, materials, transformed mesh)."""
+    import ctypes as C
+
+    import conv
+    import orc
+    from ada_ray_tracer_amd import scenes
+    d = scenes.reference_scene().desc
+    od = conv.desc_from_oracle(art, orc.CornellScene()).desc
+
+    def same(a, b, n):
+        return C.string_at(a, n) == C.string_at(b, n)
+    assert (d.n_spheres, d.n_lights, d.n_materials, d.n_meshes, d.has_cornell) == (3, 1, 11, 1, 1)
+    assert same(d.spheres, od.spheres, C.sizeof(art.ArtSphere) * 3) and same(d.lights, od.lights, C.sizeof(art.ArtLight))
+    assert same(d.materials, od.materials, C.sizeof(art.ArtMaterial) * 11)
+    m, om = d.meshes[0], od.meshes[0]
+    assert (m.mode, m.nverts, m.ntris) == (om.mode, om.nverts, om.ntris) == (art.MESH_REFERENCE_BF, 17, 8)
+    assert same(m.pos, om.pos, 17 * 12) and same(m.nrm, om.nrm, 17 * 12) and same(m.idx, om.idx, 24 * 4)
+    assert list(m.bbmin) == list(om.bbmin) and list(m.bbmax) == list(om.bbmax)
+    assert list(d.cam_pos) == list(od.cam_pos) and list(d.cam_matrix) == list(od.cam_matrix)
+    assert list(d.cb_min) == list(od.cb_min) and list(d.cb_mat) == list(od.cb_mat)
+    assert open(scenes.PYRAMID_VSGF, "rb").read() == open(orc.PYRAMID_VSGF, "rb").read()
+
+
+def test_c1_eight_sphere_scene_golden(art):
+    """BASELINE configs[0]: the named 8-sphere scene; the oracle's RT_DEBUG ids match the committed golden and show all 8 spheres."""
+    import numpy as np
+
+    import conv
+    import orc
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.eight_sphere_scene()
+    assert sd.desc.n_spheres == 8 and sd.desc.n_meshes == 0
+    _, prim, mat, ptype = orc.debug_pass(conv.OracleScene(sd).scene, orc.make_params(64, 64, orc.RT_DEBUG, False))
+    g = np.load(orc.GOLDEN + "/c1_debug_64.npz")
+    assert np.array_equal(prim, g["prim"]) and np.array_equal(mat, g["mat"]) and np.array_equal(ptype, g["ptype"])
+    assert set(np.unique(prim[ptype == 1])) == set(range(8))

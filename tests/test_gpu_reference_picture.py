@@ -5,8 +5,6 @@ suite that does not go through the oracle: a misreading of the Ada source shared
 import numpy as np
 import pytest
 
-import conv
-import orc
 import picture_pin
 
 pytestmark = pytest.mark.gpu
@@ -14,10 +12,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("size,vthreads", [(1024, 256), (512, 64)])
 def test_product_reproduces_the_reference_picture(art, backend, size, vthreads):
-    cs = orc.CornellScene()                       # only used to read pyramid2.vsgf and the scene constants into an ArtSceneDesc
-    sd = conv.desc_from_oracle(art, cs)
-    sd.desc.cam_pos = (art.C.c_float * 3)(*picture_pin.PICTURE_CAMERA) if hasattr(art, "C") else type(sd.desc.cam_pos)(*picture_pin.PICTURE_CAMERA)
-    backend.upload_scene(sd)
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.reference_scene(cam_pos=picture_pin.PICTURE_CAMERA)      # Scene.Init by the product's own host layer: no oracle anywhere in this test
+    backend.upload_scene(sd.desc)
     backend.resize(size, size)
     p = art.Backend.pass_params(art.PT_MIS, True, 8, vthreads, seed=1)
     _, screen, spp = backend.render_pass(p, 0, want_accum=False, want_screen=True)

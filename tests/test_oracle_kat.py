@@ -132,3 +132,13 @@ def test_intersect_triangle_against_numpy_float32_transcription():
     assert np.float32(h.t) == t and np.float32(h.tx) == 0 and v > 0 and u > 0
     back = orc.closest_hits(s, (o + np.array([0, 0, -6], f))[None], (d * np.array([1, 1, -1], f))[None])[0]
     assert back.is_hit == 0        # max(det, 1e-25) rejects back faces (geometry.adb:243)
+
+
+def test_task_pool_organisation_gives_the_same_bits():
+    """orc_render_pass_tasks (Threads_Num tasks, each a whole-frame DoPass into a private frame: the reference's organisation,
+    ray_tracer.adb:142-194) == orc_render_pass (pixel-parallel), bit for bit, for any number of OS threads."""
+    cs = orc.CornellScene()
+    for aa, nthreads in ((True, 3), (False, 0)):
+        a, spp_a, ca = orc.render(cs.scene, orc.make_params(40, 32, orc.PT_MIS, aa, 8, 5, seed=4))
+        b, spp_b, cb = orc.render_tasks(cs.scene, orc.make_params(40, 32, orc.PT_MIS, aa, 8, 5, seed=4, nthreads=nthreads))
+        assert spp_a == spp_b and ca.rays == cb.rays and np.array_equal(a.view(np.uint32), b.view(np.uint32))
