@@ -240,7 +240,7 @@ class Backend:
         _check(self.lib.art_set_option(name.encode(), int(value)))
 
     def upload_scene(self, scene):
-        desc = scene.desc if isinstance(scene, SceneDesc) else scene
+        desc = getattr(scene, "desc", scene)          # SceneDesc / scenes.HostSceneDesc, or a raw ArtSceneDesc
         _check(self.lib.art_upload_scene(C.byref(desc)))
 
     def resize(self, width, height):

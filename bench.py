@@ -7,14 +7,25 @@ Render_Pass of `--vthreads` x 4 samples per pixel (default 64 spp); the full 256
 Rays = closest-hit queries actually issued (camera + bounce + shadow).  Scene upload and BVH build are
 outside the timed region and reported separately in `config`.
 
-N > 1: one process per GPU (torch.distributed / RCCL), interleaved 32x32 pixel tiles per rank (strong scaling of
-the fixed frame), one RCCL reduce(sum) of the float3 framebuffer to rank 0 inside the timed region.
+N > 1, two ways to drive the same sharding (interleaved 32x32 pixel tiles, strong scaling of the fixed frame, ONE RCCL
+reduce(sum) of the float3 framebuffer to rank / device 0 inside the timed region):
+  * launched by torchrun (WORLD_SIZE > 1): one process per GPU, torch.distributed (backend "nccl" = RCCL) does the reduce;
+  * plain `python bench.py --gpus N`: ONE process, art_init_devices(N) -- the library shards and reduces by itself
+    (what the single-task Ada host gets).
 
-Extra objects on the line: "roofline" (algorithmic bytes of the trace kernel / its HIP-event time, SURVEY 8d
-formula 32*B + 48*T + 64 bytes per ray with B, T counted on this very workload) and "cpu_baseline" (the CPU oracle,
-BVH-accelerated, on a bounded sample of the same scene and camera, timed on this host).
+Extra objects on the line:
+  "roofline"      the trace kernel against the memory roofline it is bound by.  achieved = rays x algorithmic bytes per ray /
+                  trace-kernel time (HIP events around every launch, on the launch stream); algorithmic bytes per ray =
+                  node_bytes x node visits + 48 x triangle tests + 64, the visits and tests counted on this very workload by
+                  the counting variant of the kernel (equal to the oracle's walk of the exported tree); peak = 8 TB/s HBM3E.
+                  "traffic" = bytes that actually left L2 per second (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE passes,
+                  profiles/), only when the committed profile was taken on this source, scene and options; else null.
+  "cpu_baseline"  the CPU oracle (kind "port": the reference is Ada and cannot be built or shipped) on a bounded sample of
+                  the same workload, timed on this host; for --scene c2 also "mode_a", the reference-faithful organisation
+                  (brute-force mesh, Threads_Num = 28 whole-frame tasks).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -22,13 +33,13 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
 import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PROFILE_TAG = "r2_final"
 
 
 def build_scene(art, args):
@@ -39,23 +50,33 @@ def build_scene(art, args):
         return scenes.synthetic_scene(100000, 3), "C3: synthetic 100000 triangles + 3 sphere lights in the Cornell box"
     if args.scene == "c5":
         return scenes.mixed_scene(20000, 5), "C5: spheres + 20000-triangle mesh, glass/diffuse/emissive"
-    import conv
-    import orc
-    cs = orc.CornellScene()
-    return conv.desc_from_oracle(art, cs), "C2: internal Cornell scene with data/pyramid2.vsgf"
+    if args.scene == "c1":
+        return scenes.eight_sphere_scene(), "C1: Cornell-box-style 8-sphere scene"
+    return scenes.reference_scene(), "C2: internal Cornell scene with data/pyramid2.vsgf (Scene.Init by the product's host layer)"
 
 
-def measured_traffic(args, W, H):
-    """HBM-side traffic of the trace kernel in GB/s from the committed rocprofv3 PMC passes (profiles/collect.sh ->
-    profiles/summarize.py): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch / launch time.  The factor 2 on FETCH_SIZE is the
-    gfx950 correction, calibrated on this kernel's own access pattern (profiles/calib_fetch.hip: 17.15 GB reported for
-    34.36 GB of known 128-byte segment gathers).  Only valid for the profiled workload (default C4); null otherwise."""
-    if args.scene != "c4" or args.tris != 1000000 or (W, H) != (1920, 1080) or args.kernel != "coop":
-        return None
+def source_fingerprint():
+    """sha256 over the kernel / driver sources: a committed PMC profile only describes the build it was taken on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ada-ray-tracer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def workload_fingerprint(args, W, H, info, opts):
+    return {"scene": args.scene, "tris": args.tris if args.scene == "c4" else None, "width": W, "height": H, "spp_per_step": 4 * args.vthreads,
+            "kernel": args.kernel, "bvh_width": info.node_width, "bvh_nodes": info.n_nodes, "options": sorted(opts), "source": source_fingerprint()}
+
+
+def profiled(args, fp):
+    """The committed rocprofv3 PMC summary (profiles/collect.sh -> profiles/summarize.py) if it was taken on exactly this source,
+    scene and options; None otherwise -- a number measured on another build must not sit next to this run's."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r1_final", "pmc_summary.json")))
-        k = [x for x in d if "k_trace_coop" in x][0]
-        return round(d[k]["traffic_GBps_fetch_x2"], 1)
+        d = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG, "pmc_summary.json")))
+        if d.get("fingerprint") != fp:
+            return None
+        return d["k_trace_coop"]
     except Exception:
         return None
 
@@ -80,15 +101,15 @@ def host_cpu_share():
     return n
 
 
-def cpu_baseline(art, sd, args):
-    """CPU oracle (kind "port": the reference is Ada and cannot be built or shipped) on a bounded sample of the same
-    workload: same scene, same camera, reduced frame (ray distribution preserved), PT_MIS depth 8, all host threads.
-    The closest-hit mesh search walks the product's exported BVH (oracle/art_oracle.c: intersect_mesh_closest)."""
+def cpu_baseline(art, sd, args, be):
+    """CPU oracle (kind "port") on a bounded sample of the same workload: same scene, same camera, reduced frame (ray
+    distribution preserved), PT_MIS depth 8, all host threads of the job's share.  The closest-hit mesh search walks the product's
+    exported BVH (oracle/art_oracle.c: intersect_mesh_closest) -- the reference's own O(N) scan is timed as mode_a where feasible."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import conv
     import orc
     w, h = args.cpu_width, args.cpu_height
     osc = conv.OracleScene(sd)
-    be = args._backend
     if sd.desc.n_meshes and sd.desc.meshes[0].mode == art.MESH_CLOSEST:
         nodes, tris, binfo = be.export_bvh()
         osc.attach_bvh(nodes, tris, binfo.node_width)
@@ -105,8 +126,28 @@ def cpu_baseline(art, sd, args):
         if time.time() - t0 > args.cpu_seconds or passes >= 64:
             break
     dt = time.time() - t0
-    return {"value": round(cnt_total / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "same scene+camera at %dx%d, %d passes x 4 spp, PT_MIS depth 8, BVH closest-hit, %.1f s" % (w, h, passes, dt)}
+    out = {"value": round(cnt_total / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+           "sample": "same scene+camera at %dx%d, %d passes x 4 spp, PT_MIS depth 8, BVH closest-hit, %.1f s" % (w, h, passes, dt),
+           "mode_a": None}
+    if args.scene in ("c1", "c2"):
+        # BASELINE.md section 3, mode A: what the Ada program does -- brute-force mesh scan (IntersectMeshBF), Threads_Num = 28 tasks
+        # that each render the whole frame (Path_Trace_Thread), private frames instead of the global GNAT.Task_Lock
+        osa = conv.OracleScene(sd)                                  # no BVH attached: geometry.adb:266-323 order and cost
+        pa = orc.make_params(w, h, orc.PT_MIS, True, 8, 28, seed=1, nthreads=cores)
+        t0 = time.time()
+        n_pass = 0; rays_a = 0
+        while True:
+            _, _, cnt = orc.render_tasks(osa.scene, pa)
+            rays_a += cnt.rays; n_pass += 1
+            if time.time() - t0 > args.cpu_seconds or n_pass >= 16:
+                break
+        dta = time.time() - t0
+        out["mode_a"] = {"value": round(rays_a / dta / 1e6, 4), "unit": "Mrays/s", "cores": cores, "threads_num": 28,
+                         "sample": "Threads_Num = 28 whole-frame tasks (112 spp per pass) on %d OS threads, %dx%d, %d passes, brute-force mesh, "
+                                   "private frames instead of GNAT.Task_Lock, %.1f s" % (cores, w, h, n_pass, dta)}
+    else:
+        out["mode_a_note"] = "the reference's O(N) mesh scan is ~8 ms per ray at 1M triangles on 8 cores: not timed here; --scene c2 reports mode_a"
+    return out
 
 
 def main():
@@ -114,7 +155,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="c4", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--scene", default="c4", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--tris", type=int, default=1000000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -128,6 +169,7 @@ def main():
     ap.add_argument("--no-counters", action="store_true", help="skip the untimed B/T counting pass")
     ap.add_argument("--host-buffers", action="store_true", help="hand AccumBuff/screen_buffer over in host memory every pass (Ada layout), i.e. include PCIe")
     ap.add_argument("--simulate-shard", default="", help="R/N: render only rank R's pixel tiles of an N-GPU job on this one GPU (scaling rehearsal)")
+    ap.add_argument("--contexts", type=int, default=0, help="rehearse the one-process N-device path with N contexts on GPU 0 (a 1-GPU box)")
     ap.add_argument("--opt", action="append", default=[], help="backend option name=value (art_set_option), e.g. bvh_leaf_base_milli=1000")
     args = ap.parse_args()
 
@@ -137,14 +179,19 @@ def main():
     dist = None
     torch = None
     use_dist = world > 1 or bool(os.environ.get("ART_BENCH_FORCE_DIST"))     # FORCE: rehearse the torch/RCCL path with one rank
+    in_library = (not use_dist) and (args.gpus > 1 or args.contexts > 1)       # one process drives all the GPUs through art_init_devices
     if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     art = ge.load_package()
-    be = art.Backend(local_rank if use_dist else 0)
-    args._backend = be
+    if in_library:
+        be = art.Backend(devices=([0] * args.contexts) if args.contexts > 1 else args.gpus)
+        n_gpus = args.contexts if args.contexts > 1 else args.gpus
+    else:
+        be = art.Backend(local_rank if use_dist else 0)
+        n_gpus = world
     be.set_option("trace_kernel", art.TRACE_COOP if args.kernel == "coop" else art.TRACE_SIMPLE)
     for kv in args.opt:
         k, v = kv.split("=")
@@ -164,11 +211,12 @@ def main():
         accum_t = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
         be.bind_accum(accum_t.data_ptr())
         be.set_stream(torch.cuda.current_stream().cuda_stream)
-    if args.simulate_shard:
-        r_, n_ = [int(v) for v in args.simulate_shard.split("/")]
-        be.set_shard(r_, n_, 32)
-    else:
-        be.set_shard(rank, world, 32)
+    if not in_library:
+        if args.simulate_shard:
+            r_, n_ = [int(v) for v in args.simulate_shard.split("/")]
+            be.set_shard(r_, n_, 32)
+        else:
+            be.set_shard(rank, world, 32)
     be.resize(W, H)
     prm = art.Backend.pass_params(art.PT_MIS, True, 8, args.vthreads, seed=1)
     spp = 0
@@ -194,6 +242,8 @@ def main():
         be.synchronize()
         dist.reduce(accum_t, dst=0, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
+    elif in_library:
+        be.reduce()                       # the RCCL reduce of the float3 framebuffer to device 0, inside the timed region
     be.synchronize()
     elapsed = time.perf_counter() - t0
     s1 = be.stats()
@@ -208,13 +258,15 @@ def main():
         rs = torch.tensor([float(rays), float(samples)], dtype=torch.float64, device="cuda")
         dist.all_reduce(rs, op=dist.ReduceOp.SUM)
         total_rays, total_samples = float(rs[0].item()), float(rs[1].item())
+        rays_dev0 = rays
     else:
         total_rays, total_samples = float(rays), float(samples)
+        rays_dev0 = rays / n_gpus if in_library else rays          # stats(): trace_ms is device 0's, rays the whole job's
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (trace): algorithmic bytes / HIP-event time, this rank's launches
+        # ---- roofline of the dominant kernel (trace): algorithmic bytes / HIP-event time, device 0's launches
         roofline = None
-        if not args.no_counters:
+        if not args.no_counters and not in_library and info.n_tris > 0:      # a scene without a BVH mesh never launches the trace kernel
             be.set_option("count_tests", 1)
             c0 = be.stats()
             be.render_pass_device(art.Backend.pass_params(art.PT_MIS, True, 8, 1, seed=1), spp)   # untimed, counting variant
@@ -230,28 +282,41 @@ def main():
                    "groups_per_leaf_phase": round((c1.leaf_visits - c0.leaf_visits) / itl, 2),
                    "tris_per_leaf_visit": round((c1.tri_tests - c0.tri_tests) / max(1, c1.leaf_visits - c0.leaf_visits), 2),
                    "node_phase_iters": int(itn), "leaf_phase_iters": int(itl), "wave_iters": int(c1.wave_iters - c0.wave_iters)}
-            bytes_per_ray = 32.0 * B + 48.0 * T + 64.0
-            achieved = rays * bytes_per_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+            # algorithmic bytes per ray of THIS data layout: a node visit reads the node packet once (64 B quantised at
+            # width 4, 256 B binary32 at width 8), a triangle test reads a 48-B record, a ray costs 32 B in + 32 B out
+            node_bytes = 64.0 if info.node_width == 4 else 256.0
+            bytes_per_ray = node_bytes * NV + 48.0 * T + 64.0
+            achieved = rays_dev0 * bytes_per_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+            fp = workload_fingerprint(args, W, H, info, args.opt)
+            prof = profiled(args, fp)
             roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(args, W, H),
+                        "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                        "traffic": round(prof["traffic_GBps_fetch_x2"], 1) if prof else None,
+                        "traffic_source": ("profiles/%s/pmc_summary.json (same source %s, scene, options)" % (PROFILE_TAG, fp["source"])) if prof else None,
                         "kernel": "k_trace_coop" if args.kernel == "coop" else "k_trace_simple",
-                        "bytes_per_ray": round(bytes_per_ray, 1), "box_tests_per_ray": round(B, 2), "tri_tests_per_ray": round(T, 2),
-                        "node_visits_per_ray": round(NV, 2), "leaf_visits_per_ray": round(LV, 2), "wave_occupancy": occ,
+                        "bound_evidence": "one more scattered node read per step: 1.83x slower; 16 more VALU instructions per step: +4 % "
+                                          "(profiles/r2_sensitivity.json): the kernel waits for L2-miss line fills, not for issue slots",
+                        "bytes_per_ray": round(bytes_per_ray, 1), "node_bytes": node_bytes, "box_tests_per_ray": round(B, 2), "tri_tests_per_ray": round(T, 2),
+                        "node_visits_per_ray": round(NV, 2), "leaf_visits_per_ray": round(LV, 2),
+                        "survey_8d_formula_GBps": round(rays_dev0 * (32.0 * B + 48.0 * T + 64.0) / (trace_ms * 1e-3) / 1e9, 1) if trace_ms > 0 else None,
+                        "l2_hit_rate": round(prof["l2_hit_rate"], 4) if prof and "l2_hit_rate" in prof else None,
+                        "wave_occupancy": occ,
                         "avg_launch_ms": round(trace_ms / max(1, launches), 4), "launches": int(launches),
-                        "trace_Mrays_per_s": round(rays / (trace_ms * 1e-3) / 1e6, 2) if trace_ms > 0 else None}
+                        "trace_Mrays_per_s": round(rays_dev0 / (trace_ms * 1e-3) / 1e6, 2) if trace_ms > 0 else None}
         cpu = None
-        if not args.no_cpu and world == 1:          # timed on rank 0 at N = 1 only
-            cpu = cpu_baseline(art, sd, args)
+        if not args.no_cpu and n_gpus == 1:          # timed on rank 0 at N = 1 only
+            cpu = cpu_baseline(art, sd, args, be)
         value = total_rays / elapsed / 1e6
         line = {
-            "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / max(1, args.steps), 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, %dx%d, PT_MIS depth 8, 2x2 AA, %d spp per step" % (scene_name, W, H, 4 * args.vthreads),
                        "spp_per_step": 4 * args.vthreads, "rays_per_sample": round(total_rays / max(1.0, total_samples), 3),
-                       "Msamples_per_s": round(total_samples / elapsed / 1e6, 3), "parallelism": "pixel-tiles x%d" % world,
+                       "Msamples_per_s": round(total_samples / elapsed / 1e6, 3),
+                       "parallelism": ("pixel-tiles x%d, %s" % (n_gpus, "one process (art_init_devices)" if in_library else "one process per GPU (torch.distributed)")) if n_gpus > 1 else "pixel-tiles x1",
                        "bvh_width": info.node_width, "bvh_nodes": info.n_nodes, "bvh_build_ms": round(info.build_ms, 1), "bvh_max_stack": info.max_stack, "scene_gen_s": round(t_gen, 2),
-                       "scene_upload_s": round(t_upload, 2)},
+                       "scene_upload_s": round(t_upload, 2), "fingerprint": workload_fingerprint(args, W, H, info, args.opt)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns gpurun_out/prof_final (raw rocprofv3 csv, scratch) into the committed summaries under profiles/<tag>/:
 kernel_stats.csv (rocprofv3 --kernel-trace --stats) and pmc_summary.json (per-kernel counter sums, per-launch HBM traffic
-of the trace kernel).  usage: python profiles/summarize.py r1_final"""
+of the trace kernel).  usage: python profiles/summarize.py r2_final c4"""
 import collections
 import csv
 import glob
@@ -17,10 +17,13 @@ def newest(pattern):
 
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof_final")
 
 
-def main(tag):
+def main(tag, name="c4"):
+    """tag: directory under profiles/ (r2_final for the bench.py default workload C4, which bench.py quotes; r2_c3 ...);
+    name: the collect.sh run to read (gpurun_out/prof_<name>)"""
+    global SRC
+    SRC = os.path.join(ROOT, "gpurun_out", "prof_" + name)
     dst = os.path.join(ROOT, "profiles", tag)
     os.makedirs(dst, exist_ok=True)
     shutil.copyfile(newest(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv")), os.path.join(dst, "kernel_stats.csv"))
@@ -50,12 +53,17 @@ def main(tag):
                 o["effective_clock_GHz"] = o["GRBM_GUI_ACTIVE"] / 8.0 / o["total_ns_sq"]
             if "TCC_HIT_sum" in o:
                 o["l2_hit_rate"] = o["TCC_HIT_sum"] / (o["TCC_HIT_sum"] + o["TCC_MISS_sum"])
-    json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
     b = os.path.join(SRC, "bench_under_rocprof.json")
     if os.path.exists(b):
         shutil.copyfile(b, os.path.join(dst, "bench_under_rocprof.json"))
+        # bench.py only quotes this profile for runs with the same fingerprint (source hash, scene, frame, options, tree)
+        out["fingerprint"] = json.load(open(b))["config"]["fingerprint"]
+    for k in list(out):
+        if "k_trace_coop" in k:
+            out["k_trace_coop"] = out[k]
+    json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
     print("wrote", dst)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r1_final")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r2_final", sys.argv[2] if len(sys.argv) > 2 else "c4")

@@ -63,4 +63,27 @@ def test_bench_contract(art):
     assert line["metric"] == "Mrays/s" and line["value"] > 0 and line["vs_baseline"] is None and "workload" in line["config"]
     rf = line["roofline"]
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+    assert rf["frac"] <= 1.0 and rf["traffic"] is None             # a reduced frame never matches the committed profile's fingerprint
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["mode_a"] is None
+
+
+def test_bench_c2_comes_from_the_product_and_reports_mode_a(art):
+    """--scene c2: Scene.Init by the product's host layer (no oracle in the workload), and the reference-faithful CPU organisation
+    (brute-force mesh, Threads_Num = 28 whole-frame tasks) next to the pixel-parallel port."""
+    r = subprocess.run([sys.executable, os.path.join(art.ROOT, "bench.py"), "--scene", "c2", "--width", "128", "--height", "128", "--steps", "1",
+                        "--warmup", "1", "--vthreads", "1", "--cpu-seconds", "1", "--cpu-width", "48", "--cpu-height", "48"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "Scene.Init by the product" in line["config"]["workload"] and line["value"] > 0
+    a = line["cpu_baseline"]["mode_a"]
+    assert a["threads_num"] == 28 and a["value"] > 0 and "brute-force" in a["sample"]
+
+
+def test_bench_one_process_many_contexts(art):
+    """bench.py --contexts 4: the one-process N-device path of the library (art_init_devices) rehearsed on this box's single GPU."""
+    r = subprocess.run([sys.executable, os.path.join(art.ROOT, "bench.py"), "--scene", "c3", "--width", "256", "--height", "144", "--steps", "1",
+                        "--warmup", "1", "--vthreads", "1", "--contexts", "4", "--no-cpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 4 and line["value"] > 0 and "art_init_devices" in line["config"]["parallelism"]
