@@ -99,7 +99,7 @@ EXPORTED_SYMBOLS = [
     "art_debug_hit_pass", "art_bind_accum", "art_accum_device", "art_download", "art_synchronize", "art_trace_rays",
     "art_export_bvh", "art_get_stats", "art_set_option", "art_last_error", "art_shutdown",
     "gcore_init_and_clear", "gcore_destroy", "gcore_add_mesh_3f", "gcore_instance_meshes", "gcore_commit_scene",
-    "gcore_closest_hit",
+    "gcore_closest_hit", "gcore_closest_hit_n",
 ]
 
 
@@ -142,6 +142,8 @@ def load_library():
     L.gcore_instance_meshes.argtypes = [C.c_int, f32p, C.c_int]
     L.gcore_closest_hit.argtypes = [f32p, f32p, C.c_float, C.c_float, C.POINTER(HitCpp)]
     L.gcore_closest_hit.restype = C.c_bool
+    L.gcore_closest_hit_n.argtypes = [C.c_int, f32p, f32p, f32p, f32p, C.POINTER(HitCpp), C.POINTER(C.c_ubyte)]
+    L.gcore_closest_hit_n.restype = C.c_int
     _lib = L
     return L
 

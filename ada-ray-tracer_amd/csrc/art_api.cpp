@@ -248,7 +248,7 @@ static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
 }
 
 // one trace launch, bracketed by HIP events on the launch stream
-static int trace(const DevPaths& q, int n_rays) {
+static int trace(const DevPaths& q, int n_rays, bool timed = true) {
   Ctx& c = g_ctx;
   const bool coop = (c.trace_kernel == TRACE_COOP);
   if (coop && ensure(c.b_queue, (size_t)n_rays * sizeof(int))) return 1;
@@ -258,16 +258,18 @@ static int trace(const DevPaths& q, int n_rays) {
   if (coop) {
     HIP_TRY(hipMemsetAsync(c.d_cursor, 0, kCursorInts * sizeof(int), c.stream));
   }
-  if (c.ev_pool.size() < c.ev_used + 2) {
+  if (timed && c.ev_pool.size() < c.ev_used + 2) {
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     c.ev_pool.push_back(e0); c.ev_pool.push_back(e1);
   }
   if (coop) launch_analytic(c.stream, c.d_scene, a, c.count_tests);   // outside the trace-kernel event pair
-  HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used], c.stream));
-  launch_trace(c.stream, c.d_scene, a, c.trace_kernel, c.count_tests, coop_grid());
-  HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used + 1], c.stream));
-  c.ev_used += 2;
+  if (timed) HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used], c.stream));
+  // a workgroup keeps 4 waves x (64 / width) rays in flight: a handful of rays (the legacy per-ray seam) gets a handful of workgroups
+  const int rays_per_block = 4 * (64 / std::max(1, c.scene.node_width));
+  const int grid = (int)std::min<int64_t>(coop_grid(), ((int64_t)n_rays + rays_per_block - 1) / rays_per_block);
+  launch_trace(c.stream, c.d_scene, a, c.trace_kernel, c.count_tests, std::max(1, grid));
+  if (timed) { HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used + 1], c.stream)); c.ev_used += 2; }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -546,13 +548,13 @@ int trace_rays(const float* origins, const float* dirs, const float* tfar, int64
   float* d = (float*)c.b_rays.p;
   HIP_TRY(hipMemcpyAsync(d, soa.data(), 7 * N * 4, hipMemcpyHostToDevice, c.stream));
   HIP_TRY(hipMemsetAsync(d + 7 * N, 0xff, 4 * N * 4, c.stream));
-  HIP_TRY(hipMemsetAsync(c.d_counters + 3, 0, 8 * sizeof(unsigned long long), c.stream));
+  if (st) HIP_TRY(hipMemsetAsync(c.d_counters + 3, 0, 8 * sizeof(unsigned long long), c.stream));
   DevPaths q; std::memset(&q, 0, sizeof q);
   q.ray_ox = d; q.ray_oy = d + N; q.ray_oz = d + 2 * N; q.ray_dx = d + 3 * N; q.ray_dy = d + 4 * N; q.ray_dz = d + 5 * N; q.ray_tfar = d + 6 * N;
   q.hit_t = d + 7 * N; q.hit_key = (uint32_t*)(d + 8 * N); q.hit_u = d + 9 * N; q.hit_v = d + 10 * N;
   const int saved_kernel = c.trace_kernel; const bool saved_count = c.count_tests;
   c.trace_kernel = kernel; c.count_tests = (st != nullptr);
-  const int rc = trace(q, (int)n);
+  const int rc = trace(q, (int)n, /*timed=*/st != nullptr);       // without stats: no events, no counter read-back (the per-ray seam)
   c.trace_kernel = saved_kernel; c.count_tests = saved_count;
   if (rc) return 1;
   std::vector<float> hits(4 * N);
@@ -573,8 +575,10 @@ int trace_rays(const float* origins, const float* dirs, const float* tfar, int64
     h.prim_type = (cls == KEY_CORNELL) ? 0 : (cls == KEY_SPHERE) ? 1 : (cls == KEY_QUAD) ? 3 : 2;
     h.normal[0] = sf.normal.x; h.normal[1] = sf.normal.y; h.normal[2] = sf.normal.z;
   }
-  if (synchronize()) return 1;
-  if (st) *st = c.stats;
+  if (st) {
+    if (synchronize()) return 1;
+    *st = c.stats;
+  }
   return 0;
 }
 

@@ -10,9 +10,11 @@
 // with hit = (1-u-v) v0 + u v1 + v v2.  Two-sidedness is obtained by uploading each triangle in both
 // windings (the kernel's Moeller-Trumbore test is the reference's one-sided one, geometry.adb:243).
 //
-// gcore_closest_hit launches one single-ray trace per call and is serialised by the backend mutex:
-// it is the per-ray compatibility path (SURVEY 8b "per-ray fallback for debugging"); the frame-level
-// art_render_pass is the fast path.
+// gcore_closest_hit is the per-ray compatibility path (SURVEY 8b "per-ray fallback for debugging"); the frame-level
+// art_render_pass is the fast path.  Concurrent callers are combined into one launch; gcore_closest_hit_n takes a batch.
+// The scene committed here REPLACES the art_* scene of the process (one backend singleton, like g_data in embree_connect.cpp:12-22):
+// a process uses either seam at a time.
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -118,17 +120,23 @@ void gcore_commit_scene(void) {
   g.committed = true;
 }
 
-bool gcore_closest_hit(const float a_rayPos[3], const float a_rayDir[3], float t_near, float t_far, HitCpp* pHit) {
-  std::lock_guard<std::mutex> lk(art::g_mu);
-  if (!g.committed || !a_rayPos || !a_rayDir || !pHit) return false;
-  const float tn = (t_near > 0.0f) ? t_near : 0.0f;
-  float o[3] = { a_rayPos[0] + tn * a_rayDir[0], a_rayPos[1] + tn * a_rayDir[1], a_rayPos[2] + tn * a_rayDir[2] };
-  float far = t_far - tn;
-  if (!(far > 0.0f)) return false;
-  ArtHit h;
-  if (art::trace_rays(o, a_rayDir, &far, 1, &h, art::TRACE_COOP, nullptr)) return false;
-  if (!h.is_hit || h.prim_type != 2) return false;
+// ---- ray queries.  One GPU launch answers any number of rays, so concurrent callers are combined: the reference calls
+// gcore_closest_hit from up to 28 Ada tasks at once (scene_hydra_embree.adb:426-446, Threads_Num ray_tracer.ads:23).  The first caller
+// to arrive becomes the leader and launches what is pending; callers arriving meanwhile queue up and ride the NEXT launch together
+// (flat combining: no thread is created, nobody spins).  gcore_closest_hit_n is the explicit batch form of the same query.
+namespace {
+
+struct Req { const float* pos; const float* dir; float t_near, t_far; HitCpp* out; bool found; bool done; };
+std::mutex q_mu;
+std::condition_variable q_cv;
+std::vector<Req*> q_pending;
+bool q_leader = false;
+
+void fill_hit(const ArtHit& h, float tn, Req& r) {
+  r.found = false;
+  if (!h.is_hit || h.prim_type != 2) return;
   const int32_t k = h.prim_index >> 1; const bool flipped = (h.prim_index & 1) != 0;
+  HitCpp* pHit = r.out;
   pHit->primIndex = g.tri_prim[k];
   pHit->geomIndex = 0;                 // each mesh scene holds a single geometry (embree_connect.cpp:139)
   pHit->instIndex = g.tri_inst[k];
@@ -142,7 +150,75 @@ bool gcore_closest_hit(const float a_rayPos[3], const float a_rayDir[3], float t
   // kernel barycentrics: v = weight of its 2nd vertex, u = weight of its 3rd (geometry.adb:245-246)
   pHit->texCoord[0] = flipped ? h.u : h.v;   // weight of v1
   pHit->texCoord[1] = flipped ? h.v : h.u;   // weight of v2
-  return true;
+  r.found = true;
+}
+
+// answers reqs[0..n) with ONE launch (art_trace_rays without statistics: no events, no counter read-back)
+void run_batch(Req* const* reqs, size_t n) {
+  std::lock_guard<std::mutex> lk(art::g_mu);
+  std::vector<float> o(3 * n), d(3 * n), far(n), tn(n);
+  std::vector<ArtHit> hits(n);
+  std::vector<char> live(n, 0);
+  size_t m = 0;                                               // rays with a non-empty interval, packed to the front
+  std::vector<size_t> who(n);
+  for (size_t i = 0; i < n; ++i) {
+    Req& r = *reqs[i];
+    r.found = false;
+    if (!g.committed || !r.pos || !r.dir || !r.out) continue;
+    const float t0 = (r.t_near > 0.0f) ? r.t_near : 0.0f;
+    const float f = r.t_far - t0;
+    if (!(f > 0.0f)) continue;
+    for (int a = 0; a < 3; ++a) { o[3 * m + a] = r.pos[a] + t0 * r.dir[a]; d[3 * m + a] = r.dir[a]; }
+    far[m] = f; tn[m] = t0; who[m] = i; ++m;
+  }
+  if (m == 0) return;
+  if (art::trace_rays(o.data(), d.data(), far.data(), (int64_t)m, hits.data(), art::TRACE_COOP, nullptr)) return;
+  for (size_t k = 0; k < m; ++k) fill_hit(hits[k], tn[k], *reqs[who[k]]);
+}
+
+}  // namespace
+
+bool gcore_closest_hit(const float a_rayPos[3], const float a_rayDir[3], float t_near, float t_far, HitCpp* pHit) {
+  Req me; me.pos = a_rayPos; me.dir = a_rayDir; me.t_near = t_near; me.t_far = t_far; me.out = pHit; me.found = false; me.done = false;
+  std::unique_lock<std::mutex> lk(q_mu);
+  q_pending.push_back(&me);
+  if (q_leader) {                                             // somebody is launching: wait for the launch that carries my ray
+    q_cv.wait(lk, [&] { return me.done; });
+    return me.found;
+  }
+  q_leader = true;
+  while (!q_pending.empty()) {
+    std::vector<Req*> batch; batch.swap(q_pending);
+    lk.unlock();
+    run_batch(batch.data(), batch.size());
+    lk.lock();
+    for (Req* r : batch) r->done = true;
+    q_cv.notify_all();
+  }
+  q_leader = false;
+  return me.found;
+}
+
+// Batch form of gcore_closest_hit (an extension of the seam: embree_connect.cpp has no counterpart; Embree's own batch entry point
+// would be rtcIntersect1M).  positions / directions: 3 floats per ray; t_near / t_far: one value per ray, or NULL for 0 / 1e5 (the
+// values scene_hydra_embree.adb:436 passes); hits[i] is written and found[i] set to 1 where ray i has a hit in (t_near, t_far).
+// Returns the number of hits.
+int gcore_closest_hit_n(int a_rayNum, const float* a_rayPos3f, const float* a_rayDir3f, const float* t_near, const float* t_far,
+                        HitCpp* pHits, unsigned char* pFound) {
+  if (a_rayNum <= 0 || !a_rayPos3f || !a_rayDir3f || !pHits || !pFound) return 0;
+  std::vector<Req> reqs((size_t)a_rayNum);
+  std::vector<Req*> ptr((size_t)a_rayNum);
+  for (int i = 0; i < a_rayNum; ++i) {
+    Req& r = reqs[(size_t)i];
+    r.pos = a_rayPos3f + 3 * (size_t)i; r.dir = a_rayDir3f + 3 * (size_t)i;
+    r.t_near = t_near ? t_near[i] : 0.0f; r.t_far = t_far ? t_far[i] : 100000.0f;
+    r.out = pHits + i; r.found = false; r.done = false;
+    ptr[(size_t)i] = &r;
+  }
+  run_batch(ptr.data(), ptr.size());
+  int n = 0;
+  for (int i = 0; i < a_rayNum; ++i) { pFound[i] = reqs[(size_t)i].found ? 1 : 0; n += pFound[i]; }
+  return n;
 }
 
 }  // extern "C"

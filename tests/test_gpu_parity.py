@@ -427,3 +427,46 @@ def test_gcore_closest_hit_is_thread_safe(art, backend):
     [t.start() for t in ts]; [t.join() for t in ts]
     assert out == serial and any(s[0] for s in serial)
     L.gcore_destroy()
+
+
+def test_gcore_queries_combine_and_batch(art, backend):
+    """28 concurrent callers (Threads_Num, ray_tracer.ads:23) are combined into shared launches, and gcore_closest_hit_n answers a whole
+    batch with one: same answers as one call per ray, and the rates say so (printed; round 1 served ~1 query per full persistent-grid
+    launch under a global mutex)."""
+    import threading
+    import time
+    L = backend.lib
+    rng = np.random.default_rng(4)
+    verts = (rng.random((3000, 3)) * 4 - 2).astype(np.float32)
+    idx = rng.integers(0, 3000, 9000).astype(np.int32)
+    L.gcore_init_and_clear()
+    mid = L.gcore_add_mesh_3f(verts.ctypes.data_as(art.f32p), 3000, idx.ctypes.data_as(art.i32p), 9000)
+    m = np.eye(4, dtype=np.float32)
+    L.gcore_instance_meshes(mid, m.ctypes.data_as(art.f32p), 1)
+    L.gcore_commit_scene()
+    n = 28 * 40
+    o = (rng.random((n, 3)) * 2 - 1).astype(np.float32); o[:, 2] = 6.0
+    d = np.tile(np.array([0, 0, -1], np.float32), (n, 1))
+
+    def query(i):
+        h = art.HitCpp(); h.primIndex = -1
+        ok = L.gcore_closest_hit(o[i].ctypes.data_as(art.f32p), d[i].ctypes.data_as(art.f32p), 0.0, 100000.0, C.byref(h))
+        return (True, h.primIndex, h.instIndex, h.t, tuple(h.normal), tuple(h.texCoord)) if ok else (False,)
+    t0 = time.perf_counter(); serial = [query(i) for i in range(200)]; t_serial = (time.perf_counter() - t0) / 200
+    out = [None] * n
+
+    def worker(k):
+        for i in range(k, n, 28):
+            out[i] = query(i)
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(28)]
+    t0 = time.perf_counter(); [t.start() for t in ts]; [t.join() for t in ts]; t_threads = (time.perf_counter() - t0) / n
+    assert out[:200] == serial and sum(1 for s in out if s[0]) > n // 4
+    hits = (art.HitCpp * n)(); found = (C.c_ubyte * n)()
+    t0 = time.perf_counter()
+    nh = L.gcore_closest_hit_n(n, o.ctypes.data_as(art.f32p), d.ctypes.data_as(art.f32p), None, None, hits, found)
+    t_batch = (time.perf_counter() - t0) / n
+    batch = [(True, hits[i].primIndex, hits[i].instIndex, hits[i].t, tuple(hits[i].normal), tuple(hits[i].texCoord)) if found[i] else (False,) for i in range(n)]
+    assert batch == out and nh == sum(1 for s in out if s[0])
+    print("gcore queries/s: serial %.0f, 28 threads %.0f, batch of %d %.0f" % (1 / t_serial, 1 / t_threads, n, 1 / t_batch))
+    assert t_batch * 50 < t_serial, "a batch must cost far less per ray than one launch per ray"
+    L.gcore_destroy()
