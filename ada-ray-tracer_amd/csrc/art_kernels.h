@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "art_shade.h"
 #include "art_qnode.h"
+#include "art_instanced.h"
 
 namespace art {
 
@@ -42,6 +43,7 @@ void launch_debug(hipStream_t st, const DevFrame& F, const DevScene& S, const De
 void launch_to_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, int h);
 void launch_to_xmajor_u32(hipStream_t st, const uint32_t* src, uint32_t* dst, int w, int h);
 void launch_from_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, int h);
+void launch_trace_instanced(hipStream_t st, const InstScene& T, const float* o, const float* d, const float* tfar, int n, InstHit* out);
 void launch_add_f32(hipStream_t st, const float* src, float* dst, size_t n);
 size_t trace_coop_lds_bytes(int stack_entries, int width);
 void launch_trace(hipStream_t st, const DevScene* d_scene, const TraceArgs& A, int kernel, bool stats, int grid_blocks);

@@ -498,6 +498,16 @@ __global__ __launch_bounds__(256) void k_trace_simple(const DevScene* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// two-level search of the legacy geometry-core seam (art_instanced.h): one ray per lane
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_trace_instanced(const InstScene T, const float* __restrict__ o, const float* __restrict__ d,
+                                                        const float* __restrict__ tfar, int n, InstHit* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = instanced_closest(T, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tfar[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // wavefront stages
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_raygen(const DevFrame F, const DevScene S, const DevPaths Q) {
@@ -609,6 +619,10 @@ void launch_to_xmajor_u32(hipStream_t st, const uint32_t* src, uint32_t* dst, in
 }
 void launch_from_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, int h) {
   hipLaunchKernelGGL(k_from_xmajor_f3, dim3(blocks_for(w * h)), dim3(256), 0, st, src, dst, w, h);
+}
+
+void launch_trace_instanced(hipStream_t st, const InstScene& T, const float* o, const float* d, const float* tfar, int n, InstHit* out) {
+  hipLaunchKernelGGL(k_trace_instanced, dim3((n + 63) / 64), dim3(64), 0, st, T, o, d, tfar, n, out);
 }
 
 void launch_add_f32(hipStream_t st, const float* src, float* dst, size_t n) {

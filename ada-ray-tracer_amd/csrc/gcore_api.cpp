@@ -14,15 +14,42 @@
 // art_render_pass is the fast path.  Concurrent callers are combined into one launch; gcore_closest_hit_n takes a batch.
 // The scene committed here REPLACES the art_* scene of the process (one backend singleton, like g_data in embree_connect.cpp:12-22):
 // a process uses either seam at a time.
+#include <algorithm>
+#include <array>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
 
 #include "art_api_internal.h"
 
 namespace {
+
+// ---- two-level scene (art_instanced.h): used when instancing is real (>= kTwoLevelMinInstances instances, or forced)
+constexpr int kTwoLevelMinInstances = 16;
+struct TwoLevel {
+  bool on = false;
+  std::vector<art::InstRec> inst;
+  art::Bvh8 tlas;
+  std::vector<float> blas_nodes, blas_tris;
+  std::vector<int32_t> mesh_node_base, mesh_tri_base, mesh_ntris;
+  // device copies
+  void *d_tlas_nodes = nullptr, *d_tlas_tris = nullptr, *d_blas_nodes = nullptr, *d_blas_tris = nullptr, *d_inst = nullptr;
+  void *d_rays = nullptr, *d_hits = nullptr; size_t ray_cap = 0;
+  void release() {
+    void** ps[] = {&d_tlas_nodes, &d_tlas_tris, &d_blas_nodes, &d_blas_tris, &d_inst, &d_rays, &d_hits};
+    for (void** p : ps) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    ray_cap = 0;
+  }
+};
+int g_force_two_level = -1;          // -1 automatic, 0 never, 1 always (gcore_set_two_level, tests)
+
 
 struct GMesh { std::vector<float> verts; std::vector<int32_t> idx; };
 struct GInst { int mesh; float m[12]; };
@@ -35,7 +62,94 @@ struct GState {
   std::vector<int32_t> tri_inst, tri_prim;
   std::vector<float> wverts;   // world-space vertices of every instance, 3 per vertex
   std::vector<int32_t> widx;
+  TwoLevel two;
 } g;
+
+bool invert_3x4(const float m[12], float out[12]) {            // world -> object in binary64, rounded once
+  const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g0 = m[8], h = m[9], i = m[10];
+  const double det = a * (e * i - f * h) - b * (d * i - f * g0) + c * (d * h - e * g0);
+  if (!(std::fabs(det) > 1.0e-300) || !std::isfinite(det)) return false;
+  const double r[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,
+                       (f * g0 - d * i) / det, (a * i - c * g0) / det, (c * d - a * f) / det,
+                       (d * h - e * g0) / det, (b * g0 - a * h) / det, (a * e - b * d) / det};
+  for (int row = 0; row < 3; ++row) {
+    for (int k = 0; k < 3; ++k) out[4 * row + k] = (float)r[3 * row + k];
+    out[4 * row + 3] = (float)-(r[3 * row] * (double)m[3] + r[3 * row + 1] * (double)m[7] + r[3 * row + 2] * (double)m[11]);
+  }
+  return true;
+}
+
+template <typename T> bool to_device(void** p, const std::vector<T>& v) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (v.empty()) return true;
+  if (hipMalloc(p, v.size() * sizeof(T)) != hipSuccess) return false;
+  return hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess;
+}
+
+// one tree per mesh (object space, both windings), one tree over the instances' world boxes
+bool build_two_level(std::string& err) {
+  TwoLevel& T = g.two;
+  T.release(); T = TwoLevel();
+  art::BvhBuildParams bp; bp.width = 4;
+  const size_t nm = g.meshes.size();
+  T.mesh_node_base.assign(nm, 0); T.mesh_tri_base.assign(nm, 0); T.mesh_ntris.assign(nm, 0);
+  std::vector<std::array<float, 6>> mesh_box(nm);
+  for (size_t mi = 0; mi < nm; ++mi) {
+    const GMesh& m = g.meshes[mi];
+    const size_t nt = m.idx.size() / 3;
+    std::vector<float> tri9(18 * nt);
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (size_t t = 0; t < nt; ++t) {
+      const float* A = &m.verts[3 * (size_t)m.idx[3 * t]]; const float* B = &m.verts[3 * (size_t)m.idx[3 * t + 1]]; const float* C = &m.verts[3 * (size_t)m.idx[3 * t + 2]];
+      float* f = &tri9[18 * t];
+      std::memcpy(f, A, 12); std::memcpy(f + 3, B, 12); std::memcpy(f + 6, C, 12);          // record 2t:   front winding
+      std::memcpy(f + 9, A, 12); std::memcpy(f + 12, C, 12); std::memcpy(f + 15, B, 12);     // record 2t+1: back winding
+      for (const float* P : {A, B, C}) for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], P[a]); hi[a] = std::max(hi[a], P[a]); }
+    }
+    art::Bvh8 b;
+    if (!art::build_bvh8(tri9.data(), nullptr, (int32_t)(2 * nt), bp, b, err)) return false;
+    T.mesh_node_base[mi] = (int32_t)(T.blas_nodes.size() / art::node_floats(4));
+    T.mesh_tri_base[mi] = (int32_t)(T.blas_tris.size() / art::kTriFloats);
+    T.mesh_ntris[mi] = b.n_tris;
+    T.blas_nodes.insert(T.blas_nodes.end(), b.nodes.begin(), b.nodes.end());
+    T.blas_tris.insert(T.blas_tris.end(), b.tris.begin(), b.tris.end());
+    mesh_box[mi] = {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]};
+  }
+  // proxies: ONE triangle per instance whose corners span exactly the instance's (padded) world box, prim = instance index
+  std::vector<float> proxy9; std::vector<int32_t> proxy_id;
+  for (size_t ii = 0; ii < g.insts.size(); ++ii) {
+    const GInst& in = g.insts[ii];
+    art::InstRec R; std::memset(&R, 0, sizeof R);
+    if (!invert_3x4(in.m, R.minv)) { std::printf("[c_gcore]: instance %d has a singular matrix, skipped\n", (int)ii); continue; }
+    R.node_base = T.mesh_node_base[in.mesh]; R.tri_base = T.mesh_tri_base[in.mesh]; R.n_tris = T.mesh_ntris[in.mesh]; R.mesh = in.mesh;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    const std::array<float, 6>& mb = mesh_box[in.mesh];
+    for (int corner = 0; corner < 8; ++corner) {
+      const double x = mb[(corner & 1) ? 3 : 0], y = mb[(corner & 2) ? 4 : 1], z = mb[(corner & 4) ? 5 : 2];
+      for (int r = 0; r < 3; ++r) {
+        const double w = (double)in.m[4 * r] * x + (double)in.m[4 * r + 1] * y + (double)in.m[4 * r + 2] * z + (double)in.m[4 * r + 3];
+        lo[r] = std::min(lo[r], w); hi[r] = std::max(hi[r], w);
+      }
+    }
+    float flo[3], fhi[3];
+    for (int r = 0; r < 3; ++r) {        // pad: the ray is taken to object space in binary32, so the world box must not be tight
+      const double pad = 1.0e-4 * (hi[r] - lo[r]) + 1.0e-5 * std::max(std::fabs(lo[r]), std::fabs(hi[r])) + 1.0e-6;
+      flo[r] = (float)(lo[r] - pad); fhi[r] = (float)(hi[r] + pad);
+    }
+    const float p[9] = {flo[0], flo[1], flo[2], fhi[0], fhi[1], fhi[2], flo[0], fhi[1], flo[2]};
+    proxy9.insert(proxy9.end(), p, p + 9);
+    proxy_id.push_back((int32_t)T.inst.size());
+    T.inst.push_back(R);
+    g.tri_inst.push_back((int32_t)ii);   // instance record -> caller's instance index
+  }
+  if (T.inst.empty()) { err = "no valid instances"; return false; }
+  art::BvhBuildParams tp; tp.width = 4; tp.max_leaf = 1;
+  if (!art::build_bvh8(proxy9.data(), proxy_id.data(), (int32_t)proxy_id.size(), tp, T.tlas, err)) return false;
+  if (!to_device(&T.d_tlas_nodes, T.tlas.nodes) || !to_device(&T.d_tlas_tris, T.tlas.tris) || !to_device(&T.d_blas_nodes, T.blas_nodes) ||
+      !to_device(&T.d_blas_tris, T.blas_tris) || !to_device(&T.d_inst, T.inst)) { err = "device upload of the two-level scene failed"; return false; }
+  T.on = true;
+  return true;
+}
 
 }  // namespace
 
@@ -43,8 +157,12 @@ extern "C" {
 
 void gcore_destroy(void) {
   std::lock_guard<std::mutex> lk(art::g_mu);
+  g.two.release();
   g = GState();
 }
+
+// -1 automatic (two-level from 16 instances on), 0 always flatten, 1 always two-level; takes effect at the next gcore_commit_scene
+void gcore_set_two_level(int mode) { std::lock_guard<std::mutex> lk(art::g_mu); g_force_two_level = mode; }
 
 void gcore_init_and_clear(void) {
   gcore_destroy();
@@ -90,6 +208,16 @@ void gcore_instance_meshes(int a_geomId, const float* a_matrices16f, int a_matri
 void gcore_commit_scene(void) {
   std::lock_guard<std::mutex> lk(art::g_mu);
   g.tri_inst.clear(); g.tri_prim.clear(); g.wverts.clear(); g.widx.clear();
+  g.two.release(); g.two.on = false;
+  const bool two_level = (g_force_two_level == 1) || (g_force_two_level < 0 && (int)g.insts.size() >= kTwoLevelMinInstances);
+  if (two_level) {                       // embree_connect.cpp:147-184: one tree per mesh, instances on top
+    if (g.insts.empty()) { std::printf("[c_gcore]: gcore_commit_scene, no instances\n"); return; }
+    std::string err;
+    if (art::ensure_device()) { std::printf("[c_gcore]: %s\n", art_last_error()); return; }
+    if (!build_two_level(err)) { std::printf("[c_gcore]: two-level build: %s\n", err.c_str()); return; }
+    g.committed = true;
+    return;
+  }
   for (size_t ii = 0; ii < g.insts.size(); ++ii) {
     const GInst& in = g.insts[ii];
     const GMesh& m = g.meshes[in.mesh];
@@ -172,6 +300,51 @@ void run_batch(Req* const* reqs, size_t n) {
     far[m] = f; tn[m] = t0; who[m] = i; ++m;
   }
   if (m == 0) return;
+  if (g.two.on) {
+    TwoLevel& T = g.two;
+    if (T.ray_cap < m) {
+      if (T.d_rays) (void)hipFree(T.d_rays);
+      if (T.d_hits) (void)hipFree(T.d_hits);
+      T.d_rays = T.d_hits = nullptr; T.ray_cap = 0;
+      const size_t cap = std::max<size_t>(m, 1024);
+      if (hipMalloc(&T.d_rays, cap * 7 * sizeof(float)) != hipSuccess || hipMalloc(&T.d_hits, cap * sizeof(art::InstHit)) != hipSuccess) return;
+      T.ray_cap = cap;
+    }
+    float* dr = (float*)T.d_rays;
+    hipStream_t st = art::g_devs[0].stream;
+    if (hipMemcpyAsync(dr, o.data(), 3 * m * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(dr + 3 * T.ray_cap, d.data(), 3 * m * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(dr + 6 * T.ray_cap, far.data(), m * 4, hipMemcpyHostToDevice, st) != hipSuccess) return;
+    art::InstScene S;
+    S.tlas_nodes = (const float*)T.d_tlas_nodes; S.tlas_tris = (const float*)T.d_tlas_tris; S.blas_nodes = (const float*)T.d_blas_nodes;
+    S.blas_tris = (const float*)T.d_blas_tris; S.inst = (const art::InstRec*)T.d_inst; S.n_inst = (int32_t)T.inst.size(); S.width = 4;
+    art::launch_trace_instanced(st, S, dr, dr + 3 * T.ray_cap, dr + 6 * T.ray_cap, (int)m, (art::InstHit*)T.d_hits);
+    std::vector<art::InstHit> ih(m);
+    if (hipMemcpyAsync(ih.data(), T.d_hits, m * sizeof(art::InstHit), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return;
+    for (size_t k = 0; k < m; ++k) {
+      Req& r = *reqs[who[k]];
+      const art::InstHit& h = ih[k];
+      if (h.inst < 0) continue;
+      const art::InstRec& R = T.inst[(size_t)h.inst];
+      const GMesh& gm = g.meshes[(size_t)R.mesh];
+      const int32_t tri = h.prim >> 1; const bool flipped = (h.prim & 1) != 0;
+      const GInst& gi = g.insts[(size_t)g.tri_inst[(size_t)h.inst]];
+      HitCpp* pHit = r.out;
+      pHit->primIndex = tri; pHit->geomIndex = 0; pHit->instIndex = g.tri_inst[(size_t)h.inst];
+      pHit->t = h.t + tn[k];
+      // Ng of the instanced triangle in WORLD space: cross of the transformed edges (what the flattened upload reports)
+      float w[3][3];
+      for (int c = 0; c < 3; ++c) {
+        const float* v = &gm.verts[3 * (size_t)gm.idx[3 * (size_t)tri + c]];
+        for (int rr = 0; rr < 3; ++rr) w[c][rr] = gi.m[4 * rr] * v[0] + gi.m[4 * rr + 1] * v[1] + gi.m[4 * rr + 2] * v[2] + gi.m[4 * rr + 3];
+      }
+      const float e1[3] = {w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2]}, e2[3] = {w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2]};
+      pHit->normal[0] = e1[1] * e2[2] - e1[2] * e2[1]; pHit->normal[1] = e1[2] * e2[0] - e1[0] * e2[2]; pHit->normal[2] = e1[0] * e2[1] - e1[1] * e2[0];
+      pHit->texCoord[0] = flipped ? h.u : h.v; pHit->texCoord[1] = flipped ? h.v : h.u;
+      r.found = true;
+    }
+    return;
+  }
   if (art::trace_rays(o.data(), d.data(), far.data(), (int64_t)m, hits.data(), art::TRACE_COOP, nullptr)) return;
   for (size_t k = 0; k < m; ++k) fill_hit(hits[k], tn[k], *reqs[who[k]]);
 }

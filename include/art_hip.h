@@ -195,6 +195,10 @@ bool gcore_closest_hit(const float a_rayPos[3], const float a_rayDir[3], float t
 _Bool gcore_closest_hit(const float a_rayPos[3], const float a_rayDir[3], float t_near, float t_far, HitCpp* pHit);
 #endif
 
+/* Scene representation chosen by gcore_commit_scene: -1 automatic (one tree per mesh + a tree over the instances from 16 instances on,
+ * like Embree's instance geometries, embree_connect.cpp:147-184; below that every instance is flattened into one world-space mesh),
+ * 0 always flatten, 1 always two-level. */
+void gcore_set_two_level(int mode);
 /* Batch form (extension; no counterpart in embree_connect.cpp): t_near / t_far may be NULL for 0 / 1e5; returns the number of hits. */
 int  gcore_closest_hit_n(int a_rayNum, const float* a_rayPos3f, const float* a_rayDir3f, const float* t_near, const float* t_far,
                          HitCpp* pHits, unsigned char* pFound);

@@ -470,3 +470,79 @@ def test_gcore_queries_combine_and_batch(art, backend):
     print("gcore queries/s: serial %.0f, 28 threads %.0f, batch of %d %.0f" % (1 / t_serial, 1 / t_threads, n, 1 / t_batch))
     assert t_batch * 50 < t_serial, "a batch must cost far less per ray than one launch per ray"
     L.gcore_destroy()
+
+
+def test_gcore_two_level_instancing_matches_the_flattened_scene(art, backend):
+    """embree_connect.cpp:147-184: one tree per mesh + a tree over the instances (art_instanced.h).  1,000 instances of the 8-triangle
+    pyramid (rotated, scaled, translated): hits against the oracle's brute-force scan of the explicitly transformed two-sided triangles,
+    and against this library's own flattened upload of the same scene.  The triangle test runs in OBJECT space here and in world space
+    there, so t agrees to rounding (1e-5 relative), ids exactly -- except for the handful of rays that graze an edge."""
+    L = backend.lib
+    F = np.float32
+    ident = np.eye(4, dtype=F).ravel(); om = orc.Mesh()
+    assert orc.lib().orc_load_vsgf(orc.PYRAMID_VSGF.encode(), orc.fp(ident), C.byref(om)) == 0
+    pos = np.ctypeslib.as_array(om.pos, (om.nverts, 3)).copy(); idx = np.ctypeslib.as_array(om.idx, (om.ntris, 3)).copy().astype(np.int32)
+    rng = np.random.default_rng(11)
+    n_inst = 1000
+    mats = np.zeros((n_inst, 16), F)
+    for k in range(n_inst):
+        a = rng.random() * 2 * np.pi; s = 0.5 + rng.random()
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]) * s
+        m = np.eye(4); m[:3, :3] = R; m[:3, 3] = rng.random(3) * 40 - 20
+        mats[k] = m.astype(F).ravel()
+
+    def commit(mode):
+        L.gcore_set_two_level(mode)
+        L.gcore_init_and_clear()
+        mid = L.gcore_add_mesh_3f(np.ascontiguousarray(pos).ctypes.data_as(art.f32p), pos.shape[0], np.ascontiguousarray(idx).ctypes.data_as(art.i32p), idx.size)
+        L.gcore_instance_meshes(mid, mats.ctypes.data_as(art.f32p), n_inst)
+        L.gcore_commit_scene()
+
+    n = 6000
+    tgt_inst = rng.integers(0, n_inst, n)
+    centres = mats.reshape(n_inst, 4, 4)[tgt_inst, :3, 3] + np.array([0, 0.15, 0], F)
+    o = (centres + rng.normal(size=(n, 3)) * 6).astype(F)
+    tgt = (centres + (rng.random((n, 3)) - 0.5) * 0.5).astype(F)
+    d = tgt - o; d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(F)
+
+    def query():
+        hits = (art.HitCpp * n)(); found = (C.c_ubyte * n)()
+        L.gcore_closest_hit_n(n, o.ctypes.data_as(art.f32p), d.ctypes.data_as(art.f32p), None, None, hits, found)
+        return (np.array([found[i] for i in range(n)], bool), np.array([hits[i].instIndex for i in range(n)]), np.array([hits[i].primIndex for i in range(n)]),
+                np.array([hits[i].t for i in range(n)], np.float64), np.array([list(hits[i].normal) for i in range(n)]), np.array([list(hits[i].texCoord) for i in range(n)]))
+    try:
+        commit(-1)                      # automatic: 1000 instances -> two-level
+        two = query()
+        commit(0)                       # the same scene flattened: 16,000 world-space triangles
+        flat = query()
+    finally:
+        L.gcore_set_two_level(-1)
+        L.gcore_destroy()
+    # oracle on the flattened mesh (as tests/test_hydra_scene.py builds it)
+    wpos, widx = [], []
+    for k in range(n_inst):
+        m = mats[k].reshape(4, 4)
+        w = np.stack([((m[r, 0] * pos[:, 0] + m[r, 1] * pos[:, 1]).astype(F) + m[r, 2] * pos[:, 2]).astype(F) + m[r, 3] for r in range(3)], 1).astype(F)
+        base = k * pos.shape[0]
+        wpos.append(w)
+        widx.append(np.stack([np.stack([base + idx[:, 0], base + idx[:, 1], base + idx[:, 2]], 1), np.stack([base + idx[:, 0], base + idx[:, 2], base + idx[:, 1]], 1)], 1).reshape(-1, 3))
+    wpos = np.concatenate(wpos); widx = np.concatenate(widx).astype(np.int32)
+    from ada_ray_tracer_amd import scenes
+    mesh = dict(mode=art.MESH_CLOSEST, pos=wpos, nrm=np.zeros_like(wpos), idx=widx, matid=np.ones(widx.shape[0], np.int32))
+    light = [dict(shape=art.LIGHT_SPHERE, mat=4, center=(0.0, 400.5, 1.0), radius=0.5, intensity=(10.0, 10.0, 10.0), surfaceArea=3.14159)]
+    want = orc.closest_hits(conv.OracleScene(art.SceneDesc([], light, scenes.cornell_materials(), [mesh], None, scenes.REFERENCE_CAMERA)).scene, o, d)
+    w_hit = np.array([bool(h.is_hit) and h.t < 100000.0 for h in want]); w_k = np.array([h.prim_index >> 1 for h in want]); w_t = np.array([h.t for h in want], np.float64)
+    # flattened upload == oracle exactly (ids, t bits)
+    assert np.array_equal(flat[0], w_hit) and np.array_equal(flat[1][w_hit], w_k[w_hit] // 8) and np.array_equal(flat[2][w_hit], w_k[w_hit] % 8)
+    assert np.array_equal(flat[3][w_hit].astype(np.float32).view(np.uint32), w_t[w_hit].astype(np.float32).view(np.uint32))
+    # two-level == flattened up to object-space rounding
+    both = two[0] & flat[0]
+    assert (two[0] != flat[0]).sum() <= n // 500, "hit / miss differs on %d rays" % (two[0] != flat[0]).sum()
+    same_id = (two[1] == flat[1]) & (two[2] == flat[2])
+    assert (both & ~same_id).sum() <= n // 500, "another triangle on %d rays" % (both & ~same_id).sum()
+    ok = both & same_id
+    assert ok.sum() > n // 3
+    assert np.abs(two[3][ok] - flat[3][ok]).max() <= 2.0e-5 * np.abs(flat[3][ok]).max()
+    assert np.abs(two[5][ok] - flat[5][ok]).max() < 1.0e-3                                   # barycentrics
+    nn = lambda v: v / np.linalg.norm(v, axis=1, keepdims=True)
+    assert np.abs(nn(two[4][ok]) - nn(flat[4][ok])).max() < 1.0e-4                            # world-space Ng
