@@ -148,11 +148,17 @@ int upload_scene(const ArtSceneDesc* d) {
     }
     // the trace kernel addresses nodes and triangles with 32-bit byte offsets; the 4-wide entry word keeps bit 31 for the leaf flag
     const uint64_t off_limit = (hs.hdr.node_width == 4) ? (1ull << 31) : (1ull << 32);
-    if ((uint64_t)hs.hdr.n_nodes * node_floats(hs.hdr.node_width) * 4 >= (1ull << 32) || (uint64_t)hs.hdr.n_tris * kTriFloats * 4 >= off_limit)
-      return fail("mesh too large: the trace kernel addresses nodes and triangles with 32-bit byte offsets (max ~44M triangles at width 4, ~89M at width 8)");
+    if ((uint64_t)hs.hdr.n_nodes * node_floats(hs.hdr.node_width) * 4 >= (1ull << 32) || (uint64_t)hs.hdr.n_tris * (hs.hdr.node_width == 4 ? kQTriBytes : kTriBytes) >= off_limit)
+      return fail("mesh too large: the trace kernel addresses nodes and triangles with 32-bit byte offsets (max ~33M triangles at width 4, ~89M at width 8)");
     if (hs.hdr.node_width == 4 && hs.hdr.n_nodes > 0 && hs.gpu_built && !c.b_qnodes.p) return fail("internal: GPU build returned no quantised nodes");
     if (dev_stack > kStackEntries) return fail("BVH traversal stack bound " + std::to_string(dev_stack) + " exceeds " + std::to_string(kStackEntries));
     if (upload_scene_arrays(hs)) return 1;
+    c.b_qtris.release();
+    if (hs.hdr.node_width == 4 && hs.hdr.n_tris > 0) {       // 64-byte padded copy of the triangle records for the 4-wide kernel
+      if (ensure(c.b_qtris, (size_t)hs.hdr.n_tris * kQTriBytes)) return 1;
+      launch_pad_tris(c.stream, (const float*)c.b_tris.p, (float*)c.b_qtris.p, hs.hdr.n_tris);
+      HIP_TRY(hipStreamSynchronize(c.stream));
+    }
     c.bvh_stack_bound = std::max(8, dev_stack);
     c.blocks_per_cu = 0;   // re-query occupancy
     c.scene_ready = true;
@@ -240,7 +246,7 @@ static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
   a.node_min = c.node_min; a.segments = c.queue_segments; a.chunk = c.ray_chunk;
   a.ray_ox = q.ray_ox; a.ray_oy = q.ray_oy; a.ray_oz = q.ray_oz; a.ray_dx = q.ray_dx; a.ray_dy = q.ray_dy; a.ray_dz = q.ray_dz; a.ray_tfar = q.ray_tfar;
   a.hit_t = q.hit_t; a.hit_key = q.hit_key; a.hit_u = q.hit_u; a.hit_v = q.hit_v;
-  a.nodes = c.scene.nodes; a.qnodes = (const uint32_t*)c.b_qnodes.p; a.tris = c.scene.tris; a.n_tris = c.scene.n_tris;
+  a.nodes = c.scene.nodes; a.qnodes = (const uint32_t*)c.b_qnodes.p; a.tris = c.scene.tris; a.qtris = (const float*)c.b_qtris.p; a.n_tris = c.scene.n_tris;
   a.sh_min = (c.shadow_anyhit && q.sh_min_t && n_rays > q.P) ? q.sh_min_t : nullptr; a.shadow_begin = q.P;
   a.cursor = c.d_cursor; a.stats = c.d_counters + 3; a.live_rays = c.d_counters;
   a.queue = (int*)c.b_queue.p; a.queue_count = c.d_cursor + 1;
@@ -592,7 +598,7 @@ void shutdown() {
     if (c.device >= 0) (void)hipSetDevice(c.device);
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c.b_spheres, &c.b_sphere_mat, &c.b_lights, &c.b_materials, &c.b_bf_pos, &c.b_bf_nrm, &c.b_bf_uv, &c.b_bf_idx,
-                      &c.b_nodes, &c.b_qnodes, &c.b_tris, &c.b_m_nrm, &c.b_m_uv, &c.b_m_idx, &c.b_m_matid, &c.b_accum, &c.b_screen, &c.b_stage,
+                      &c.b_nodes, &c.b_qnodes, &c.b_tris, &c.b_qtris, &c.b_m_nrm, &c.b_m_uv, &c.b_m_idx, &c.b_m_matid, &c.b_accum, &c.b_screen, &c.b_stage,
                       &c.b_pixmap, &c.b_paths, &c.b_rays, &c.b_ids, &c.b_queue, &c.b_ovf};
     for (DevBuf* b : bufs) b->release();
     if (c.d_cursor) (void)hipFree(c.d_cursor);

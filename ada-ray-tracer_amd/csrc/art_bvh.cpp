@@ -317,7 +317,7 @@ bool build_bvh8(const float* tri9, const int32_t* prim_ids, int32_t n, const Bvh
       }
       if (best < 0) break;
       const Node2 c = B.nodes[ch[best]];
-      ch[best] = c.left; ch.push_back(c.right);
+      ch[best] = c.left; ch.insert(ch.begin() + best + 1, c.right);   // in-order: BVH2 siblings stay neighbours (slots, hence node indices: two 64-byte nodes share an L2 line)
     }
     // a BVH2 leaf with more than kMaxLeafTris triangles cannot occur (max_leaf <= 8 is enforced below)
     float* nd = &N[(size_t)p.n8 * NF];

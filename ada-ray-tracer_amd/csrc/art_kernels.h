@@ -24,7 +24,7 @@ struct TraceArgs {
   // sh_min[i - shadow_begin] = 10*eps.  nullptr: every ray is a closest-hit query.
   const float* sh_min; int32_t shadow_begin;
   float* hit_t; uint32_t* hit_key; float* hit_u; float* hit_v;
-  const float* nodes; const uint32_t* qnodes; const float* tris; int32_t n_tris;   // qnodes: 64-byte quantised nodes (width 4, art_qnode.h)   // BVH of the closest-hit mesh (hot-loop operands)
+  const float* nodes; const uint32_t* qnodes; const float* tris; const float* qtris; int32_t n_tris;   // qnodes: 64-byte quantised nodes (width 4, art_qnode.h)   // BVH of the closest-hit mesh (hot-loop operands)
   int32_t chunk;                // rays a wave claims per atomic on the cursor
   int* cursor;                  // work cursors, zeroed before every launch: segment k's cursor is cursor[32 * (k + 1)] (cursor[0] serves the
                                 // kernels with a single cursor)
@@ -44,6 +44,7 @@ void launch_to_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, in
 void launch_to_xmajor_u32(hipStream_t st, const uint32_t* src, uint32_t* dst, int w, int h);
 void launch_from_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, int h);
 void launch_trace_instanced(hipStream_t st, const InstScene& T, const float* o, const float* d, const float* tfar, int n, InstHit* out);
+void launch_pad_tris(hipStream_t st, const float* src12, float* dst16, int n);
 void launch_add_f32(hipStream_t st, const float* src, float* dst, size_t n);
 size_t trace_coop_lds_bytes(int stack_entries, int width);
 void launch_trace(hipStream_t st, const DevScene* d_scene, const TraceArgs& A, int kernel, bool stats, int grid_blocks);

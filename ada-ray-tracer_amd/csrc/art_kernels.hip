@@ -184,9 +184,9 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
   // kernel-argument bases stay in SGPRs; per-lane addressing is a 32-bit byte offset (scalar base + vector offset loads).
   // art_upload_scene guarantees that node and triangle byte offsets fit (31 bits for G = 4, 32 for G = 8).
   const char* const nodes_b = reinterpret_cast<const char*>(G == 4 ? (const void*)A.qnodes : (const void*)A.nodes);
-  const char* const tris_b = reinterpret_cast<const char*>(A.tris);
+  const char* const tris_b = reinterpret_cast<const char*>(G == 4 ? (const void*)A.qtris : (const void*)A.tris);
   const uint32_t jrec = (G == 4) ? 16u + 12u * (uint32_t)j : 16u * (uint32_t)j;     // this lane's child record inside a node
-  const uint32_t jtri = (uint32_t)j * (uint32_t)kTriBytes;
+  const uint32_t jtri = (uint32_t)j * (uint32_t)(G == 4 ? kQTriBytes : kTriBytes);
   const int n_queue = *A.queue_count;
 
   int chunk_pos = 0, chunk_end = 0;   // wave-uniform
@@ -581,6 +581,14 @@ __global__ __launch_bounds__(256) void k_from_xmajor_f3(const float* src_xmajor,
   dst_rowmajor[3 * s] = src_xmajor[3 * (size_t)i]; dst_rowmajor[3 * s + 1] = src_xmajor[3 * (size_t)i + 1]; dst_rowmajor[3 * s + 2] = src_xmajor[3 * (size_t)i + 2];
 }
 
+// 48-byte triangle records -> 64-byte padded records for the 4-wide trace kernel
+__global__ __launch_bounds__(256) void k_pad_tris(const float* __restrict__ src, float* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 16) return;
+  const int t = i >> 4, k = i & 15;
+  dst[i] = (k < kTriFloats) ? src[(size_t)t * kTriFloats + k] : 0.0f;
+}
+
 // dst[i] += src[i]: the framebuffer sum between two contexts that live on the same physical GPU (multi-device rehearsal; distinct
 // GPUs use the RCCL reduce).  Written as src + dst: adding exact zeros in any order gives the same bits anyway.
 __global__ __launch_bounds__(256) void k_add_f32(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
@@ -623,6 +631,10 @@ void launch_from_xmajor_f3(hipStream_t st, const float* src, float* dst, int w, 
 
 void launch_trace_instanced(hipStream_t st, const InstScene& T, const float* o, const float* d, const float* tfar, int n, InstHit* out) {
   hipLaunchKernelGGL(k_trace_instanced, dim3((n + 63) / 64), dim3(64), 0, st, T, o, d, tfar, n, out);
+}
+
+void launch_pad_tris(hipStream_t st, const float* src, float* dst, int n) {
+  hipLaunchKernelGGL(k_pad_tris, dim3((unsigned)(((size_t)n * 16 + 255) / 256)), dim3(256), 0, st, src, dst, n);
 }
 
 void launch_add_f32(hipStream_t st, const float* src, float* dst, size_t n) {

@@ -9,7 +9,7 @@
 //   bytes  0..15   origin.x origin.y origin.z scale          binary32; scale is a power of two, shared by the three axes
 //   bytes 16+12j   child j:  { qlo.x qlo.y qlo.z qhi.x | qhi.y qhi.z 0 0 | entry }     j = 0..3
 //   entry          inner child: node_index * 64               (bit 31 clear, low 6 bits clear)
-//                  leaf:        0x80000000 | first_triangle * 48 | count   (count 1..4 in the low 4 bits)
+//                  leaf:        0x80000000 | first_triangle * 64 | count   (count 1..4 in the low 4 bits; 64-byte padded triangle records)
 //                  empty slot:  0xffffffff
 //   child box      lo = fma(float(qlo), scale, origin)   hi = fma(float(qhi), scale, origin)      one rounding each
 //
@@ -24,6 +24,7 @@ namespace art {
 constexpr int kQNodeBytes = 64;
 constexpr uint32_t kQEntryEmpty = 0xffffffffu, kQEntryLeaf = 0x80000000u;
 constexpr int kTriBytes = kTriFloats * 4;
+constexpr int kQTriBytes = 64;       // the 4-wide kernel reads triangle records padded to 64 bytes: a record never straddles a 128-byte L2 line
 
 struct QNode { float origin[3]; float scale; uint32_t child[4][3]; };
 static_assert(sizeof(QNode) == kQNodeBytes, "quantised node is 64 bytes");
@@ -76,7 +77,7 @@ ART_HD void quantise_node(float* nd, QNode& q) {
     if (ref < 0) { q.child[j][0] = 0x00ffffffu; q.child[j][1] = 0u; q.child[j][2] = kQEntryEmpty; continue; }   // lo = 255, hi = 0
     q.child[j][0] = ql[j][0] | (ql[j][1] << 8) | (ql[j][2] << 16) | (qh[j][0] << 24);
     q.child[j][1] = qh[j][1] | (qh[j][2] << 8);
-    q.child[j][2] = cnt ? (kQEntryLeaf | ((uint32_t)ref * (uint32_t)kTriBytes) | (uint32_t)cnt) : ((uint32_t)ref * (uint32_t)kQNodeBytes);
+    q.child[j][2] = cnt ? (kQEntryLeaf | ((uint32_t)ref * (uint32_t)kQTriBytes) | (uint32_t)cnt) : ((uint32_t)ref * (uint32_t)kQNodeBytes);
     for (int a = 0; a < 3; ++a) {
       nd[4 * j + a] = __builtin_fmaf((float)ql[j][a], s, o[a]);
       nd[4 * W + 4 * j + a] = __builtin_fmaf((float)qh[j][a], s, o[a]);
