@@ -85,6 +85,10 @@ package Art_Hip is
   function art_init (device_ordinal : int) return int;
   pragma Import (C, art_init, "art_init");
 
+  --  one process, n GPUs of the node (instead of art_init): ordinals = Null_Address means devices 0 .. n-1
+  function art_init_devices (n : int; ordinals : System.Address) return int;
+  pragma Import (C, art_init_devices, "art_init_devices");
+
   function art_upload_scene (scene : access constant Art_Scene_Desc) return int;
   pragma Import (C, art_upload_scene, "art_upload_scene");
 
