@@ -85,6 +85,9 @@ int ensure_device() {
   HIP_TRY(hipGetDeviceProperties(&prop, c.device));
   c.num_cus = prop.multiProcessorCount;
   c.arch = prop.gcnArchName;
+  // LDS per CU: 160 KB on gfx950 (MI355X_MICROARCH.md); the runtime's own figure where it is larger than the per-workgroup 64 KB
+  c.lds_per_cu = (c.arch.rfind("gfx950", 0) == 0) ? 160 * 1024 : std::max<int>(64 * 1024, (int)prop.maxSharedMemoryPerMultiProcessor);
+  c.arch = prop.gcnArchName;
   HIP_TRY(hipMalloc(&c.d_cursor, kCursorInts * sizeof(int)));   // [0] work cursor, [1] live-ray queue length, [2] overflow queue length, [32*k] cursor of queue segment k
   HIP_TRY(hipMalloc(&c.d_counters, 16 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(c.d_counters, 0, 16 * sizeof(unsigned long long)));
@@ -223,7 +226,7 @@ static void carve(DevPaths& q, int P, int depth) {
 // largest size that does; then pushes are checked and the few rays that go deeper are finished by k_trace_overflow.
 static void stack_plan(int kernel, int& entries, bool& overflow) {
   Ctx& c = g_ctx;
-  const int per_block = 160 * 1024 / 8, groups = 64 / c.scene.node_width;
+  const int per_block = c.lds_per_cu / 8, groups = 64 / c.scene.node_width;        // 8 workgroups of 4 waves per CU = 8 waves per SIMD
   (void)kernel;
   int cap = per_block / (4 * groups * 8) - 3;     // entries per ray (+ 2 guard entries + the sink of masked pushes)
   if (c.lds_stack_cap > 0) cap = c.lds_stack_cap;

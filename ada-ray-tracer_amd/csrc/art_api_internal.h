@@ -17,7 +17,7 @@ constexpr int kCursorInts = 32 * 9;   // d_cursor: 3 scalars + one work cursor p
 struct DevBuf { void* p = nullptr; size_t bytes = 0; void release(); };
 
 struct Ctx {
-  int device = -1; bool device_ready = false; int num_cus = 0; std::string arch;
+  int device = -1; bool device_ready = false; int num_cus = 0; int lds_per_cu = 160 * 1024; std::string arch;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;            // multi-device mode: the stream this context created (stream == own_stream)
   // scene

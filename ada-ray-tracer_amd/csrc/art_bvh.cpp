@@ -266,6 +266,8 @@ bool build_bvh8(const float* tri9, const int32_t* prim_ids, int32_t n, const Bvh
     b.grow(t); b.grow(t + 3); b.grow(t + 6);
     for (int a = 0; a < 3; ++a)
       if (!std::isfinite(b.lo[a]) || !std::isfinite(b.hi[a])) { err = "non-finite triangle vertex"; return false; }
+    for (int a = 0; a < 3; ++a)
+      if (std::fabs(b.lo[a]) > 1.0e18f || std::fabs(b.hi[a]) > 1.0e18f) { err = "triangle coordinate beyond 1e18: box extents and the node quantisation need headroom in binary32"; return false; }
     refs[i].box = b; refs[i].tri = i;
   }
   const int64_t budget = (prm.spatial_alpha >= 0.0f) ? (int64_t)((double)prm.spatial_budget * n) : 0;

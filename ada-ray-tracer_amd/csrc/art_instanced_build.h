@@ -1,0 +1,30 @@
+// art_instanced_build.h -- host-side construction of the two-level scene of art_instanced.h (no HIP here: the geometry-core seam
+// uploads the result, the host simulation of the tests walks it on the CPU).
+#pragma once
+#include <string>
+#include <vector>
+#include "art_bvh.h"
+#include "art_instanced.h"
+
+namespace art {
+
+struct InstMeshIn { const float* verts; size_t n_verts; const int32_t* idx; size_t n_tris; };   // object space, 3 floats / 3 indices
+struct InstIn { int32_t mesh; float m[12]; };                                                    // object -> world, 3x4 row-major
+
+struct TwoLevelHost {
+  std::vector<InstRec> inst;            // valid instances (a singular matrix drops its instance)
+  std::vector<int32_t> inst_src;        // inst[k] is the caller's instance inst_src[k]
+  Bvh8 tlas;                            // 4-wide tree over one proxy triangle per instance (its corners span the padded world box)
+  std::vector<float> blas_nodes, blas_tris;
+  InstScene view() const {
+    InstScene S;
+    S.tlas_nodes = tlas.nodes.data(); S.tlas_tris = tlas.tris.data(); S.blas_nodes = blas_nodes.data(); S.blas_tris = blas_tris.data();
+    S.inst = inst.data(); S.n_inst = (int32_t)inst.size(); S.width = 4;
+    return S;
+  }
+};
+
+// one tree per mesh (object space, both windings: record 2t front, 2t+1 back), one tree over the instances' world boxes
+bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vector<InstIn>& insts, TwoLevelHost& out, std::string& err);
+
+}  // namespace art

@@ -28,6 +28,7 @@
 #include <cmath>
 
 #include "art_api_internal.h"
+#include "art_instanced_build.h"
 
 namespace {
 
@@ -35,10 +36,7 @@ namespace {
 constexpr int kTwoLevelMinInstances = 16;
 struct TwoLevel {
   bool on = false;
-  std::vector<art::InstRec> inst;
-  art::Bvh8 tlas;
-  std::vector<float> blas_nodes, blas_tris;
-  std::vector<int32_t> mesh_node_base, mesh_tri_base, mesh_ntris;
+  art::TwoLevelHost host;
   // device copies
   void *d_tlas_nodes = nullptr, *d_tlas_tris = nullptr, *d_blas_nodes = nullptr, *d_blas_tris = nullptr, *d_inst = nullptr;
   void *d_rays = nullptr, *d_hits = nullptr; size_t ray_cap = 0;
@@ -65,20 +63,6 @@ struct GState {
   TwoLevel two;
 } g;
 
-bool invert_3x4(const float m[12], float out[12]) {            // world -> object in binary64, rounded once
-  const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g0 = m[8], h = m[9], i = m[10];
-  const double det = a * (e * i - f * h) - b * (d * i - f * g0) + c * (d * h - e * g0);
-  if (!(std::fabs(det) > 1.0e-300) || !std::isfinite(det)) return false;
-  const double r[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,
-                       (f * g0 - d * i) / det, (a * i - c * g0) / det, (c * d - a * f) / det,
-                       (d * h - e * g0) / det, (b * g0 - a * h) / det, (a * e - b * d) / det};
-  for (int row = 0; row < 3; ++row) {
-    for (int k = 0; k < 3; ++k) out[4 * row + k] = (float)r[3 * row + k];
-    out[4 * row + 3] = (float)-(r[3 * row] * (double)m[3] + r[3 * row + 1] * (double)m[7] + r[3 * row + 2] * (double)m[11]);
-  }
-  return true;
-}
-
 template <typename T> bool to_device(void** p, const std::vector<T>& v) {
   if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (v.empty()) return true;
@@ -86,67 +70,18 @@ template <typename T> bool to_device(void** p, const std::vector<T>& v) {
   return hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess;
 }
 
-// one tree per mesh (object space, both windings), one tree over the instances' world boxes
+// one tree per mesh (object space, both windings), one tree over the instances' world boxes (art_instanced_build.cpp), then to HBM
 bool build_two_level(std::string& err) {
   TwoLevel& T = g.two;
   T.release(); T = TwoLevel();
-  art::BvhBuildParams bp; bp.width = 4;
-  const size_t nm = g.meshes.size();
-  T.mesh_node_base.assign(nm, 0); T.mesh_tri_base.assign(nm, 0); T.mesh_ntris.assign(nm, 0);
-  std::vector<std::array<float, 6>> mesh_box(nm);
-  for (size_t mi = 0; mi < nm; ++mi) {
-    const GMesh& m = g.meshes[mi];
-    const size_t nt = m.idx.size() / 3;
-    std::vector<float> tri9(18 * nt);
-    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
-    for (size_t t = 0; t < nt; ++t) {
-      const float* A = &m.verts[3 * (size_t)m.idx[3 * t]]; const float* B = &m.verts[3 * (size_t)m.idx[3 * t + 1]]; const float* C = &m.verts[3 * (size_t)m.idx[3 * t + 2]];
-      float* f = &tri9[18 * t];
-      std::memcpy(f, A, 12); std::memcpy(f + 3, B, 12); std::memcpy(f + 6, C, 12);          // record 2t:   front winding
-      std::memcpy(f + 9, A, 12); std::memcpy(f + 12, C, 12); std::memcpy(f + 15, B, 12);     // record 2t+1: back winding
-      for (const float* P : {A, B, C}) for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], P[a]); hi[a] = std::max(hi[a], P[a]); }
-    }
-    art::Bvh8 b;
-    if (!art::build_bvh8(tri9.data(), nullptr, (int32_t)(2 * nt), bp, b, err)) return false;
-    T.mesh_node_base[mi] = (int32_t)(T.blas_nodes.size() / art::node_floats(4));
-    T.mesh_tri_base[mi] = (int32_t)(T.blas_tris.size() / art::kTriFloats);
-    T.mesh_ntris[mi] = b.n_tris;
-    T.blas_nodes.insert(T.blas_nodes.end(), b.nodes.begin(), b.nodes.end());
-    T.blas_tris.insert(T.blas_tris.end(), b.tris.begin(), b.tris.end());
-    mesh_box[mi] = {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]};
-  }
-  // proxies: ONE triangle per instance whose corners span exactly the instance's (padded) world box, prim = instance index
-  std::vector<float> proxy9; std::vector<int32_t> proxy_id;
-  for (size_t ii = 0; ii < g.insts.size(); ++ii) {
-    const GInst& in = g.insts[ii];
-    art::InstRec R; std::memset(&R, 0, sizeof R);
-    if (!invert_3x4(in.m, R.minv)) { std::printf("[c_gcore]: instance %d has a singular matrix, skipped\n", (int)ii); continue; }
-    R.node_base = T.mesh_node_base[in.mesh]; R.tri_base = T.mesh_tri_base[in.mesh]; R.n_tris = T.mesh_ntris[in.mesh]; R.mesh = in.mesh;
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    const std::array<float, 6>& mb = mesh_box[in.mesh];
-    for (int corner = 0; corner < 8; ++corner) {
-      const double x = mb[(corner & 1) ? 3 : 0], y = mb[(corner & 2) ? 4 : 1], z = mb[(corner & 4) ? 5 : 2];
-      for (int r = 0; r < 3; ++r) {
-        const double w = (double)in.m[4 * r] * x + (double)in.m[4 * r + 1] * y + (double)in.m[4 * r + 2] * z + (double)in.m[4 * r + 3];
-        lo[r] = std::min(lo[r], w); hi[r] = std::max(hi[r], w);
-      }
-    }
-    float flo[3], fhi[3];
-    for (int r = 0; r < 3; ++r) {        // pad: the ray is taken to object space in binary32, so the world box must not be tight
-      const double pad = 1.0e-4 * (hi[r] - lo[r]) + 1.0e-5 * std::max(std::fabs(lo[r]), std::fabs(hi[r])) + 1.0e-6;
-      flo[r] = (float)(lo[r] - pad); fhi[r] = (float)(hi[r] + pad);
-    }
-    const float p[9] = {flo[0], flo[1], flo[2], fhi[0], fhi[1], fhi[2], flo[0], fhi[1], flo[2]};
-    proxy9.insert(proxy9.end(), p, p + 9);
-    proxy_id.push_back((int32_t)T.inst.size());
-    T.inst.push_back(R);
-    g.tri_inst.push_back((int32_t)ii);   // instance record -> caller's instance index
-  }
-  if (T.inst.empty()) { err = "no valid instances"; return false; }
-  art::BvhBuildParams tp; tp.width = 4; tp.max_leaf = 1;
-  if (!art::build_bvh8(proxy9.data(), proxy_id.data(), (int32_t)proxy_id.size(), tp, T.tlas, err)) return false;
-  if (!to_device(&T.d_tlas_nodes, T.tlas.nodes) || !to_device(&T.d_tlas_tris, T.tlas.tris) || !to_device(&T.d_blas_nodes, T.blas_nodes) ||
-      !to_device(&T.d_blas_tris, T.blas_tris) || !to_device(&T.d_inst, T.inst)) { err = "device upload of the two-level scene failed"; return false; }
+  std::vector<art::InstMeshIn> meshes; std::vector<art::InstIn> insts;
+  for (const GMesh& m : g.meshes) meshes.push_back({m.verts.data(), m.verts.size() / 3, m.idx.data(), m.idx.size() / 3});
+  for (const GInst& in : g.insts) { art::InstIn x; x.mesh = in.mesh; std::memcpy(x.m, in.m, sizeof x.m); insts.push_back(x); }
+  if (!art::build_two_level_host(meshes, insts, T.host, err)) return false;
+  if (T.host.inst.size() != insts.size()) std::printf("[c_gcore]: %d instances with a singular matrix skipped\n", (int)(insts.size() - T.host.inst.size()));
+  g.tri_inst = T.host.inst_src;          // instance record -> caller's instance index
+  if (!to_device(&T.d_tlas_nodes, T.host.tlas.nodes) || !to_device(&T.d_tlas_tris, T.host.tlas.tris) || !to_device(&T.d_blas_nodes, T.host.blas_nodes) ||
+      !to_device(&T.d_blas_tris, T.host.blas_tris) || !to_device(&T.d_inst, T.host.inst)) { err = "device upload of the two-level scene failed"; return false; }
   T.on = true;
   return true;
 }
@@ -317,7 +252,7 @@ void run_batch(Req* const* reqs, size_t n) {
         hipMemcpyAsync(dr + 6 * T.ray_cap, far.data(), m * 4, hipMemcpyHostToDevice, st) != hipSuccess) return;
     art::InstScene S;
     S.tlas_nodes = (const float*)T.d_tlas_nodes; S.tlas_tris = (const float*)T.d_tlas_tris; S.blas_nodes = (const float*)T.d_blas_nodes;
-    S.blas_tris = (const float*)T.d_blas_tris; S.inst = (const art::InstRec*)T.d_inst; S.n_inst = (int32_t)T.inst.size(); S.width = 4;
+    S.blas_tris = (const float*)T.d_blas_tris; S.inst = (const art::InstRec*)T.d_inst; S.n_inst = (int32_t)T.host.inst.size(); S.width = 4;
     art::launch_trace_instanced(st, S, dr, dr + 3 * T.ray_cap, dr + 6 * T.ray_cap, (int)m, (art::InstHit*)T.d_hits);
     std::vector<art::InstHit> ih(m);
     if (hipMemcpyAsync(ih.data(), T.d_hits, m * sizeof(art::InstHit), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return;
@@ -325,7 +260,7 @@ void run_batch(Req* const* reqs, size_t n) {
       Req& r = *reqs[who[k]];
       const art::InstHit& h = ih[k];
       if (h.inst < 0) continue;
-      const art::InstRec& R = T.inst[(size_t)h.inst];
+      const art::InstRec& R = T.host.inst[(size_t)h.inst];
       const GMesh& gm = g.meshes[(size_t)R.mesh];
       const int32_t tri = h.prim >> 1; const bool flipped = (h.prim & 1) != 0;
       const GInst& gi = g.insts[(size_t)g.tri_inst[(size_t)h.inst]];

@@ -8,6 +8,7 @@
 #include <vector>
 #include "../../ada-ray-tracer_amd/csrc/art_host_scene.h"
 #include "../../ada-ray-tracer_amd/csrc/art_shade.h"
+#include "../../ada-ray-tracer_amd/csrc/art_instanced_build.h"
 
 using namespace art;
 
@@ -136,4 +137,21 @@ extern "C" void hs_kat_mat_eval(const ArtMaterial* m, const float l[3], const fl
   f3 b; float pdf;
   bsdf_eval(d, ld3(l), ld3(v), ld3(n), b, pdf);
   out4[0] = b.x; out4[1] = b.y; out4[2] = b.z; out4[3] = pdf;
+}
+
+// ---- two-level (instanced) closest hit of the legacy seam, on the CPU: art_instanced_build.cpp + art_instanced.h, the code the GPU runs
+extern "C" int hs_trace_instanced(const float* verts, int n_verts, const int* idx, int n_tris, const float* matrices16, int n_inst,
+                                  const float* o, const float* d, int n_rays, float tfar, int* out_inst, int* out_prim, float* out_t, float* out_uv) {
+  std::vector<InstMeshIn> meshes = {{verts, (size_t)n_verts, idx, (size_t)n_tris}};
+  std::vector<InstIn> insts((size_t)n_inst);
+  for (int k = 0; k < n_inst; ++k) { insts[k].mesh = 0; std::memcpy(insts[k].m, matrices16 + 16 * (size_t)k, 12 * sizeof(float)); }
+  TwoLevelHost T;
+  if (!build_two_level_host(meshes, insts, T, g_err)) return 1;
+  const InstScene S = T.view();
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int i = 0; i < n_rays; ++i) {
+    const InstHit h = instanced_closest(S, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tfar);
+    out_inst[i] = h.inst < 0 ? -1 : T.inst_src[(size_t)h.inst]; out_prim[i] = h.prim; out_t[i] = h.t; out_uv[2 * i] = h.u; out_uv[2 * i + 1] = h.v;
+  }
+  return 0;
 }

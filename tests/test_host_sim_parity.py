@@ -271,3 +271,54 @@ def test_host_sah_tree_at_bench_scale_is_sound_and_finds_the_brute_force_hits(ar
     hit = b[1] == 1
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3][hit], b[3][hit]) and np.array_equal(bits(a[0][hit]), bits(b[0][hit]))
     assert (b[2] == 2).sum() > nrays // 3
+
+
+def test_two_level_instanced_search_matches_the_flattened_brute_force(art):
+    """csrc/art_instanced.h + art_instanced_build.cpp on the CPU (the code k_trace_instanced runs, embree_connect.cpp:147-184): 300
+    instances of the pyramid, hits against the oracle's brute-force scan of the explicitly transformed two-sided triangles.  The
+    triangle test runs in object space here and in world space there: ids exact apart from edge-grazing rays, t to rounding."""
+    import ctypes as C
+    F = np.float32
+    L = hostsim.lib(art)
+    L.hs_trace_instanced.argtypes = [art.f32p, C.c_int, art.i32p, C.c_int, art.f32p, C.c_int, art.f32p, art.f32p, C.c_int, C.c_float,
+                                     art.i32p, art.i32p, art.f32p, art.f32p]
+    ident = np.eye(4, dtype=F).ravel(); om = orc.Mesh()
+    assert orc.lib().orc_load_vsgf(orc.PYRAMID_VSGF.encode(), orc.fp(ident), C.byref(om)) == 0
+    pos = np.ascontiguousarray(np.ctypeslib.as_array(om.pos, (om.nverts, 3)).copy()); idx = np.ascontiguousarray(np.ctypeslib.as_array(om.idx, (om.ntris, 3)).astype(np.int32))
+    rng = np.random.default_rng(12)
+    n_inst = 300
+    mats = np.zeros((n_inst, 16), F)
+    for k in range(n_inst):
+        a = rng.random() * 2 * np.pi; s = 0.5 + rng.random()
+        m = np.eye(4); m[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]) * s; m[:3, 3] = rng.random(3) * 24 - 12
+        mats[k] = m.astype(F).ravel()
+    mats[7, :12] = 0.0                                   # a singular matrix: that instance can never be hit, and must not break the build
+    n = 3000
+    tgt_inst = rng.integers(0, n_inst, n)
+    centres = mats.reshape(n_inst, 4, 4)[tgt_inst, :3, 3] + np.array([0, 0.15, 0], F)
+    o = (centres + rng.normal(size=(n, 3)) * 5).astype(F)
+    d = (centres + (rng.random((n, 3)) - 0.5) * 0.5).astype(F) - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(F)
+    inst = np.zeros(n, np.int32); prim = np.zeros(n, np.int32); t = np.zeros(n, F); uv = np.zeros((n, 2), F)
+    assert L.hs_trace_instanced(pos.ctypes.data_as(art.f32p), pos.shape[0], idx.ctypes.data_as(art.i32p), idx.shape[0], mats.ctypes.data_as(art.f32p), n_inst,
+                                o.ctypes.data_as(art.f32p), d.ctypes.data_as(art.f32p), n, 100000.0, inst.ctypes.data_as(art.i32p), prim.ctypes.data_as(art.i32p),
+                                t.ctypes.data_as(art.f32p), uv.ctypes.data_as(art.f32p)) == 0, L.hs_last_error()
+    wpos, widx = [], []
+    for k in range(n_inst):
+        m = mats[k].reshape(4, 4)
+        wpos.append(np.stack([((m[r, 0] * pos[:, 0] + m[r, 1] * pos[:, 1]).astype(F) + m[r, 2] * pos[:, 2]).astype(F) + m[r, 3] for r in range(3)], 1).astype(F))
+        base = k * pos.shape[0]
+        widx.append(np.stack([np.stack([base + idx[:, 0], base + idx[:, 1], base + idx[:, 2]], 1), np.stack([base + idx[:, 0], base + idx[:, 2], base + idx[:, 1]], 1)], 1).reshape(-1, 3))
+    wpos = np.concatenate(wpos); widx = np.concatenate(widx).astype(np.int32)
+    from ada_ray_tracer_amd import scenes
+    mesh = dict(mode=art.MESH_CLOSEST, pos=wpos, nrm=np.zeros_like(wpos), idx=widx, matid=np.ones(widx.shape[0], np.int32))
+    light = [dict(shape=art.LIGHT_SPHERE, mat=4, center=(0.0, 400.5, 1.0), radius=0.5, intensity=(10.0, 10.0, 10.0), surfaceArea=3.14159)]
+    want = orc.closest_hits(conv.OracleScene(art.SceneDesc([], light, scenes.cornell_materials(), [mesh], None, scenes.REFERENCE_CAMERA)).scene, o, d)
+    w_hit = np.array([bool(h.is_hit) and h.t < 100000.0 for h in want]); w_rec = np.array([h.prim_index for h in want]); w_t = np.array([h.t for h in want], np.float64)
+    g_hit = inst >= 0
+    assert (g_hit != w_hit).sum() <= n // 500
+    both = g_hit & w_hit
+    same = (inst == w_rec // 16) & (prim == w_rec % 16)          # 16 records per instance: 8 triangles x 2 windings, same order
+    assert (both & ~same).sum() <= n // 500 and (both & same).sum() > n // 3 and not (inst == 7).any()
+    ok = both & same
+    assert np.abs(t[ok] - w_t[ok]).max() <= 2.0e-5 * np.abs(w_t[ok]).max()
