@@ -428,7 +428,7 @@ static int synchronize_one() {
 // there the sum is a chain of local adds in device order, which is the same exact sum.
 static int reduce_accum(const float** out) {
   Ctx& c0 = g_devs[0];
-  if (g_ndev == 1) { *out = c0.ext_accum ? c0.ext_accum : (const float*)c0.b_accum.p; return 0; }
+  if (g_ndev == 1 && !g_comms_ready) { *out = c0.ext_accum ? c0.ext_accum : (const float*)c0.b_accum.p; return 0; }
   const size_t count = (size_t)c0.width * c0.height * 3;
   Dev0Guard guard;
   if (use_dev(0) || ensure(c0.b_reduced, count * 4)) return 1;
@@ -668,7 +668,9 @@ int art_init_devices(int32_t n, const int32_t* ordinals) {
       c.stream = c.own_stream;
     }
   }
-  if (n > 1 && distinct) {
+  // ART_FORCE_RCCL=1: build the communicator for a single device too, so that a 1-GPU box exercises the very RCCL calls of the n-GPU path
+  const bool force_rccl = (n == 1) && getenv("ART_FORCE_RCCL") && std::atoi(getenv("ART_FORCE_RCCL")) != 0;
+  if ((n > 1 && distinct) || force_rccl) {
     const ncclResult_t r = ncclCommInitAll(g_comms, n, ord);
     if (r != ncclSuccess) { shutdown(); return fail(std::string("ncclCommInitAll: ") + ncclGetErrorString(r)); }
     g_comms_ready = true;

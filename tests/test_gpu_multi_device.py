@@ -56,3 +56,43 @@ def test_n_contexts_in_one_process_give_the_single_device_image(art):
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out == {"oracle_equal": True, "one": True, "init_devices_1": True, "three_contexts": True, "eight_contexts": True,
                    "three_contexts_set_shard_refused": True, "eight_contexts_set_shard_refused": True}, out
+
+
+def test_rccl_calls_of_the_n_device_path_run_on_one_device(art):
+    """ART_FORCE_RCCL=1: art_init_devices(1) builds the communicator (ncclCommInitAll) and the framebuffer goes through the grouped
+    ncclReduce into device 0's reduce buffer -- the collective of SURVEY 8(e) with one rank.  Same image as without it."""
+    script = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import __graft_entry__ as ge
+art = ge.load_package()
+from ada_ray_tracer_amd import scenes
+sd = scenes.synthetic_scene(2000, 3)
+p = art.Backend.pass_params(art.PT_MIS, True, 8, 1, seed=9)
+out = []
+for force in ("0", "1"):
+    os.environ["ART_FORCE_RCCL"] = force
+    be = art.Backend(devices=[0])
+    be.upload_scene(sd); be.resize(64, 48)
+    accum, screen, spp = be.render_pass(p, 0, True, True)
+    be.reduce(); be.synchronize()
+    out.append((accum.copy(), screen.copy()))
+    be.shutdown()
+print(json.dumps({"same": bool(np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)) and np.array_equal(out[0][1], out[1][1])), "nonzero": bool(out[1][0].any())}))
+'''
+    r = subprocess.run([sys.executable, "-c", script, art.ROOT], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1]) == {"same": True, "nonzero": True}
+
+
+def test_bench_under_torchrun_with_one_rank(art):
+    """The driver's launch line for N > 1 (python -m torch.distributed.run ... bench.py --gpus N) with one rank: torch.distributed over
+    RCCL, device_id passed to init_process_group, shard + bound accum + dist.reduce."""
+    env = dict(os.environ, ART_BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29517",
+                        os.path.join(art.ROOT, "bench.py"), "--gpus", "1", "--scene", "c3", "--width", "256", "--height", "144", "--steps", "1", "--warmup", "1",
+                        "--vthreads", "1", "--no-cpu"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["metric"] == "Mrays/s" and line["value"] > 0 and line["n_gpus"] == 1
