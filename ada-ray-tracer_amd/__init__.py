@@ -76,7 +76,7 @@ class ArtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("trace_ms", C.c_double), ("pass_ms", C.c_double),
                 ("trace_launches", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("node_visits", C.c_uint64), ("leaf_visits", C.c_uint64), ("traced_rays", C.c_uint64),
-                ("node_phase_iters", C.c_uint64), ("leaf_phase_iters", C.c_uint64), ("wave_iters", C.c_uint64)]
+                ("node_phase_iters", C.c_uint64), ("leaf_phase_iters", C.c_uint64), ("wave_iters", C.c_uint64), ("lost_paths", C.c_uint64)]
 
 
 class ArtHit(C.Structure):

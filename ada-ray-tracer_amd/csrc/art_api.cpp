@@ -204,22 +204,38 @@ static float* accum_ptr() { return g_ctx.ext_accum ? g_ctx.ext_accum : (float*)g
 static int download_from(const float* acc_dev, float* accum_host, uint32_t* screen_host, int layout, int spp);
 
 // path arrays for P slots and `depth` fold levels, carved out of one allocation
-static size_t path_floats(size_t P, int depth) { return (14 + 8 + 3 + 3 + 6 * (size_t)depth + 3 + 3) * P; }
+// Path arrays for P slots and `depth` fold levels, carved out of one allocation.  Hot state (rays, hits, per-path words, item -> slot
+// map: 29 words per item) exists in TWO banks: every bounce reads one and writes the survivors densely into the other (k_shade_compact);
+// cold state (fold stack, terminal value, per-sample radiance, final flags) is indexed by slot.
+static size_t hot_floats(size_t P) { return (14 + 8 + 1 + 1 + 1 + 3 + 1) * P; }
+static size_t path_floats(size_t P, int depth) { return 2 * hot_floats(P) + (6 * (size_t)depth + 3 + 3 + 1) * P; }
 
 static int ensure_paths(size_t P, int depth) { return ensure(g_ctx.b_paths, path_floats(P, depth) * 4 + 256); }
 
-static void carve(DevPaths& q, int P, int depth) {
+// q[0], q[1]: the two banks (slot_id = their own map); both share the cold arrays.  An identity-layout user takes q[0] with slot_id = nullptr
+// and final_flags = flags.
+static void carve(DevPaths q[2], int P, int depth) {
   float* f = (float*)g_ctx.b_paths.p; const size_t p = (size_t)P;
   auto take = [&](size_t n) { float* r = f; f += n; return r; };
-  q.ray_ox = take(2 * p); q.ray_oy = take(2 * p); q.ray_oz = take(2 * p);
-  q.ray_dx = take(2 * p); q.ray_dy = take(2 * p); q.ray_dz = take(2 * p); q.ray_tfar = take(2 * p);
-  q.hit_t = take(2 * p); q.hit_key = (uint32_t*)take(2 * p); q.hit_u = take(2 * p); q.hit_v = take(2 * p);
-  q.prev_pdf = take(p); q.flags = (uint32_t*)take(p); q.sh_min_t = take(p);
-  q.cand_r = take(p); q.cand_g = take(p); q.cand_b = take(p);
-  q.e_r = take(depth * p); q.e_g = take(depth * p); q.e_b = take(depth * p);
-  q.w_r = take(depth * p); q.w_g = take(depth * p); q.w_b = take(depth * p);
-  q.term_r = take(p); q.term_g = take(p); q.term_b = take(p);
-  q.rad_r = take(p); q.rad_g = take(p); q.rad_b = take(p);
+  for (int k = 0; k < 2; ++k) {
+    DevPaths& b = q[k];
+    b.ray_ox = take(2 * p); b.ray_oy = take(2 * p); b.ray_oz = take(2 * p);
+    b.ray_dx = take(2 * p); b.ray_dy = take(2 * p); b.ray_dz = take(2 * p); b.ray_tfar = take(2 * p);
+    b.hit_t = take(2 * p); b.hit_key = (uint32_t*)take(2 * p); b.hit_u = take(2 * p); b.hit_v = take(2 * p);
+    b.prev_pdf = take(p); b.flags = (uint32_t*)take(p); b.sh_min_t = take(p);
+    b.cand_r = take(p); b.cand_g = take(p); b.cand_b = take(p);
+    b.slot_id = (const uint32_t*)take(p);
+  }
+  DevPaths& a = q[0];
+  a.e_r = take(depth * p); a.e_g = take(depth * p); a.e_b = take(depth * p);
+  a.w_r = take(depth * p); a.w_g = take(depth * p); a.w_b = take(depth * p);
+  a.term_r = take(p); a.term_g = take(p); a.term_b = take(p);
+  a.rad_r = take(p); a.rad_g = take(p); a.rad_b = take(p);
+  a.final_flags = (uint32_t*)take(p);
+  DevPaths& c = q[1];
+  c.e_r = a.e_r; c.e_g = a.e_g; c.e_b = a.e_b; c.w_r = a.w_r; c.w_g = a.w_g; c.w_b = a.w_b;
+  c.term_r = a.term_r; c.term_g = a.term_g; c.term_b = a.term_b; c.rad_r = a.rad_r; c.rad_g = a.rad_g; c.rad_b = a.rad_b;
+  c.final_flags = a.final_flags;
 }
 
 // LDS stack per ray: the tree's worst-case bound if 8 workgroups per CU (8 waves per SIMD) still fit in the CU's 160 KB, else the
@@ -254,14 +270,16 @@ static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
   a.cursor = c.d_cursor; a.stats = c.d_counters + 3; a.live_rays = c.d_counters;
   a.queue = (int*)c.b_queue.p; a.queue_count = c.d_cursor + 1;
   a.ovf_queue = (int*)c.b_ovf.p; a.ovf_count = c.d_cursor + 2;
+  a.item_count = nullptr;
 }
 
 // one trace launch, bracketed by HIP events on the launch stream
-static int trace(const DevPaths& q, int n_rays, bool timed = true) {
+static int trace(const DevPaths& q, int n_rays, bool timed = true, const int* item_count = nullptr) {
   Ctx& c = g_ctx;
   const bool coop = (c.trace_kernel == TRACE_COOP);
   if (coop && ensure(c.b_queue, (size_t)n_rays * sizeof(int))) return 1;
   TraceArgs a; fill_trace_args(a, q, n_rays);
+  a.item_count = item_count;
   if (coop && a.stack_overflow && ensure(c.b_ovf, (size_t)n_rays * sizeof(int))) return 1;
   a.ovf_queue = (int*)c.b_ovf.p;
   if (coop) {
@@ -296,6 +314,7 @@ static int collect_timing() {
   HIP_TRY(hipMemcpy(cnt, c.d_counters, sizeof cnt, hipMemcpyDeviceToHost));
   c.stats.node_phase_iters = cnt[8]; c.stats.leaf_phase_iters = cnt[9]; c.stats.wave_iters = cnt[10];
   c.stats.rays = cnt[0];
+  c.stats.lost_paths = cnt[15];
   c.stats.box_tests = cnt[3]; c.stats.tri_tests = cnt[4]; c.stats.node_visits = cnt[5]; c.stats.leaf_visits = cnt[6]; c.stats.traced_rays = cnt[7];
   return 0;
 }
@@ -376,17 +395,44 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
       const int pn = std::min(pc, npix - px0);
       for (int s0 = 0; s0 < S; s0 += sc) {
         const int sn = std::min(sc, S - s0);
-        DevPaths q; std::memset(&q, 0, sizeof q);
-        q.P = pn * sn; q.npix = pn; q.pixmap = (const uint32_t*)c.b_pixmap.p + px0; q.sample_base = (uint32_t)(c.spp + s0);
-        carve(q, q.P, p->max_depth);
-        launch_raygen(c.stream, F, c.scene, q);
-        c.camera_rays += (uint64_t)q.P;
-        for (int b = 0; b < p->max_depth; ++b) {
-          if (trace(q, b == 0 ? q.P : 2 * q.P)) return 1;
-          launch_shade(c.stream, F, c.scene, q, b);
+        DevPaths bank[2]; std::memset(bank, 0, sizeof bank);
+        for (DevPaths& b : bank) { b.P = pn * sn; b.npix = pn; b.pixmap = (const uint32_t*)c.b_pixmap.p + px0; b.sample_base = (uint32_t)(c.spp + s0); }
+        carve(bank, bank[0].P, p->max_depth);
+        c.camera_rays += (uint64_t)bank[0].P;
+        DevPaths q = bank[0];                            // identity layout for raygen / the plain schedule
+        q.slot_id = nullptr;
+        if (c.trace_kernel == TRACE_COOP) {
+          // Compacted work sets: raygen fills bank 0 (one item per slot); stage b shades the items of bank b & 1 and writes the survivors
+          // densely into the other bank, which k_analytic + the trace kernel then serve.  d_live[0] / d_live[32]: the banks' item counts.
+          if (!c.d_live) HIP_TRY(hipMalloc(&c.d_live, 64 * sizeof(int)));
+          launch_raygen(c.stream, F, c.scene, q);
+          if (trace(q, q.P)) return 1;
+          for (int b = 0; b < p->max_depth; ++b) {
+            const int in = b & 1, out = in ^ 1;
+            const DevPaths& qi = (b == 0) ? q : bank[in];
+            HIP_TRY(hipMemsetAsync(c.d_live + 32 * out, 0, sizeof(int), c.stream));
+            launch_shade_compact(c.stream, F, c.scene, qi, bank[out], b, b == 0 ? nullptr : c.d_live + 32 * in, c.d_live + 32 * out,
+                                 const_cast<uint32_t*>(bank[out].slot_id), c.d_counters + 15);
+            if (getenv("ART_DEBUG_LIVE")) {
+              int n = -1; unsigned long long r0 = 0;
+              (void)hipStreamSynchronize(c.stream); (void)hipMemcpy(&n, c.d_live + 32 * out, 4, hipMemcpyDeviceToHost); (void)hipMemcpy(&r0, c.d_counters, 8, hipMemcpyDeviceToHost);
+              std::fprintf(stderr, "stage %d: items out %d of %d, rays so far %llu\n", b, n, q.P, r0);
+            }
+            if (b + 1 < p->max_depth || p->render_type != ART_PT_STUPID) { if (trace(bank[out], 2 * q.P, true, c.d_live + 32 * out)) return 1; }
+          }
+          const int last = p->max_depth & 1;              // the bank the last stage wrote
+          launch_resolve_last(c.stream, bank[last], c.d_live + 32 * last, p->max_depth - 1);
+          launch_fold(c.stream, F, bank[last]);
+        } else {                                          // one-ray-per-lane cross-check kernel: the plain schedule over all slots, in place
+          q.final_flags = q.flags;
+          launch_raygen(c.stream, F, c.scene, q);
+          for (int b = 0; b < p->max_depth; ++b) {
+            if (trace(q, b == 0 ? q.P : 2 * q.P)) return 1;
+            launch_shade(c.stream, F, c.scene, q, b);
+          }
+          if (p->render_type != ART_PT_STUPID) { if (trace(q, 2 * q.P)) return 1; }
+          launch_finish(c.stream, F, q, p->max_depth - 1);
         }
-        if (p->render_type != ART_PT_STUPID) { if (trace(q, 2 * q.P)) return 1; }
-        launch_finish(c.stream, F, q, p->max_depth - 1);
         launch_accumulate(c.stream, F, q, sn, accum_ptr());
         HIP_TRY(hipGetLastError());
       }
@@ -516,9 +562,10 @@ static int debug_pass_one(const ArtPassParams* p, float* accum_host, uint32_t* s
   if (npix > 0 && ensure_paths((size_t)pc, 1)) return 1;
   for (int px0 = 0; px0 < npix; px0 += pc) {
     const int pn = std::min(pc, npix - px0);
-    DevPaths q; std::memset(&q, 0, sizeof q);
-    q.P = pn; q.npix = pn; q.pixmap = (const uint32_t*)c.b_pixmap.p + px0; q.sample_base = 0;
-    carve(q, pn, 1);
+    DevPaths bank[2]; std::memset(bank, 0, sizeof bank);
+    carve(bank, pn, 1);
+    DevPaths q = bank[0];
+    q.P = pn; q.npix = pn; q.pixmap = (const uint32_t*)c.b_pixmap.p + px0; q.sample_base = 0; q.slot_id = nullptr; q.final_flags = q.flags;
     launch_raygen(c.stream, F, c.scene, q);
     c.camera_rays += (uint64_t)pn;
     if (trace(q, pn)) return 1;
@@ -607,6 +654,7 @@ void shutdown() {
     if (c.d_cursor) (void)hipFree(c.d_cursor);
     if (c.d_scene) (void)hipFree(c.d_scene);
     if (c.d_counters) (void)hipFree(c.d_counters);
+    if (c.d_live) (void)hipFree(c.d_live);
     for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : c.pass_events) (void)hipEventDestroy(e);
     c.b_reduced.release();

@@ -32,11 +32,17 @@ struct TraceArgs {
   int* ovf_queue; int* ovf_count;   // stack_overflow: rays handed to k_trace_overflow, count zeroed before every launch
   unsigned long long* stats;    // [box, tri, node, leaf, rays] when counting
   unsigned long long* live_rays;   // += closest-hit queries actually issued by this launch (Mrays/s numerator)
+  const int* item_count;           // compacted work set: items [0, *item_count) exist (rays [0, n) and [shadow_begin, shadow_begin + n)); nullptr: all n_rays
 };
 
 void launch_raygen(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q);
 void launch_shade(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q, int bounce);
 void launch_finish(hipStream_t st, const DevFrame& F, const DevPaths& Q, int last_level);
+// compacted work sets (k_shade_compact): shade the items of Qi, write the survivors densely to Qo (+ their slot ids); n_in nullptr: all Qi.P items
+void launch_shade_compact(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Qi, const DevPaths& Qo, int bounce,
+                          const int* n_in, int* n_out, uint32_t* slot_out, unsigned long long* lost);
+void launch_resolve_last(hipStream_t st, const DevPaths& Q, const int* n, int last_level);
+void launch_fold(hipStream_t st, const DevFrame& F, const DevPaths& Q);
 void launch_accumulate(hipStream_t st, const DevFrame& F, const DevPaths& Q, int samples_in_batch, float* accum);
 void launch_resolve(hipStream_t st, const float* accum, int n_pixels, float norm_c, uint32_t* screen);
 void launch_debug(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q, float* accum, int32_t* prim_index, int32_t* mat_id, int32_t* prim_type);

@@ -417,11 +417,14 @@ __global__ __launch_bounds__(256) void k_analytic(const DevScene* __restrict__ S
   const DevScene& S = *Sp;
   if (threadIdx.x == 0) { s_count = 0; s_live = 0; }
   __syncthreads();
+  // compacted work set: only items [0, *item_count) exist; their extension rays are [0, n), their shadow rays [shadow_begin, shadow_begin + n)
+  const int n_items = A.item_count ? *A.item_count : 0x7fffffff;
   const int chunk0 = blockIdx.x * kAnalyticChunk;
+  if (A.item_count && ((chunk0 >= n_items && chunk0 + kAnalyticChunk <= A.shadow_begin) || chunk0 >= A.shadow_begin + n_items)) return;   // nothing exists in this chunk
   for (int k0 = 0; k0 < kAnalyticChunk; k0 += 256) {
     const int i = chunk0 + k0 + threadIdx.x;
     bool queue_it = false, live = false;
-    if (i < A.n_rays) {
+    if ((i < A.n_rays) && (!A.item_count || ((i < A.shadow_begin) ? (i < n_items) : (i - A.shadow_begin < n_items)))) {
       const float tfar = A.ray_tfar[i];
       if (tfar >= 0.0f) {
         live = true;
@@ -520,6 +523,63 @@ __global__ __launch_bounds__(256) void k_shade(const DevFrame F, const DevScene 
   if (slot < Q.P) shade_slot(F, S, Q, slot, bounce);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_shade_compact: one bounce over a compacted work set.  Every stage reads the items of the paths that still need something (input
+// set `Qi`: rays, hits, per-path state, item -> slot map) and writes only the items that will need something at the next stage to the
+// output set `Qo`, densely: the kernels that follow (k_analytic, the trace kernel's ray fetch, the next shade) then stream full
+// 128-byte lines of live data instead of lines in which a quarter of the slots is alive.  A workgroup handles a chunk of 4096 items:
+// pass 1 decides who survives (item_survives: flags, hit key, material type), one exclusive scan numbers them in item order, ONE global
+// atomic reserves the chunk's range of the output set; pass 2 shades and stores at the reserved positions.
+// ------------------------------------------------------------------------------------------------
+constexpr int kShadeChunk = 4096, kShadePerThread = kShadeChunk / 256;
+
+__global__ __launch_bounds__(256) void k_shade_compact(const DevFrame F, const DevScene S, const DevPaths Qi, const DevPaths Qo, int bounce,
+                                                       const int* __restrict__ n_in_ptr, int* __restrict__ n_out_ptr, uint32_t* __restrict__ slot_out,
+                                                       unsigned long long* lost) {
+  __shared__ int s_cnt[kShadePerThread * 4];      // survivors per (round k, wave)
+  __shared__ int s_base;
+  const int n_in = n_in_ptr ? *n_in_ptr : Qi.P;
+  const int c0 = blockIdx.x * kShadeChunk;
+  if (c0 >= n_in) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t keep_bits = 0;
+  for (int k = 0; k < kShadePerThread; ++k) {
+    const int w = c0 + k * 256 + threadIdx.x;
+    const bool keep = (w < n_in) && item_survives(F, S, Qi, w, bounce);
+    keep_bits |= keep ? (1u << k) : 0u;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+    if (lane == 0) s_cnt[k * 4 + wave] = (int)__popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int total = 0;
+    for (int i = 0; i < kShadePerThread * 4; ++i) { const int c = s_cnt[i]; s_cnt[i] = total; total += c; }
+    s_base = total ? atomicAdd(n_out_ptr, total) : 0;
+  }
+  __syncthreads();
+  const int base = s_base;
+  for (int k = 0; k < kShadePerThread; ++k) {
+    const int w = c0 + k * 256 + threadIdx.x;
+    const bool keep = (keep_bits >> k) & 1u;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+    const int wo = keep ? base + s_cnt[k * 4 + wave] + (int)__popcll(m & ((1ull << lane) - 1ull)) : -1;
+    if (w < n_in) {
+      if (keep) slot_out[wo] = (uint32_t)item_slot(Qi, w);
+      shade_item(F, S, Qi, Qo, w, wo, bounce, lost);
+    }
+  }
+}
+
+// the shadow tests still owed after the last trace, over the last work set; then the fold over all slots
+__global__ __launch_bounds__(256) void k_resolve_last(const DevPaths Q, const int* __restrict__ n_ptr, int last_level) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < *n_ptr) resolve_last_shadow(Q, w, last_level);
+}
+__global__ __launch_bounds__(256) void k_fold(const DevFrame F, const DevPaths Q) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot < Q.P) fold_slot(F, Q, slot);
+}
+
 __global__ __launch_bounds__(256) void k_finish(const DevFrame F, const DevPaths Q, int last_level) {
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot < Q.P) finish_slot(F, Q, slot, last_level);
@@ -606,6 +666,16 @@ void launch_raygen(hipStream_t st, const DevFrame& F, const DevScene& S, const D
 }
 void launch_shade(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q, int bounce) {
   hipLaunchKernelGGL(k_shade, dim3(blocks_for(Q.P)), dim3(256), 0, st, F, S, Q, bounce);
+}
+void launch_shade_compact(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Qi, const DevPaths& Qo, int bounce,
+                          const int* n_in, int* n_out, uint32_t* slot_out, unsigned long long* lost) {
+  hipLaunchKernelGGL(k_shade_compact, dim3((Qi.P + kShadeChunk - 1) / kShadeChunk), dim3(256), 0, st, F, S, Qi, Qo, bounce, n_in, n_out, slot_out, lost);
+}
+void launch_resolve_last(hipStream_t st, const DevPaths& Q, const int* n, int last_level) {
+  hipLaunchKernelGGL(k_resolve_last, dim3(blocks_for(Q.P)), dim3(256), 0, st, Q, n, last_level);
+}
+void launch_fold(hipStream_t st, const DevFrame& F, const DevPaths& Q) {
+  hipLaunchKernelGGL(k_fold, dim3(blocks_for(Q.P)), dim3(256), 0, st, F, Q);
 }
 void launch_finish(hipStream_t st, const DevFrame& F, const DevPaths& Q, int last_level) {
   hipLaunchKernelGGL(k_finish, dim3(blocks_for(Q.P)), dim3(256), 0, st, F, Q, last_level);

@@ -95,6 +95,12 @@ struct DevPaths {
   float* term_r; float* term_g; float* term_b;   // value returned by the deepest PathTrace call
   // per-sample radiance, consumed by the accumulate kernel in the reference's summation order
   float* rad_r; float* rad_g; float* rad_b;      // [samples_in_batch][npix]
+  // Compacted work sets (round 2).  The arrays above the fold stack ("hot" state: rays, hits, prev_pdf, flags, sh_min_t, cand) are
+  // indexed by WORK ITEM; the fold stack, term and rad ("cold") by SLOT.  slot_id maps item -> slot (nullptr: the identity, i.e. the
+  // plain one-item-per-slot layout of raygen, of the one-ray-per-lane schedule and of the host simulation).  final_flags[slot] keeps the
+  // flags word a path ended with (levels recorded, bits 8..) for the fold; with the identity layout it is the flags array itself.
+  const uint32_t* slot_id;
+  uint32_t* final_flags;
 };
 
 constexpr uint32_t FLAG_ALIVE = 1u, FLAG_PREV_SPEC = 2u, FLAG_SHADOW_PENDING = 4u;

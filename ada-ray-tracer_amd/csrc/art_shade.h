@@ -312,133 +312,188 @@ ART_HD void raygen_slot(const DevFrame& f, const DevScene& s, const DevPaths& q,
 }
 
 // ---------------------------------------------------------------- one bounce
-ART_HD void kill_path(const DevPaths& q, int slot, uint32_t fl, int levels, f3 terminal) {
-  q.term_r[slot] = terminal.x; q.term_g[slot] = terminal.y; q.term_b[slot] = terminal.z;
-  q.flags[slot] = (fl & ~(FLAG_ALIVE | 0xffffff00u)) | ((uint32_t)levels << 8);
-  q.ray_tfar[slot] = -1.0f;
+// Work items and slots (art_scene.h): item w of the INPUT set `qi` is path slot item_slot(qi, w); what the path needs for its next
+// bounce is written to item `wo` of the OUTPUT set `qo` (wo < 0: the path is known to need nothing more).  With qi == qo and wo == w
+// (identity layout) this is the plain in-place update; all reads of an item happen before its writes.
+ART_HD int item_slot(const DevPaths& q, int w) { return q.slot_id ? (int)q.slot_id[w] : w; }
+
+// Will item w still need an item after shade_item(bounce)?  (It will if the path goes on, or if it emits a shadow ray whose test is
+// resolved at the next stage.)  Used to number the output items before shading; it must never say no where shade_item says yes --
+// shade_item reports that case (lost != nullptr) -- while a needless yes only costs an idle item.
+ART_HD bool item_survives(const DevFrame& f, const DevScene& s, const DevPaths& qi, int w, int bounce) {
+  const uint32_t fl = qi.flags[w];
+  if (!(fl & FLAG_ALIVE)) return false;                       // only owed a shadow test: resolved now
+  const uint32_t key = qi.hit_key[w];
+  if (key == KEY_MISS) return false;
+  const uint32_t cls = key & ~KEY_INDEX_MASK, idx = key & KEY_INDEX_MASK;
+  int32_t mat;
+  if (cls == KEY_SPHERE) mat = s.sphere_mat[idx];
+  else if (cls == KEY_CORNELL) mat = s.cb_mat[idx];
+  else if (cls == KEY_QUAD) mat = s.lights[idx].mat;
+  else if (cls == KEY_BFTRI) mat = 2;
+  else mat = s.m_matid[idx];
+  if (mat < 0 || mat >= s.n_materials) return false;
+  const int32_t type = s.materials[mat].type;
+  if (type == MAT_NULL || type == MAT_LIGHT) return false;
+  return (f.render_type != PT_STUPID) || (bounce + 1 < f.max_depth);
 }
 
-ART_HD void resolve_pending_shadow(const DevPaths& q, int slot, uint32_t& fl, int level) {
-  if (!(fl & FLAG_SHADOW_PENDING)) return;
-  const size_t si = (size_t)q.P + slot;
-  // Compute_Shadow: hit and t < maxDist - eps2 (enforced by the ray's tfar clip) and t > 10*eps
-  const bool in_shadow = (q.hit_key[si] != KEY_MISS) && (q.hit_t[si] > q.sh_min_t[slot]);
-  const size_t li = (size_t)level * q.P + slot;
-  q.e_r[li] = in_shadow ? 0.0f : q.cand_r[slot];
-  q.e_g[li] = in_shadow ? 0.0f : q.cand_g[slot];
-  q.e_b[li] = in_shadow ? 0.0f : q.cand_b[slot];
-  q.ray_tfar[si] = -1.0f;
-  fl &= ~FLAG_SHADOW_PENDING;
-}
-
-ART_HD void shade_slot(const DevFrame& f, const DevScene& s, const DevPaths& q, int slot, int bounce) {
-  uint32_t fl = q.flags[slot];
-  resolve_pending_shadow(q, slot, fl, bounce - 1);
-  if (!(fl & FLAG_ALIVE)) { q.flags[slot] = fl; return; }
-
-  const uint32_t key = q.hit_key[slot];
+ART_HD void shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, const DevPaths& qo, int w, int wo, int bounce, unsigned long long* lost = nullptr) {
+  const int slot = item_slot(qi, w);
+  const size_t P = (size_t)qi.P;
+  uint32_t fl = qi.flags[w];
+  // ---- everything the item holds is read first
+  const uint32_t key = qi.hit_key[w];
+  const f3 o = mk3(qi.ray_ox[w], qi.ray_oy[w], qi.ray_oz[w]);
+  const f3 d = mk3(qi.ray_dx[w], qi.ray_dy[w], qi.ray_dz[w]);
+  const float t = qi.hit_t[w], hu = qi.hit_u[w], hv = qi.hit_v[w];
+  const float prev_pdf = qi.prev_pdf[w];
+  if (fl & FLAG_SHADOW_PENDING) {
+    // Compute_Shadow: hit and t < maxDist - eps2 (enforced by the ray's tfar clip) and t > 10*eps
+    const size_t si = P + (size_t)w;
+    const bool in_shadow = (qi.hit_key[si] != KEY_MISS) && (qi.hit_t[si] > qi.sh_min_t[w]);
+    const size_t li = (size_t)(bounce - 1) * P + (size_t)slot;
+    qi.e_r[li] = in_shadow ? 0.0f : qi.cand_r[w];
+    qi.e_g[li] = in_shadow ? 0.0f : qi.cand_g[w];
+    qi.e_b[li] = in_shadow ? 0.0f : qi.cand_b[w];
+    fl &= ~FLAG_SHADOW_PENDING;
+  }
+  // ---- what the output item will hold
+  bool alive = (fl & FLAG_ALIVE) != 0u, shadow = false;
+  f3 no = o, nd = d, so = o, sd = d;
+  float s_tfar = -1.0f, sh_min = 0.0f, new_pdf = prev_pdf;
+  f3 cand = mk3(0.0f, 0.0f, 0.0f);
   const f3 zero = mk3(0.0f, 0.0f, 0.0f);
-  if (key == KEY_MISS) { kill_path(q, slot, fl, bounce, zero); return; }            // integrators.adb:218-220
-
-  const f3 o = mk3(q.ray_ox[slot], q.ray_oy[slot], q.ray_oz[slot]);
-  const f3 d = mk3(q.ray_dx[slot], q.ray_dy[slot], q.ray_dz[slot]);
-  const float t = q.hit_t[slot];
-  const Surface sf = surface_at(s, o, d, t, key, q.hit_u[slot], q.hit_v[slot]);
-  if (sf.mat < 0 || sf.mat >= s.n_materials) { kill_path(q, slot, fl, bounce, zero); return; }
-  const DevMaterial m = s.materials[sf.mat];
-  if (m.type == MAT_NULL) { kill_path(q, slot, fl, bounce, zero); return; }
-  const f3 n = sf.normal;
-  const float sel_pdf = 1.0f / (float)s.n_lights;
-
-  if (m.type == MAT_LIGHT) {                                                         // :102-108 / :155-157 / :222-247
-    f3 out = zero;
-    if (f.render_type != PT_SHADOW && !(dot(neg(d), n) < 0.0f)) {
-      const f3 emit = (m.light >= 0 && m.light < s.n_lights) ? ld3(s.lights[m.light].intensity) : zero;
-      if (f.render_type == PT_STUPID) out = emit;
-      else {
-        float mis = 1.0f;
-        if (!(fl & FLAG_PREV_SPEC)) {
-          const float lp = light_eval_pdf(s.lights[m.light], o, d, t) * sel_pdf;
-          const float bp = q.prev_pdf[slot];
-          mis = bp * bp / (lp * lp + bp * bp);
+  auto kill = [&](int levels, f3 terminal) {       // the deepest PathTrace call returned `terminal`; `levels` fold levels were recorded
+    qi.term_r[slot] = terminal.x; qi.term_g[slot] = terminal.y; qi.term_b[slot] = terminal.z;
+    fl = (fl & ~(FLAG_ALIVE | 0xffffff00u)) | ((uint32_t)levels << 8);
+    qi.final_flags[slot] = fl;
+    alive = false;
+  };
+  if (alive) {
+    const Surface sf = (key != KEY_MISS) ? surface_at(s, o, d, t, key, hu, hv) : Surface{zero, -1, -1};
+    const bool mat_ok = (key != KEY_MISS) && sf.mat >= 0 && sf.mat < s.n_materials;
+    const DevMaterial m = mat_ok ? s.materials[sf.mat] : DevMaterial{MAT_NULL, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
+    if (!mat_ok || m.type == MAT_NULL) kill(bounce, zero);                            // integrators.adb:218-220
+    else if (m.type == MAT_LIGHT) {                                                   // :102-108 / :155-157 / :222-247
+      const f3 n = sf.normal;
+      const float sel_pdf = 1.0f / (float)s.n_lights;
+      f3 out = zero;
+      if (f.render_type != PT_SHADOW && !(dot(neg(d), n) < 0.0f)) {
+        const f3 emit = (m.light >= 0 && m.light < s.n_lights) ? ld3(s.lights[m.light].intensity) : zero;
+        if (f.render_type == PT_STUPID) out = emit;
+        else {
+          float mis = 1.0f;
+          if (!(fl & FLAG_PREV_SPEC)) {
+            const float lp = light_eval_pdf(s.lights[m.light], o, d, t) * sel_pdf;
+            const float bp = prev_pdf;
+            mis = bp * bp / (lp * lp + bp * bp);
+          }
+          out = emit * mis;
         }
-        out = emit * mis;
       }
-    }
-    kill_path(q, slot, fl, bounce, out);
-    return;
-  }
-
-  uint32_t pixel, sample;
-  slot_to_sample(q, slot, pixel, sample);
-  const u4 rnd = philox4x32_10(pixel, sample, (uint32_t)bounce, 0u, f.seed_lo, f.seed_hi);
-  const f3 hpos = o + d * t;
-  const size_t li = (size_t)bounce * q.P + slot;
-
-  if (f.render_type != PT_STUPID) {                                                  // explicit light sampling :159-178 / :251-287
-    int light = 0;
-    if (s.n_lights > 1) {
-      const u4 r1 = philox4x32_10(pixel, sample, (uint32_t)bounce, 1u, f.seed_lo, f.seed_hi);
-      light = (int)(u01(r1.x) * (float)s.n_lights);
-      if (light > s.n_lights - 1) light = s.n_lights - 1;
-    }
-    const LightSample ls = light_sample(s.lights[light], u01(rnd.x), u01(rnd.y), hpos);
-    const f3 sdir = normalize(ls.pos - hpos);
-    const float lp = ls.pdf * sel_pdf;
-    f3 bx; float bp;
-    bsdf_eval(m, sdir, neg(d), n, bx, bp);
-    const float c1 = amax(dot(sdir, n), 0.0f);
-    f3 cand;
-    if (f.render_type == PT_MIS) {
-      const float mis = lp * lp / (lp * lp + bp * bp);
-      cand = ((ls.intensity * (1.0f / amax(lp, kGEpsilonDiv))) * (c1 * bx)) * mis;
+      kill(bounce, out);
     } else {
-      cand = (ls.intensity * (c1 * bx)) * (1.0f / amax(lp, kGEpsilonDiv));
+      const f3 n = sf.normal;
+      const float sel_pdf = 1.0f / (float)s.n_lights;
+      uint32_t pixel, sample;
+      slot_to_sample(qi, slot, pixel, sample);
+      const u4 rnd = philox4x32_10(pixel, sample, (uint32_t)bounce, 0u, f.seed_lo, f.seed_hi);
+      const f3 hpos = o + d * t;
+      const size_t li = (size_t)bounce * P + (size_t)slot;
+      if (f.render_type != PT_STUPID) {                                                // explicit light sampling :159-178 / :251-287
+        int light = 0;
+        if (s.n_lights > 1) {
+          const u4 r1 = philox4x32_10(pixel, sample, (uint32_t)bounce, 1u, f.seed_lo, f.seed_hi);
+          light = (int)(u01(r1.x) * (float)s.n_lights);
+          if (light > s.n_lights - 1) light = s.n_lights - 1;
+        }
+        const LightSample ls = light_sample(s.lights[light], u01(rnd.x), u01(rnd.y), hpos);
+        const f3 sdir = normalize(ls.pos - hpos);
+        const float lp = ls.pdf * sel_pdf;
+        f3 bx; float bp;
+        bsdf_eval(m, sdir, neg(d), n, bx, bp);
+        const float c1 = amax(dot(sdir, n), 0.0f);
+        if (f.render_type == PT_MIS) {
+          const float mis = lp * lp / (lp * lp + bp * bp);
+          cand = ((ls.intensity * (1.0f / amax(lp, kGEpsilonDiv))) * (c1 * bx)) * mis;
+        } else {
+          cand = (ls.intensity * (c1 * bx)) * (1.0f / amax(lp, kGEpsilonDiv));
+        }
+        // Compute_Shadow (ray_tracer.adb:100-132): the closest hit of this ray decides visibility
+        float eps = amax3(fabsf(hpos.x), fabsf(hpos.y), fabsf(hpos.z)) * 0.000000001f;
+        eps = amax(eps, 1.0e-30f);
+        sd = normalize(ls.pos - hpos);
+        so = hpos + sd * eps;
+        const float max_dist = length(hpos - ls.pos);
+        const float eps2 = amax(max_dist * 0.000001f, 1.0e-30f);
+        // a NaN / negative bound can never be "in shadow": emit the ray with an empty interval
+        const float bound = max_dist - eps2;
+        s_tfar = (bound > 0.0f) ? bound : 0.0f;
+        sh_min = 10.0f * eps;
+        shadow = true;
+        fl |= FLAG_SHADOW_PENDING;
+      } else {
+        qi.e_r[li] = 0.0f; qi.e_g[li] = 0.0f; qi.e_b[li] = 0.0f;
+      }
+      const BsdfSample bs = bsdf_sample(m, u01(rnd.z), u01(rnd.w), d, n);                // :116-124 / :183-191 / :291-299
+      const f3 bxv = bs.color * (1.0f / amax(bs.pdf, kGEpsilonDiv));
+      const float ct = dot(bs.dir, n);
+      no = hpos + (asign(ct) * n) * kGEpsilon;
+      nd = bs.dir;
+      const f3 wv = fabsf(ct) * bxv;
+      qi.w_r[li] = wv.x; qi.w_g[li] = wv.y; qi.w_b[li] = wv.z;
+      new_pdf = bs.pdf;
+      fl = bs.specular ? (fl | FLAG_PREV_SPEC) : (fl & ~FLAG_PREV_SPEC);
+      if (bounce + 1 >= f.max_depth) kill(bounce + 1, zero);                             // next level returns 0 untraced (:212-214)
     }
-    // Compute_Shadow (ray_tracer.adb:100-132): the closest hit of this ray decides visibility
-    float eps = amax3(fabsf(hpos.x), fabsf(hpos.y), fabsf(hpos.z)) * 0.000000001f;
-    eps = amax(eps, 1.0e-30f);
-    const f3 sd = normalize(ls.pos - hpos);
-    const f3 so = hpos + sd * eps;
-    const float max_dist = length(hpos - ls.pos);
-    const float eps2 = amax(max_dist * 0.000001f, 1.0e-30f);
-    const size_t si = (size_t)q.P + slot;
-    q.ray_ox[si] = so.x; q.ray_oy[si] = so.y; q.ray_oz[si] = so.z;
-    q.ray_dx[si] = sd.x; q.ray_dy[si] = sd.y; q.ray_dz[si] = sd.z;
-    // a NaN / negative bound can never be "in shadow": emit the ray with an empty interval
-    const float bound = max_dist - eps2;
-    q.ray_tfar[si] = (bound > 0.0f) ? bound : 0.0f;
-    q.sh_min_t[slot] = 10.0f * eps;
-    q.cand_r[slot] = cand.x; q.cand_g[slot] = cand.y; q.cand_b[slot] = cand.z;
-    fl |= FLAG_SHADOW_PENDING;
-  } else {
-    q.e_r[li] = 0.0f; q.e_g[li] = 0.0f; q.e_b[li] = 0.0f;
   }
-
-  const BsdfSample bs = bsdf_sample(m, u01(rnd.z), u01(rnd.w), d, n);                // :116-124 / :183-191 / :291-299
-  const f3 bxv = bs.color * (1.0f / amax(bs.pdf, kGEpsilonDiv));
-  const float ct = dot(bs.dir, n);
-  const f3 no = hpos + (asign(ct) * n) * kGEpsilon;
-  const f3 w = fabsf(ct) * bxv;
-  q.w_r[li] = w.x; q.w_g[li] = w.y; q.w_b[li] = w.z;
-  q.prev_pdf[slot] = bs.pdf;
-  fl = bs.specular ? (fl | FLAG_PREV_SPEC) : (fl & ~FLAG_PREV_SPEC);
-
-  if (bounce + 1 >= f.max_depth) {                                                    // next level returns 0 untraced (:212-214)
-    kill_path(q, slot, fl, bounce + 1, zero);
+  // ---- the output item
+  if (wo < 0) {
+    if (lost != nullptr && (alive || shadow)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      atomicAdd(lost, 1ull);
+#endif
+    }
     return;
   }
-  q.ray_ox[slot] = no.x; q.ray_oy[slot] = no.y; q.ray_oz[slot] = no.z;
-  q.ray_dx[slot] = bs.dir.x; q.ray_dy[slot] = bs.dir.y; q.ray_dz[slot] = bs.dir.z;
-  q.ray_tfar[slot] = kInfinity;
-  q.flags[slot] = fl;
+  const size_t so_i = (size_t)qo.P + (size_t)wo;
+  qo.flags[wo] = fl;
+  qo.prev_pdf[wo] = new_pdf;
+  qo.ray_tfar[wo] = alive ? kInfinity : -1.0f;
+  if (alive) {
+    qo.ray_ox[wo] = no.x; qo.ray_oy[wo] = no.y; qo.ray_oz[wo] = no.z;
+    qo.ray_dx[wo] = nd.x; qo.ray_dy[wo] = nd.y; qo.ray_dz[wo] = nd.z;
+  }
+  qo.ray_tfar[so_i] = s_tfar;
+  if (shadow) {
+    qo.ray_ox[so_i] = so.x; qo.ray_oy[so_i] = so.y; qo.ray_oz[so_i] = so.z;
+    qo.ray_dx[so_i] = sd.x; qo.ray_dy[so_i] = sd.y; qo.ray_dz[so_i] = sd.z;
+    qo.sh_min_t[wo] = sh_min;
+    qo.cand_r[wo] = cand.x; qo.cand_g[wo] = cand.y; qo.cand_b[wo] = cand.z;
+  }
 }
 
-// after the last trace: resolve the last shadow test and fold  L = e_k + w_k * L  from the deepest level out
-ART_HD void finish_slot(const DevFrame& f, const DevPaths& q, int slot, int last_level) {
-  uint32_t fl = q.flags[slot];
-  resolve_pending_shadow(q, slot, fl, last_level);
-  const int levels = (int)(fl >> 8);
+// the plain layout: one item per slot, updated in place
+ART_HD void shade_slot(const DevFrame& f, const DevScene& s, const DevPaths& q, int slot, int bounce) { shade_item(f, s, q, q, slot, slot, bounce); }
+
+// after the last trace: resolve the shadow test item w still owes ...
+ART_HD void resolve_last_shadow(const DevPaths& q, int w, int last_level) {
+  const uint32_t fl = q.flags[w];
+  if (!(fl & FLAG_SHADOW_PENDING)) return;
+  const int slot = item_slot(q, w);
+  const size_t si = (size_t)q.P + (size_t)w;
+  const bool in_shadow = (q.hit_key[si] != KEY_MISS) && (q.hit_t[si] > q.sh_min_t[w]);
+  const size_t li = (size_t)last_level * (size_t)q.P + (size_t)slot;
+  q.e_r[li] = in_shadow ? 0.0f : q.cand_r[w];
+  q.e_g[li] = in_shadow ? 0.0f : q.cand_g[w];
+  q.e_b[li] = in_shadow ? 0.0f : q.cand_b[w];
+  q.flags[w] = fl & ~FLAG_SHADOW_PENDING;
+}
+
+// ... and fold  L = e_k + w_k * L  from the deepest level out (the levels a path recorded are in the flags word it ended with)
+ART_HD void fold_slot(const DevFrame& f, const DevPaths& q, int slot) {
+  const int levels = (int)(q.final_flags[slot] >> 8);
   f3 L = mk3(q.term_r[slot], q.term_g[slot], q.term_b[slot]);
   for (int k = levels - 1; k >= 0; --k) {
     const size_t li = (size_t)k * q.P + slot;
@@ -447,7 +502,11 @@ ART_HD void finish_slot(const DevFrame& f, const DevPaths& q, int slot, int last
     else L = mk3(q.e_r[li], q.e_g[li], q.e_b[li]) + w * L;
   }
   q.rad_r[slot] = L.x; q.rad_g[slot] = L.y; q.rad_b[slot] = L.z;
-  q.flags[slot] = fl;
+}
+
+ART_HD void finish_slot(const DevFrame& f, const DevPaths& q, int slot, int last_level) {     // plain layout: both steps per slot
+  resolve_last_shadow(q, slot, last_level);
+  fold_slot(f, q, slot);
 }
 
 // DoPass accumulation (integrators.adb:42-52 / :60-64) for one local pixel, in sample order

@@ -112,6 +112,7 @@ typedef struct ArtStats {
   uint64_t trace_launches;
   uint64_t box_tests, tri_tests, node_visits, leaf_visits, traced_rays;  /* only filled by art_trace_rays(stats) / option count_tests */
   uint64_t node_phase_iters, leaf_phase_iters, wave_iters;               /* cooperative kernel: wave-level loop counters (count_tests) */
+  uint64_t lost_paths;      /* self-check of the compacted work sets: paths that needed an item and had none; must stay 0 */
 } ArtStats;
 
 typedef struct ArtHit {          /* geometry.ads:57-67 flattened */

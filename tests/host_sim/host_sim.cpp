@@ -75,6 +75,7 @@ extern "C" int hs_render(const ArtSceneDesc* sd, const ArtPassParams* p, int w, 
   q.prev_pdf = take(pp); q.flags = (uint32_t*)take(pp); q.sh_min_t = take(pp); q.cand_r = take(pp); q.cand_g = take(pp); q.cand_b = take(pp);
   q.e_r = take(D * pp); q.e_g = take(D * pp); q.e_b = take(D * pp); q.w_r = take(D * pp); q.w_g = take(D * pp); q.w_b = take(D * pp);
   q.term_r = take(pp); q.term_g = take(pp); q.term_b = take(pp); q.rad_r = take(pp); q.rad_g = take(pp); q.rad_b = take(pp);
+  q.slot_id = nullptr; q.final_flags = q.flags;            // identity layout: one item per slot, updated in place
   unsigned long long rays = 0;
   auto trace = [&](int nr) {
 #pragma omp parallel for schedule(dynamic, 1024) reduction(+ : rays)

@@ -21,7 +21,7 @@ def test_struct_layouts_match_the_header(art):
     assert C.sizeof(art.ArtMaterial) == 40 and C.sizeof(art.ArtSphere) == 20 and C.sizeof(art.ArtLight) == 76
     assert C.sizeof(art.ArtPassParams) == 48 and art.ArtPassParams.seed.offset == 32
     assert C.sizeof(art.ArtHit) == 44
-    assert C.sizeof(art.ArtStats) == 13 * 8
+    assert C.sizeof(art.ArtStats) == 14 * 8
 
 
 def test_no_cpu_fallback(art):
