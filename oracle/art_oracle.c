@@ -8,7 +8,10 @@
  * plain IEEE inf/NaN propagation.
  *
  * Parity: UNPINNED at bit level vs the Ada binary (GNAT RNG + elementary functions are not in
- * the reference tree); pinned statistically against the reference's image.png.  See header.
+ * the reference tree, and the reference holds no golden vectors).  Pinned as far as the reference allows:
+ * statistically against the reference's own output picture image.png AS A WHOLE (64 x 64 block means + 18 named regions, rendered
+ * from the picture's camera: tests/picture_pin.py, tests/test_oracle_image_pin.py), and bit for bit against an independent
+ * numpy-float32 transcription of lights.adb / materials.adb / the sampling helpers (tests/ada_transcription.py, tests/test_sampling_kat.py).
  */
 #include "art_oracle.h"
 

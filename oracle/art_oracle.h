@@ -21,9 +21,14 @@
  *     transcendental functions defined below (double-precision kernels,
  *     rounded once to float).
  *   - What IS pinned: data/pyramid2.vsgf decode (tests/golden), the hard-coded
- *     scene constants of scene.adb, and the reference's own output picture
- *     image.png, against which the oracle's converged render of the internal
- *     Cornell scene is compared statistically (tests/test_oracle_image_pin.py).
+ *     scene constants of scene.adb; the reference's own output picture image.png
+ *     AS A WHOLE -- it is the HEAD scene seen from (0, 2.55, 11): the oracle's
+ *     render from there matches it block by block (0.33 LDR levels mean on
+ *     16x16-pixel block means) and in 18 named regions (glass, Phong, caustic,
+ *     pyramid, light, walls; tests/picture_pin.py, tests/test_oracle_image_pin.py);
+ *     and the sampling code (lights.adb, materials.adb, vector_math.adb helpers)
+ *     bit for bit against an independent numpy-float32 transcription of the Ada
+ *     text (tests/ada_transcription.py, tests/test_sampling_kat.py).
  */
 #ifndef ART_ORACLE_H
 #define ART_ORACLE_H
