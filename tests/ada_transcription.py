@@ -307,3 +307,213 @@ def phong_eval(refl, pw, l, v, n):
 
 def lambert_eval(kd, l, v, n):
     return scale(INV_PI, kd), amax(dot(n, l), f(0)) * INV_PI
+
+
+# ================================================================================================ geometry.adb / scene.adb
+# Independent transcription of the intersectors and of the three integrators, again straight from the Ada text:
+#   geometry.adb:48-115 (spheres), :118-143 (flat light), :146-191 (box), :193-229 (Cornell box), :231-263 (triangle), :266-323 (mesh BF)
+#   scene.adb:56-86 (Find_Closest_Hit), ray_tracer.adb:61-132 (camera rays, Compute_Shadow), ray_tracer-integrators.adb:82-301
+# A scene is a dict: spheres [(pos, r, mat)], cornell {min, max, mat[6], nrm[6]}, light {..}, materials [{type, ...}], mesh {pos, nrm, idx, bbmin, bbmax}.
+def intersect_all_spheres(o, d, spheres):
+    min_t = INFINITY; min_i = 0
+    for i, (c, r, _) in enumerate(spheres):
+        k = sub(o, c)
+        b = dot(k, d)
+        cc = dot(k, k) - r * r
+        disc = b * b - cc
+        if disc >= 0:
+            sq = sqrt(disc)
+            t1 = -b - sq; t2 = -b + sq
+            if t1 > 0 and t1 < min_t:
+                min_t = t1; min_i = i
+            elif t2 > 0 and t2 < min_t:
+                min_t = t2; min_i = i
+    is_hit = bool(min_t > 0 and min_t < INFINITY)
+    normal = V(0, 1, 0)
+    if not is_hit:
+        min_t = f(1)
+    else:
+        normal = normalize(sub(add(o, scale(min_t, d)), spheres[min_i][0]))
+    return dict(is_hit=is_hit, t=min_t, normal=normal, mat=spheres[min_i][2], prim=("sphere", min_i))
+
+
+def intersect_box(o, d, bmin, bmax):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ix, iy, iz = f(1) / d[0], f(1) / d[1], f(1) / d[2]
+        lo, hi = (bmax[0] - o[0]) * ix, (bmin[0] - o[0]) * ix
+        lo1, hi1 = (bmax[1] - o[1]) * iy, (bmin[1] - o[1]) * iy
+        lo2, hi2 = (bmax[2] - o[2]) * iz, (bmin[2] - o[2]) * iz
+    tmin, tmax = amin(lo, hi), amax(lo, hi)
+    tmin = amax(tmin, amin(lo1, hi1)); tmax = amin(tmax, amax(lo1, hi1))
+    tmin = amax(tmin, amin(lo2, hi2)); tmax = amin(tmax, amax(lo2, hi2))
+    return bool(tmax > 0 and tmin <= tmax), tmin, tmax
+
+
+def intersect_cornell(o, d, cb):
+    hit, _, tmax = intersect_box(o, d, cb["min"], cb["max"])
+    if not hit:
+        return dict(is_hit=False, t=f(0))
+    p = add(o, scale(tmax, d))
+    eps = f(1.0e-5); plane = 0
+    if abs(p[0] - cb["min"][0]) < eps: plane = 0
+    if abs(p[0] - cb["max"][0]) < eps: plane = 1
+    if abs(p[1] - cb["min"][1]) < eps: plane = 2
+    if abs(p[1] - cb["max"][1]) < eps: plane = 3
+    if abs(p[2] - cb["min"][2]) < eps: plane = 4
+    if abs(p[2] - cb["max"][2]) < eps: plane = 5
+    return dict(is_hit=plane != 5, t=tmax, normal=cb["nrm"][plane], mat=cb["mat"][plane], prim=("plane", plane))
+
+
+def intersect_triangle(o, d, A, B, C, t_min, t_max):
+    e1, e2 = sub(B, A), sub(C, A)
+    pv = cross(d, e2)
+    tv = sub(o, A)
+    qv = cross(tv, e1)
+    inv = f(1) / amax(dot(e1, pv), f(1.0e-25))
+    v = dot(tv, pv) * inv
+    u = dot(qv, d) * inv
+    t = dot(e2, qv) * inv
+    if v > 0 and u > 0 and u + v < 1 and t > t_min and t < t_max:
+        return dict(is_hit=True, u=u, v=v, tmin=t, tmax=t + f(1.0e-6))
+    return dict(is_hit=False)
+
+
+def intersect_mesh_bf(o, d, mesh):
+    hit, _, _ = intersect_box(o, d, mesh["bbmin"], mesh["bbmax"])
+    if not hit:
+        return dict(is_hit=False, t=f(0))
+    near = dict(is_hit=False, tmin=f(0), tmax=f(1000000.0), u=f(0), v=f(0)); tri_id = 0
+    for i, (a, b, c) in enumerate(mesh["idx"]):
+        h = intersect_triangle(o, d, mesh["pos"][a], mesh["pos"][b], mesh["pos"][c], near["tmin"], near["tmax"])
+        if h["is_hit"]:
+            near = h; tri_id = i
+    a, b, c = mesh["idx"][tri_id]
+    w = f(1) - near["u"] - near["v"]
+    n = add(add(scale(w, mesh["nrm"][a]), scale(near["v"], mesh["nrm"][b])), scale(near["u"], mesh["nrm"][c]))
+    return dict(is_hit=near["is_hit"], t=near["tmin"], normal=n, mat=2, prim=("triangle", tri_id))
+
+
+def intersect_flat_light(o, d, light):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv_y = f(1) / d[1]
+        t = (light["boxMax"][1] - o[1]) * inv_y
+    hp = add(o, scale(t, d))
+    hit = bool(hp[0] > light["boxMin"][0] and hp[0] < light["boxMax"][0] and hp[2] > light["boxMin"][2] and hp[2] < light["boxMax"][2] and t >= 0)
+    return dict(is_hit=hit, t=t, normal=V(0, -1, 0), mat=4, prim=("quad", 0))
+
+
+def find_closest_hit(scn, o, d):
+    hits = [intersect_all_spheres(o, d, scn["spheres"]), intersect_cornell(o, d, scn["cornell"])]
+    hits.append(intersect_flat_light(o, d, scn["light"]) if scn["light"]["shape"] == 0 else dict(is_hit=False, t=f(0)))
+    hits.append(intersect_mesh_bf(o, d, scn["mesh"]))
+    nearest = 0; dist = INFINITY
+    for i, h in enumerate(hits):
+        if h["is_hit"] and h["t"] < dist:
+            nearest = i; dist = h["t"]
+    return hits[nearest]
+
+
+def compute_shadow(scn, hit_pos, lpos):
+    eps = amax(amax3(abs(hit_pos[0]), abs(hit_pos[1]), abs(hit_pos[2])) * f(0.000000001), f(1.0e-30))
+    sd = normalize(sub(lpos, hit_pos))
+    so = add(hit_pos, scale(eps, sd))
+    h = find_closest_hit(scn, so, sd)
+    max_dist = length(sub(hit_pos, lpos))
+    eps2 = amax(max_dist * f(0.000001), f(1.0e-30))
+    return bool(h["is_hit"] and (h["t"] < max_dist - eps2 and h["t"] > f(10) * eps))
+
+
+def amax3(a, b, c):
+    if a >= b and a >= c: return a
+    if b >= c and b >= a: return b
+    return c
+
+
+def _material_sample(m, u3, u4, ray_dir, n):
+    t = m["type"]
+    if t == "lambert": return lambert_sample(m["kd"], u3, u4, ray_dir, n)
+    if t == "mirror": return mirror_sample(m["refl"], ray_dir, n)
+    if t == "glass": return glass_sample(m["refl"], m["trans"], m["ior"], u3, ray_dir, n)
+    if t == "phong": return phong_sample(m["refl"], m["pw"], u3, u4, ray_dir, n)
+    raise ValueError(t)
+
+
+def _material_eval(m, l, v, n):
+    t = m["type"]
+    if t == "lambert": return lambert_eval(m["kd"], l, v, n)
+    if t == "phong": return phong_eval(m["refl"], m["pw"], l, v, n)
+    return V(0, 0, 0), f(1)
+
+
+def _light_sample(light, u1, u2, p):
+    return sphere_light_sample(light, u1, u2, p) if light["shape"] == 1 else area_light_sample(light, u1, u2, p)
+
+
+def _light_eval_pdf(light, p, ray_dir, dist):
+    return sphere_light_eval_pdf(light, p) if light["shape"] == 1 else area_light_eval_pdf(light, p, ray_dir, dist)
+
+
+def mulv(a, b):
+    return (a[0] * b[0], a[1] * b[1], a[2] * b[2])
+
+
+G_EPS = f(1.0e-5)
+G_EPS_DIV = f(1.0e-20)
+
+
+def path_trace(scn, kind, o, d, prev, level, uniforms, max_depth):
+    """kind: 'stupid' | 'shadow' | 'mis'.  uniforms(bounce) -> the four uniforms of that bounce (light x2, BSDF x2)."""
+    if level == 0:
+        return V(0, 0, 0)
+    h = find_closest_hit(scn, o, d)
+    if not h["is_hit"]:
+        return V(0, 0, 0)
+    m = scn["materials"][h["mat"]]
+    n = h["normal"]
+    u = uniforms(max_depth - level)
+    if m["type"] == "light":
+        if kind == "shadow":
+            return V(0, 0, 0)
+        if dot(scale(f(-1), d), n) < 0:
+            return V(0, 0, 0)
+        if kind == "stupid":
+            return scn["light"]["intensity"]
+        lp = _light_eval_pdf(scn["light"], o, d, h["t"])
+        bp = prev["pdf"]
+        mis = f(1) if prev["specular"] else bp * bp / (lp * lp + bp * bp)
+        return scale(mis, scn["light"]["intensity"])
+    explicit = V(0, 0, 0)
+    hpos = add(o, scale(h["t"], d))
+    if kind != "stupid":
+        ls = _light_sample(scn["light"], u[0], u[1], hpos)
+        sdir = normalize(sub(ls["pos"], hpos))
+        if not compute_shadow(scn, hpos, ls["pos"]):
+            bx, bp = _material_eval(m, sdir, scale(f(-1), d), n)
+            c1 = amax(dot(sdir, n), f(0))
+            with np.errstate(over="ignore", invalid="ignore"):
+                if kind == "mis":
+                    lp = ls["pdf"]
+                    mis = lp * lp / (lp * lp + bp * bp)
+                    explicit = scale(mis, mulv(scale(f(1) / amax(lp, G_EPS_DIV), ls["intensity"]), scale(c1, bx)))
+                else:
+                    explicit = scale(f(1) / amax(ls["pdf"], G_EPS_DIV), mulv(ls["intensity"], scale(c1, bx)))
+    ms = _material_sample(m, u[2], u[3], d, n)
+    bxv = scale(f(1) / amax(ms["pdf"], G_EPS_DIV), ms["color"])
+    ct = dot(ms["dir"], n)
+    sg = f(1) if ct >= 0 else f(-1)
+    no = add(add(o, scale(h["t"], d)), scale(G_EPS, scale(sg, n)))
+    nxt = path_trace(scn, kind, no, ms["dir"], dict(pdf=ms["pdf"], specular=ms["specular"]), level - 1, uniforms, max_depth)
+    w = scale(abs(ct), bxv)
+    with np.errstate(over="ignore", invalid="ignore"):
+        if kind == "stupid":
+            return mulv(w, nxt)
+        return add(explicit, mulv(w, nxt))
+
+
+def eye_ray_direction(x, y, ox, oy, width, height):
+    """ray_tracer.adb:61-97: ox = oy = 0.5 (no AA) or the 1/3, 2/3 offsets; fov = pi/2"""
+    fov = f(np.float64(np.pi) / 2.0)
+    half = fov / f(2)
+    tan_half = f(np.tan(np.float64(half)))                       # safe_tan: |x| /= pi/2 here
+    r = (f(x) + ox - (f(width) / f(2)), f(y) + oy - (f(height) / f(2)), -f(width) / tan_half)
+    return normalize(r)

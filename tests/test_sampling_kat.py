@@ -159,3 +159,86 @@ def test_bsdf_sample_and_eval(art, libs, name):
         assert np.array_equal(bits(h4), bits(want4)), ("product eval", name, k, h4, want4)
     if name == "FresnelDielectric":
         assert len(n_spec_branches) == 4, "reflection and refraction, entering and leaving, must all occur: %s" % n_spec_branches
+
+
+# ------------------------------------------------------------------------------------------------ whole paths
+def _transcribed_scene(rect_light=False):
+    """the reference's internal scene (scene.adb:89-217) as the transcription's dict; the transformed pyramid comes from the VSGF loader,
+    which tests/test_oracle_kat.py pins separately"""
+    cs = orc.CornellScene(use_rect_light=rect_light)
+    m = cs.mesh_arrays()
+    V = ada.V
+    mats = [dict(type="glass", refl=V(0.75, 0.75, 0.75), trans=V(0.85, 0.85, 0.85), ior=f(1.75)),
+            dict(type="lambert", kd=V(0.5, 0.5, 0.5)), dict(type="lambert", kd=V(0.25, 0.5, 0.0)), dict(type="lambert", kd=V(0.5, 0.0, 0.0)),
+            dict(type="light"), dict(type="mirror", refl=V(0.75, 0.75, 0.75)), None, None,
+            dict(type="phong", refl=V(0.75, 0.75, 0.75), pw=f(80.0)), dict(type="lambert", kd=V(0.5, 0.5, 0.5)), dict(type="lambert", kd=V(0.5, 0.5, 0.5))]
+    spheres = [(V(-1.5, 1.0, 1.5), f(1.0), 8), (V(1.4, 1.0, 3.0), f(1.0), 0)]
+    if rect_light:
+        lo, hi = V(-0.75, 4.98, 1.25), V(0.75, 4.98, 3.25)                         # scene.adb:104-107
+        light = dict(shape=0, boxMin=lo, boxMax=hi, normal=V(0, -1, 0), center=V(0, 0, 0), radius=f(0), intensity=V(20, 20, 20),
+                     surfaceArea=(hi[0] - lo[0]) * (hi[2] - lo[2]))
+    else:
+        light = dict(SPHERE_LIGHT)
+        spheres.append((V(0.0, 4.5, 1.0), f(0.5), 4))
+    scn = dict(spheres=spheres, light=light, materials=mats,
+               cornell=dict(min=V(-2.5, 0, 0), max=V(2.5, 5, 5), mat=(2, 3, 1, 1, 8, 1),
+                            nrm=(V(1, 0, 0), V(-1, 0, 0), V(0, 1, 0), V(0, -1, 0), V(0, 0, 1), V(0, 0, -1))),
+               mesh=dict(pos=[tuple(f(c) for c in p) for p in m["pos"]], nrm=[tuple(f(c) for c in p) for p in m["nrm"]],
+                         idx=[tuple(int(i) for i in t) for t in m["idx"]], bbmin=tuple(f(c) for c in m["bbmin"]), bbmax=tuple(f(c) for c in m["bbmax"])))
+    return cs, scn
+
+
+@pytest.mark.parametrize("kind,rt", [("mis", orc.PT_MIS), ("shadow", orc.PT_SHADOW), ("stupid", orc.PT_STUPID)])
+def test_whole_paths_against_the_transcribed_integrators(kind, rt):
+    """PathTrace x 3 (ray_tracer-integrators.adb:82-301), Find_Closest_Hit (scene.adb:56-86), the five intersectors (geometry.adb:48-323),
+    Compute_Shadow and the camera rays (ray_tracer.adb:61-132), transcribed a third time in numpy float32 (tests/ada_transcription.py):
+    the oracle's radiance of single camera samples must equal the transcription's BIT FOR BIT -- glass, Phong, Lambert, the light, the
+    pyramid's first-hit-wins mesh scan, shadow rays, the MIS weights and the recursion's association, paths up to depth 8."""
+    cs, scn = _transcribed_scene()
+    L = orc.lib()
+    W = H = 24; depth = 8; seed = 31
+    prm = orc.make_params(W, H, rt, True, depth, 1, seed=seed)
+    rng = np.random.default_rng(5)
+    # pixels spread over the picture + pixels aimed at the glass sphere, the Phong sphere, the pyramid and the light
+    pixels = [(int(x), int(y)) for x, y in zip(rng.integers(4, 20, 14), rng.integers(4, 20, 14))] + [(15, 8), (16, 9), (8, 8), (9, 9), (10, 7), (11, 7), (12, 16), (12, 15)]
+    third = (f(1.0 / 3.0), f(2.0 / 3.0))
+    n_nonzero = 0; deepest = 0
+    for (x, y) in pixels:
+        for sample in range(4):
+            ox, oy = third[(sample >> 1) & 1], third[sample & 1]                 # Generate4RayDirections order
+            d0 = ada.eye_ray_direction(x, y, ox, oy, W, H)
+            cm = cs.scene.cam_matrix
+            d = ada.normalize(tuple(f(cm[4 * r]) * d0[0] + f(cm[4 * r + 1]) * d0[1] + f(cm[4 * r + 2]) * d0[2] + f(cm[4 * r + 3]) for r in range(3)))
+            o = tuple(f(v) for v in cs.scene.cam_pos)
+            pixel = y * W + x
+            seen = []
+
+            def uniforms(bounce, pixel=pixel, sample=sample, seen=seen):
+                seen.append(bounce)
+                return [f(L.orc_rng_uniform(seed, pixel, sample, bounce, s)) for s in range(4)]
+            want = ada.path_trace(scn, kind, o, d, dict(pdf=f(1), specular=True), depth, uniforms, depth)
+            got = np.zeros(3, np.float32)
+            L.orc_sample_radiance(C.byref(cs.scene), C.byref(prm), x, y, sample, orc.fp(got))
+            assert np.array_equal(bits(got), bits(np.array(want, np.float32))), (kind, x, y, sample, got, want)
+            n_nonzero += bool(np.any(got != 0)); deepest = max(deepest, max(seen) + 1 if seen else 0)
+    assert n_nonzero > (20 if kind != "stupid" else 2) and deepest == depth
+
+
+def test_whole_paths_with_the_rect_light_overflow():
+    """the reference's own overflow (AreaLight pdf = d^2 / (A * 1e-20) above the light plane -> MIS weight inf / inf = NaN,
+    lights.adb:42-45, integrators.adb:277-279) comes out of the transcription as well: same NaNs, same bits elsewhere"""
+    cs, scn = _transcribed_scene(rect_light=True)
+    L = orc.lib()
+    W = H = 16; depth = 4; seed = 3
+    prm = orc.make_params(W, H, orc.PT_MIS, False, depth, 1, seed=seed)
+    n_nan = 0
+    for (x, y) in [(8, 12), (6, 11), (10, 12), (8, 11), (7, 12), (8, 3), (3, 8), (12, 8), (8, 8)]:       # rows 11-12 look at the ceiling
+        d = ada.normalize(ada.eye_ray_direction(x, y, f(0.5), f(0.5), W, H))
+        o = tuple(f(v) for v in cs.scene.cam_pos)
+        uniforms = lambda bounce, pixel=y * W + x: [f(L.orc_rng_uniform(seed, pixel, 0, bounce, s)) for s in range(4)]
+        want = np.array(ada.path_trace(scn, "mis", o, d, dict(pdf=f(1), specular=True), depth, uniforms, depth), np.float32)
+        got = np.zeros(3, np.float32)
+        L.orc_sample_radiance(C.byref(cs.scene), C.byref(prm), x, y, 0, orc.fp(got))
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(bits(got)[~np.isnan(got)], bits(want)[~np.isnan(want)]), (x, y, got, want)
+        n_nan += bool(np.isnan(got).any())
+    assert n_nan >= 1
