@@ -517,3 +517,35 @@ def eye_ray_direction(x, y, ox, oy, width, height):
     tan_half = f(np.tan(np.float64(half)))                       # safe_tan: |x| /= pi/2 here
     r = (f(x) + ox - (f(width) / f(2)), f(y) + oy - (f(height) / f(2)), -f(width) / tan_half)
     return normalize(r)
+
+
+# ================================================================================================ the pyramid's transform chain
+# vector_math.adb:85-111 RotationMatrix, generic_vector_math.adb:233-256 "*"(Matrix4, Matrix4), vector_math.adb:137-144 "*"(float4x4, float3),
+# scene.adb:194-206 (mtans * mrot * mscale), geometry.adb:593-607 (positions transformed, bounding box of the transformed positions)
+def rotation_matrix(angle, axis):
+    M = [[f(1) if r == c else f(0) for c in range(4)] for r in range(4)]
+    v = normalize(axis)
+    ct, st = cos(angle), sin(angle)
+    one = f(1)
+    M[0][0] = (one - ct) * v[0] * v[0] + ct;          M[0][1] = (one - ct) * v[0] * v[1] - st * v[2]; M[0][2] = (one - ct) * v[0] * v[2] + st * v[1]
+    M[1][0] = (one - ct) * v[1] * v[0] + st * v[2];   M[1][1] = (one - ct) * v[1] * v[1] + ct;        M[1][2] = (one - ct) * v[1] * v[2] - st * v[0]
+    M[2][0] = (one - ct) * v[0] * v[2] - st * v[1];   M[2][1] = (one - ct) * v[2] * v[1] + st * v[0]; M[2][2] = (one - ct) * v[2] * v[2] + ct
+    return M
+
+
+def mat_mul(a, b):
+    return [[a[r][0] * b[0][c] + a[r][1] * b[1][c] + a[r][2] * b[2][c] + a[r][3] * b[3][c] for c in range(4)] for r in range(4)]
+
+
+def mat_mul_point(m, v):
+    return tuple(m[r][0] * v[0] + m[r][1] * v[1] + m[r][2] * v[2] + m[r][3] for r in range(3))
+
+
+def cornell_mesh_transform():
+    ident = lambda: [[f(1) if r == c else f(0) for c in range(4)] for r in range(4)]
+    mrot = rotation_matrix(f(-np.float64(np.pi) / 6.0), V(0, 1, 0))          # static -PI/6.0, rounded once
+    mscale = ident(); mtans = ident()
+    for r, val in enumerate((-0.75, 0.1, 3.1, 1.0)):
+        mtans[r][3] = f(val)
+    mscale[0][0] = mscale[1][1] = mscale[2][2] = f(2)
+    return mat_mul(mat_mul(mtans, mrot), mscale)

@@ -242,3 +242,20 @@ def test_whole_paths_with_the_rect_light_overflow():
         assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(bits(got)[~np.isnan(got)], bits(want)[~np.isnan(want)]), (x, y, got, want)
         n_nan += bool(np.isnan(got).any())
     assert n_nan >= 1
+
+
+def test_pyramid_transform_chain_against_the_transcription(art):
+    """scene.adb:194-206 + geometry.adb:593-607: RotationMatrix(-PI/6), mtans * mrot * mscale, positions transformed, bounding box -- the
+    transcription, the oracle's loader and the product's host layer (host/art_host.cpp) give the same bits"""
+    import json
+    from ada_ray_tracer_amd import scenes
+    T = ada.cornell_mesh_transform()
+    To = np.zeros(16, np.float32); orc.lib().orc_cornell_mesh_transform(orc.fp(To))
+    assert np.array_equal(bits(To), bits(np.array(T, np.float32).ravel()))
+    g = json.load(open(orc.GOLDEN + "/vsgf_decode.json"))
+    want = np.array([ada.mat_mul_point(T, tuple(f(c) for c in p)) for p in g["positions"]], np.float32)
+    m = orc.CornellScene().mesh_arrays()
+    assert np.array_equal(bits(m["pos"]), bits(want))
+    assert np.array_equal(bits(m["bbmin"]), bits(want.min(0))) and np.array_equal(bits(m["bbmax"]), bits(want.max(0)))
+    d = scenes.reference_scene().desc
+    assert np.array_equal(bits(np.ctypeslib.as_array(d.meshes[0].pos, (17, 3))), bits(want))
