@@ -116,18 +116,16 @@ __device__ __forceinline__ float self(mask_t m, float if_set, float if_clear) {
 __device__ __forceinline__ bool lane_of(mask_t m) { return sel(m, 1u, 0u) != 0u; }        // mask -> this lane's bit (off the hot path)
 
 // the three DPP rank compares of a quad as one borrow chain starting from `start`: returns start - #{other lanes of my quad whose
-// key is smaller than mine}.  (The compiler builds the first compare as a 0 / -1 select and adds `start` afterwards.)
+// key is smaller than mine}.  Each compare is a DPP subtract (other lane's key - mine) whose borrow is "other < mine" (keys are
+// below 2^31), taken up by v_subbrev: 6 instructions (mov_dpp + v_cmp + v_subbrev per compare: 9, measured 0.2-0.7 % slower).
 __device__ __forceinline__ int quad_sub_rank(int key, int start) {
   int r, t;
   asm("s_nop 1\n\t"
-      "v_mov_b32_dpp %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_cmp_lt_i32 vcc, %1, %2\n\t"
+      "v_sub_co_u32_dpp %1, vcc, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_subbrev_co_u32 %0, vcc, 0, %3, vcc\n\t"
-      "v_mov_b32_dpp %1, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_cmp_lt_i32 vcc, %1, %2\n\t"
+      "v_sub_co_u32_dpp %1, vcc, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_subbrev_co_u32 %0, vcc, 0, %0, vcc\n\t"
-      "v_mov_b32_dpp %1, %2 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_cmp_lt_i32 vcc, %1, %2\n\t"
+      "v_sub_co_u32_dpp %1, vcc, %2, %2 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_subbrev_co_u32 %0, vcc, 0, %0, vcc"
       : "=&v"(r), "=&v"(t) : "v"(key), "v"(start) : "vcc");
   return r;
@@ -281,6 +279,9 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       }
       // ---- node phase: lane j tests child j; groups not taking part read the root node and discard the result
       float tmn, tmx; uint32_t entry; mask_t valid;
+#if defined(ART_DIAG_LOAD)
+      uint32_t diag_x[ART_DIAG_LOAD] = {};
+#endif
       if (G == 4) {
         const uint32_t noff = sel(want_node, pend, 0u);
         const float4 h = *reinterpret_cast<const float4*>(nodes_b + noff);                 // origin, scale: same address in the 4 lanes
@@ -296,6 +297,16 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
                       mk3(__builtin_fmaf(pf.x, inv.x, noi.x), __builtin_fmaf(pf.y, inv.y, noi.y), __builtin_fmaf(pf.z, inv.z, noi.z)), best_t, tmn, tmx);
         valid = ~0ull;
         if (STATS) valid = vcmp(entry != kQEntryEmpty);
+#if defined(ART_DIAG_VALU)          // diagnostic builds only (profiles/diag.sh): n more dependent VALU instructions per node step
+        { float x = tmn;
+#pragma unroll
+          for (int k = 0; k < ART_DIAG_VALU; ++k) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x) : "v"(tmx)); }
+#endif
+#if defined(ART_DIAG_LOAD)          // ... or n more vector loads per lane and node step from the node's own line (no new L2 traffic: the TA / L1 path alone)
+        {
+#pragma unroll
+          for (int k = 0; k < ART_DIAG_LOAD; ++k) { uint32_t off2 = noff + jrec + 8u - 4u * (uint32_t)k; asm volatile("" : "+v"(off2)); diag_x[k] = *reinterpret_cast<const uint32_t*>(nodes_b + off2); } }
+#endif
       } else {
         const uint32_t noff = sel(want_node, pend >> 4, 0u) * (uint32_t)(G * 32) + jrec;
         const float4 r0 = *reinterpret_cast<const float4*>(nodes_b + noff);
@@ -321,6 +332,12 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         }
       }
       pend_valid &= ~want_node;
+#if defined(ART_DIAG_LOAD)
+      if (G == 4) {
+#pragma unroll
+        for (int k = 0; k < ART_DIAG_LOAD; ++k) asm volatile("" :: "v"(diag_x[k]));
+      }
+#endif
       if (STATS) { st_box += lane_of(want_node & valid); st_node += (lane_of(want_node) && j == 0); st_it_node += (lane == 0); }
       wave_lds_sync();
     }
