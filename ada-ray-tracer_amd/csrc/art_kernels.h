@@ -17,9 +17,11 @@ struct TraceArgs {
   int32_t segments;             // k_trace_coop: the queue is cut into this many contiguous segments (1, 2, 4, 8); workgroup b starts
                                 // in segment b % segments (its XCD) and moves on to the next segment when that one is drained
   int32_t node_min;             // a wave keeps expanding nodes while at least this many of its 8 ray groups have one
+  int32_t refill_min;           // k_trace_coop: idle groups take new rays only when at least this many of the wave's groups are idle (or nothing else is left to do)
   const float* ray_ox; const float* ray_oy; const float* ray_oz;
   const float* ray_dx; const float* ray_dy; const float* ray_dz;
   const float* ray_tfar;        // < 0: skip
+  float4* rec;                  // k_analytic -> k_trace_coop: one 64-byte record per QUEUED ray, in queue order (kTraceRec* below); n_rays + 16 records
   // shadow rays (index >= shadow_begin) only feed Compute_Shadow's test  10*eps < t_closest < tfar  (ray_tracer.adb:122):
   // sh_min[i - shadow_begin] = 10*eps.  nullptr: every ray is a closest-hit query.
   const float* sh_min; int32_t shadow_begin;
@@ -34,6 +36,11 @@ struct TraceArgs {
   unsigned long long* live_rays;   // += closest-hit queries actually issued by this launch (Mrays/s numerator)
   const int* item_count;           // compacted work set: items [0, *item_count) exist (rays [0, n) and [shadow_begin, shadow_begin + n)); nullptr: all n_rays
 };
+
+// trace record (4 x float4) of a queued ray: everything k_trace_coop needs to start it, prepared at one ray per lane by k_analytic
+//   [0] origin.xyz, starting bound t      [1] direction.xyz, starting bound key      [2] 1/direction (slab_setup), shadow-rule minimum (< 0: closest hit)
+//   [3] near-plane byte selector (width 4), ray index, far_found, 0
+constexpr int kTraceRecBytes = 64;
 
 void launch_raygen(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q);
 void launch_shade(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q, int bounce);

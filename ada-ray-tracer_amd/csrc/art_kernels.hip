@@ -150,6 +150,10 @@ __device__ __forceinline__ void lds_store(uint32_t addr, uint2 v) {       // two
   asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" :: "v"(addr), "v"(v.x), "v"(v.y) : "memory");
 }
 
+// scalar base + 32-bit byte offset: the address costs no vector instruction (a 64-bit pointer per array costs a v_lshl_add_u64 each)
+template <class T> __device__ __forceinline__ T ld_off(const T* base, uint32_t byte_off) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off); }
+template <class T> __device__ __forceinline__ void st_off(T* base, uint32_t byte_off, T v) { *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v; }
+
 // ------------------------------------------------------------------------------------------------
 // cooperative persistent trace kernel
 // ------------------------------------------------------------------------------------------------
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
   // The live-ray queue is in ray order (neighbouring rays start at neighbouring surface points), so it is cut into one
   // contiguous segment per XCD: workgroups are dealt round-robin to the XCDs, each XCD has its own L2, and rays that walk
   // the same part of the tree then share an L2.  A wave whose segment is drained helps with the next one.
-  const int n_seg = A.segments;
+  const int n_seg = A.segments, seg_shift = __builtin_ctz((unsigned)n_seg);
   int seg = (int)blockIdx.x & (n_seg - 1), segs_left = n_seg;   // wave-uniform
   mask_t has_ray = 0, pend_valid = 0;                 // group-uniform bits: the group holds a ray / a popped entry waiting for its phase
   uint32_t sa = sb; int ray = 0;
@@ -207,11 +211,15 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
   for (;;) {
     if (STATS) st_it_all += (lane == 0);
     // ---------------- refill idle groups from the wave's chunk of the live-ray queue
+    float pf_keep = 0.0f;
     while (!exhausted) {
       const mask_t need_mask = ~has_ray & leaders;
       if (need_mask == 0) break;
+      // a refill costs the whole wave ~120 instructions (ray fetch, three correctly rounded divisions, retire stores) whatever the number
+      // of rays it brings in: wait until refill_min groups are idle, unless the wave has nothing else to do
+      if (__popcll(need_mask) < A.refill_min && has_ray != 0) break;
       if (chunk_pos == chunk_end) {
-        const int seg_lo = (int)(((int64_t)n_queue * seg) / n_seg), seg_hi = (int)(((int64_t)n_queue * (seg + 1)) / n_seg);
+        const int seg_lo = (int)(((int64_t)n_queue * seg) >> seg_shift), seg_hi = (int)(((int64_t)n_queue * (seg + 1)) >> seg_shift);   // n_seg is a power of two
         int base = 0;
         if (lane == 0) base = atomicAdd(A.cursor + 32 * (seg + 1), A.chunk);
         base = __builtin_amdgcn_readfirstlane(base) + seg_lo;
@@ -222,30 +230,31 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
           if (--segs_left == 0) { exhausted = true; break; }
           continue;
         }
+        // the chunk's records (16 x 64 B = one 16-byte load per lane) on their way into the cache before the first group asks for its own
+        // (the value is only "used" after the refill's own loads below, so that nothing waits for it alone)
+        if (A.chunk == 16) pf_keep = reinterpret_cast<const float*>(A.rec)[((size_t)chunk_pos * 4 + lane) * 4];
       }
       const int avail = chunk_end - chunk_pos;
       const int n_need = __popcll(need_mask);
       const int my_rank = __popcll(need_mask & ((1ull << gbase) - 1ull));
       const bool got = !lane_of(has_ray) && (my_rank < avail);
       if (got) {
-        // the analytic primitives were intersected by k_analytic: (hit_t, hit_key) is the starting bound
-        ray = A.queue[chunk_pos + my_rank];
-        o = mk3(A.ray_ox[ray], A.ray_oy[ray], A.ray_oz[ray]);
-        d = mk3(A.ray_dx[ray], A.ray_dy[ray], A.ray_dz[ray]);
-        slab_setup(o, d, inv, noi);
-        if (G == 4) {   // child bytes: c0 = { lo.x lo.y lo.z hi.x } (selector values 0..3), c1 = { hi.y hi.z - - } (4, 5); 0x0c = constant 0
-          const uint32_t sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
-          sel_near = (sx ? 3u : 0u) | ((sy ? 4u : 1u) << 8) | ((sz ? 5u : 2u) << 16) | 0x0c000000u;
-          sel_far = (sx ? 0u : 3u) | ((sy ? 1u : 4u) << 8) | ((sz ? 2u : 5u) << 16) | 0x0c000000u;
-        }
-        best_t = A.hit_t[ray]; best_key = A.hit_key[ray];
-        shm = (A.sh_min != nullptr && ray >= A.shadow_begin) ? A.sh_min[ray - A.shadow_begin] : -1.0f;
-        far_found = (shm >= 0.0f) && (best_key != KEY_MISS);     // a queued shadow ray with a hit has a far hit (near ones are not queued)
-        best_t = far_found ? next_up_pos(shm) : best_t;
-        best_key = far_found ? KEY_MISS : best_key;
+        // the ray's 64-byte trace record, prepared by k_analytic (analytic primitives already intersected: the starting bound; slab_setup's
+        // three correctly rounded divisions; the shadow rule's starting state).  Records are in queue order: the address depends on
+        // nothing but the wave's cursor, and the whole chunk was fetched by the prefetch above.
+        const char* rb = reinterpret_cast<const char*>(A.rec) + (size_t)chunk_pos * (size_t)kTraceRecBytes;      // wave-uniform
+        const uint32_t ro = (uint32_t)my_rank * (uint32_t)kTraceRecBytes;
+        const float4 r0 = ld_off(reinterpret_cast<const float4*>(rb), ro), r1 = ld_off(reinterpret_cast<const float4*>(rb), ro + 16u),
+                     r2 = ld_off(reinterpret_cast<const float4*>(rb), ro + 32u), r3 = ld_off(reinterpret_cast<const float4*>(rb), ro + 48u);
+        o = mk3(r0.x, r0.y, r0.z); d = mk3(r1.x, r1.y, r1.z); inv = mk3(r2.x, r2.y, r2.z);
+        noi = mk3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+        best_t = r0.w; best_key = __builtin_bit_cast(uint32_t, r1.w); shm = r2.w;
+        sel_near = __builtin_bit_cast(uint32_t, r3.x); sel_far = 0x18070503u - sel_near;      // per byte: near + far = 3, 5, 7, 0x18 (0x0c + 0x0c)
+        ray = __builtin_bit_cast(int, r3.y); far_found = __builtin_bit_cast(uint32_t, r3.z) != 0u;
         held_key = KEY_MISS;
         sa = sb; pend = 0u;                                       // entry word 0 = root node (both encodings)
       }
+      asm volatile("" :: "v"(pf_keep));
       const mask_t got_mask = __builtin_amdgcn_ballot_w64(got);
       has_ray |= got_mask; pend_valid |= got_mask;
       chunk_pos += min(avail, n_need);
@@ -347,9 +356,10 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
     if (done != 0) {
       if (lane_of(done)) {
         const bool keep_far = far_found && best_key == KEY_MISS;      // shadow ray whose far hit is already stored
-        if (j == 0 && !keep_far) { A.hit_t[ray] = best_t; A.hit_key[ray] = best_key; }
+        const uint32_t roff = (uint32_t)ray << 2;
+        if (j == 0 && !keep_far) { st_off(A.hit_t, roff, best_t); st_off(A.hit_key, roff, best_key); }
         // barycentrics: only a BVH triangle found by this kernel needs storing (analytic / brute-force hits were stored by k_analytic)
-        if (shm < 0.0f && best_key != KEY_MISS && held_key == best_key) { A.hit_u[ray] = held_u; A.hit_v[ray] = held_v; }
+        if (shm < 0.0f && best_key != KEY_MISS && held_key == best_key) { st_off(A.hit_u, roff, held_u); st_off(A.hit_v, roff, held_v); }
       }
       has_ray &= ~done;
     }
@@ -384,7 +394,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       if (ballot64(sh_hit) != 0) {                         // shadow_rule, group-uniform
         const bool near = sh_hit && (win_t <= shm);
         const bool far = sh_hit && !near;                  // first far hit (afterwards the bound is <= shm)
-        if (far && j == 0) { A.hit_t[ray] = win_t; A.hit_key[ray] = (uint32_t)win; }
+        if (far && j == 0) { st_off(A.hit_t, (uint32_t)ray << 2, win_t); st_off(A.hit_key, (uint32_t)ray << 2, (uint32_t)win); }
         far_found = far_found || far;
         best_t = far ? next_up_pos(shm) : best_t;
         best_key = far ? KEY_MISS : best_key;
@@ -477,7 +487,25 @@ __global__ __launch_bounds__(256) void k_analytic(const DevScene* __restrict__ S
     if (A.stats != nullptr && s_live) atomicAdd(&A.stats[4], (unsigned long long)s_live);
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < s_count; k += 256) A.queue[s_base + k] = s_idx[k];
+  // the queue entry of a ray is its trace record (art_kernels.h): the trace kernel's per-ray setup, done here at one ray per lane
+  for (int k = threadIdx.x; k < s_count; k += 256) {
+    const int i = s_idx[k];
+    const f3 o = mk3(A.ray_ox[i], A.ray_oy[i], A.ray_oz[i]), d = mk3(A.ray_dx[i], A.ray_dy[i], A.ray_dz[i]);
+    float bt = A.hit_t[i]; uint32_t bk = A.hit_key[i];                        // written above by this workgroup
+    const float shm = (A.sh_min != nullptr && i >= A.shadow_begin) ? A.sh_min[i - A.shadow_begin] : -1.0f;
+    f3 inv, noi; slab_setup(o, d, inv, noi);
+    const bool far_found = (shm >= 0.0f) && (bk != KEY_MISS);               // a queued shadow ray with a hit has a far hit (near ones are not queued)
+    bt = far_found ? next_up_pos(shm) : bt;
+    bk = far_found ? KEY_MISS : bk;
+    // width 4, child bytes: c0 = { lo.x lo.y lo.z hi.x } (selector values 0..3), c1 = { hi.y hi.z - - } (4, 5); 0x0c = constant 0
+    const uint32_t sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+    const uint32_t sel_near = (sx ? 3u : 0u) | ((sy ? 4u : 1u) << 8) | ((sz ? 5u : 2u) << 16) | 0x0c000000u;
+    float4* r = A.rec + 4 * (size_t)(s_base + k);
+    r[0] = make_float4(o.x, o.y, o.z, bt);
+    r[1] = make_float4(d.x, d.y, d.z, __builtin_bit_cast(float, bk));
+    r[2] = make_float4(inv.x, inv.y, inv.z, shm);
+    r[3] = make_float4(__builtin_bit_cast(float, sel_near), __builtin_bit_cast(float, i), __builtin_bit_cast(float, far_found ? 1u : 0u), 0.0f);
+  }
 }
 
 // rays of a launch that bypasses k_analytic (one-ray-per-lane kernel): count the live ones, one atomic per workgroup chunk
