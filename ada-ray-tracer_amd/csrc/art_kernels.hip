@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
   // art_upload_scene guarantees that node and triangle byte offsets fit (31 bits for G = 4, 32 for G = 8).
   const char* const nodes_b = reinterpret_cast<const char*>(G == 4 ? (const void*)A.qnodes : (const void*)A.nodes);
   const char* const tris_b = reinterpret_cast<const char*>(G == 4 ? (const void*)A.qtris : (const void*)A.tris);
-  const uint32_t jrec = (G == 4) ? 16u + 12u * (uint32_t)j : 16u * (uint32_t)j;     // this lane's child record inside a node
+  const uint32_t jrec = 16u * (uint32_t)j;     // this lane's child record inside a node
   const uint32_t jtri = (uint32_t)j * (uint32_t)(G == 4 ? kQTriBytes : kTriBytes);
   const int n_queue = *A.queue_count;
 
@@ -293,9 +293,10 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
 #endif
       if (G == 4) {
         const uint32_t noff = sel(want_node, pend, 0u);
-        const float4 h = *reinterpret_cast<const float4*>(nodes_b + noff);                 // origin, scale: same address in the 4 lanes
-        const uint32_t* cp = reinterpret_cast<const uint32_t*>(nodes_b + (noff + jrec));
-        const uint32_t c0 = cp[0], c1 = cp[1]; entry = cp[2];
+        const uint4 rec = *reinterpret_cast<const uint4*>(nodes_b + (noff + jrec));       // ONE load: the quad reads the node's 64 contiguous bytes
+        const uint32_t c0 = rec.x, c1 = rec.y; entry = rec.z;
+        const float4 h = make_float4(__builtin_bit_cast(float, dpp_i<0x00>((int)rec.w)), __builtin_bit_cast(float, dpp_i<0x55>((int)rec.w)),
+                                     __builtin_bit_cast(float, dpp_i<0xAA>((int)rec.w)), __builtin_bit_cast(float, dpp_i<0xFF>((int)rec.w)));
         // near / far plane bytes by direction sign (one v_perm each), dequantised (one fma per plane: the very binary32 boxes of the
         // exported tree), then the slab distances.  An empty slot holds lo = 255, hi = 0 on every axis: its near plane lies behind
         // its far plane for every ray, so it can never be hit and needs no validity test.
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
 #if defined(ART_DIAG_LOAD)          // ... or n more vector loads per lane and node step from the node's own line (no new L2 traffic: the TA / L1 path alone)
         {
 #pragma unroll
-          for (int k = 0; k < ART_DIAG_LOAD; ++k) { uint32_t off2 = noff + jrec + 8u - 4u * (uint32_t)k; asm volatile("" : "+v"(off2)); diag_x[k] = *reinterpret_cast<const uint32_t*>(nodes_b + off2); } }
+          for (int k = 0; k < ART_DIAG_LOAD; ++k) { uint32_t off2 = noff + jrec + 4u * (uint32_t)k; asm volatile("" : "+v"(off2)); diag_x[k] = *reinterpret_cast<const uint32_t*>(nodes_b + off2); } }
 #endif
       } else {
         const uint32_t noff = sel(want_node, pend >> 4, 0u) * (uint32_t)(G * 32) + jrec;
@@ -370,10 +371,14 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       const int cnt = (int)(pend & 15u);
       const bool tri_lane = wl && (j < cnt);
       const uint32_t tbase = (G == 4) ? (pend & 0x7ffffff0u) : (pend >> 4) * (uint32_t)kTriBytes;
-      const uint32_t toff = tri_lane ? (tbase + jtri) : 0u;
-      const float4 q0 = *reinterpret_cast<const float4*>(tris_b + toff);
-      const float4 q1 = *reinterpret_cast<const float4*>(tris_b + toff + 16u);
-      const float4 q2 = *reinterpret_cast<const float4*>(tris_b + toff + 32u);
+      // only the lanes that hold a triangle load (about 12 of 64): the other lanes' result is masked anyway
+      float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q1 = q0, q2 = q0;
+      if (tri_lane) {
+        const uint32_t toff = tbase + jtri;
+        q0 = *reinterpret_cast<const float4*>(tris_b + toff);
+        q1 = *reinterpret_cast<const float4*>(tris_b + toff + 16u);
+        q2 = *reinterpret_cast<const float4*>(tris_b + toff + 32u);
+      }
       float tt, uu, vv;
       const bool pass = tri_raw(o, d, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x), tt, uu, vv);
       const bool valid = tri_lane && pass && (tt > 0.0f) && (tt < 1000000.0f);

@@ -6,8 +6,12 @@
 // the node's own origin is 64 B.  The search result cannot depend on the boxes as long as they stay conservative, so the image and
 // every hit stay bit-identical; only the traversal counters move (slightly looser boxes).
 //
-//   bytes  0..15   origin.x origin.y origin.z scale          binary32; scale is a power of two, shared by the three axes
-//   bytes 16+12j   child j:  { qlo.x qlo.y qlo.z qhi.x | qhi.y qhi.z 0 0 | entry }     j = 0..3
+//   bytes 16j..16j+15   lane record j (j = 0..3):  { qlo.x qlo.y qlo.z qhi.x | qhi.y qhi.z 0 0 | entry | header word j }
+//   header words   0: origin.x   1: origin.y   2: origin.z   3: scale        binary32; scale is a power of two, shared by the three axes
+//                  Lane j of a ray's quad reads record j with ONE 16-byte load (the quad reads the node's 64 contiguous bytes) and the
+//                  four header words are broadcast inside the quad by DPP.  Per wave load instruction and CU (profiles/ta_rate.hip): quads
+//                  reading 64 contiguous bytes ~15 clocks of the vector-memory path; a 16-byte header + 12-byte child records at a
+//                  12-byte lane stride 15 + 45.
 //   entry          inner child: node_index * 64               (bit 31 clear, low 6 bits clear)
 //                  leaf:        0x80000000 | first_triangle * 64 | count   (count 1..4 in the low 4 bits; 64-byte padded triangle records)
 //                  empty slot:  0xffffffff
@@ -26,7 +30,7 @@ constexpr uint32_t kQEntryEmpty = 0xffffffffu, kQEntryLeaf = 0x80000000u;
 constexpr int kTriBytes = kTriFloats * 4;
 constexpr int kQTriBytes = 64;       // the 4-wide kernel reads triangle records padded to 64 bytes: a record never straddles a 128-byte L2 line
 
-struct QNode { float origin[3]; float scale; uint32_t child[4][3]; };
+struct QNode { struct { uint32_t c0, c1, entry; float hdr; } rec[4]; };   // rec[j].hdr: origin.x, origin.y, origin.z, scale
 static_assert(sizeof(QNode) == kQNodeBytes, "quantised node is 64 bytes");
 
 ART_HD float q_pow2_at_least(float r) {            // smallest power of two >= r  (r > 0, finite, normal)
@@ -71,13 +75,18 @@ ART_HD void quantise_node(float* nd, QNode& q) {
     if (fits) break;
     s = s * 2.0f;
   }
-  q.origin[0] = o[0]; q.origin[1] = o[1]; q.origin[2] = o[2]; q.scale = s;
+  q.rec[0].hdr = o[0]; q.rec[1].hdr = o[1]; q.rec[2].hdr = o[2]; q.rec[3].hdr = s;
   for (int j = 0; j < W; ++j) {
     const int32_t ref = __builtin_bit_cast(int32_t, nd[4 * j + 3]), cnt = __builtin_bit_cast(int32_t, nd[4 * W + 4 * j + 3]);
-    if (ref < 0) { q.child[j][0] = 0x00ffffffu; q.child[j][1] = 0u; q.child[j][2] = kQEntryEmpty; continue; }   // lo = 255, hi = 0
-    q.child[j][0] = ql[j][0] | (ql[j][1] << 8) | (ql[j][2] << 16) | (qh[j][0] << 24);
-    q.child[j][1] = qh[j][1] | (qh[j][2] << 8);
-    q.child[j][2] = cnt ? (kQEntryLeaf | ((uint32_t)ref * (uint32_t)kQTriBytes) | (uint32_t)cnt) : ((uint32_t)ref * (uint32_t)kQNodeBytes);
+    uint32_t w0, w1, w2;
+    if (ref < 0) { w0 = 0x00ffffffu; w1 = 0u; w2 = kQEntryEmpty; }   // lo = 255, hi = 0
+    else {
+      w0 = ql[j][0] | (ql[j][1] << 8) | (ql[j][2] << 16) | (qh[j][0] << 24);
+      w1 = qh[j][1] | (qh[j][2] << 8);
+      w2 = cnt ? (kQEntryLeaf | ((uint32_t)ref * (uint32_t)kQTriBytes) | (uint32_t)cnt) : ((uint32_t)ref * (uint32_t)kQNodeBytes);
+    }
+    q.rec[j].c0 = w0; q.rec[j].c1 = w1; q.rec[j].entry = w2;
+    if (ref < 0) continue;
     for (int a = 0; a < 3; ++a) {
       nd[4 * j + a] = __builtin_fmaf((float)ql[j][a], s, o[a]);
       nd[4 * W + 4 * j + a] = __builtin_fmaf((float)qh[j][a], s, o[a]);
