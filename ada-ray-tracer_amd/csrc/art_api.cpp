@@ -291,7 +291,7 @@ static int trace(const DevPaths& q, int n_rays, bool timed = true, const int* it
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     c.ev_pool.push_back(e0); c.ev_pool.push_back(e1);
   }
-  if (coop) launch_analytic(c.stream, c.d_scene, a, c.count_tests);   // outside the trace-kernel event pair
+  if (coop) launch_analytic(c.stream, c.scene, a, c.count_tests);   // outside the trace-kernel event pair
   if (timed) HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used], c.stream));
   // a workgroup keeps 4 waves x (64 / width) rays in flight: a handful of rays (the legacy per-ray seam) gets a handful of workgroups
   const int rays_per_block = 4 * (64 / std::max(1, c.scene.node_width));

@@ -61,7 +61,7 @@ void launch_pad_tris(hipStream_t st, const float* src12, float* dst16, int n);
 void launch_add_f32(hipStream_t st, const float* src, float* dst, size_t n);
 size_t trace_coop_lds_bytes(int stack_entries, int width);
 void launch_trace(hipStream_t st, const DevScene* d_scene, const TraceArgs& A, int kernel, bool stats, int grid_blocks);
-void launch_analytic(hipStream_t st, const DevScene* d_scene, const TraceArgs& A, bool stats);
+void launch_analytic(hipStream_t st, const DevScene& scene, const TraceArgs& A, bool stats);
 int  trace_coop_blocks_per_cu(int stack_entries, int width);
 
 }  // namespace art

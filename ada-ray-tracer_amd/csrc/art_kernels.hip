@@ -440,35 +440,60 @@ __global__ __launch_bounds__(256) void k_trace_overflow(const DevScene* __restri
 // (scene.adb:62-69 candidates 1-4), stores the result as the starting bound of the BVH search and appends
 // the rays that still need the BVH to the live-ray queue (dead rays and decided shadow rays drop out here).
 // ------------------------------------------------------------------------------------------------
+constexpr int kAnalyticLdsSpheres = 64, kAnalyticLdsLights = 16;
 constexpr int kAnalyticChunk = 4096;   // rays per workgroup: ONE global atomic per chunk for the queue (a single hot word
                                        // serves only ~88 atomics/us on this chip, so per-wave atomics were the bottleneck)
 
-__global__ __launch_bounds__(256) void k_analytic(const DevScene* __restrict__ Sp, const TraceArgs A) {
+__global__ __launch_bounds__(256) void k_analytic(const DevScene S, const TraceArgs A) {   // the scene by value: kernel arguments are invariant, so its fields are fetched once, not once per round
   __shared__ int s_idx[kAnalyticChunk];
   __shared__ int s_count, s_live, s_base;
-  const DevScene& S = *Sp;
+  __shared__ DevLight s_lgt[kAnalyticLdsLights];       // ... and its lights (the rect ones are intersected here)
+  __shared__ DevSphere s_sph[kAnalyticLdsSpheres];     // the scene's spheres, fetched once per workgroup: every ray tests every sphere, and a global
+                                                       // load per sphere and ray (the compiler cannot keep them across the stores) is a wait per sphere
   if (threadIdx.x == 0) { s_count = 0; s_live = 0; }
+  const int n_sph_lds = S.n_spheres < kAnalyticLdsSpheres ? S.n_spheres : kAnalyticLdsSpheres;
+  const int n_lgt_lds = S.n_lights < kAnalyticLdsLights ? S.n_lights : kAnalyticLdsLights;
+  if ((int)threadIdx.x < n_sph_lds) s_sph[threadIdx.x] = S.spheres[threadIdx.x];
+  if ((int)threadIdx.x < n_lgt_lds) s_lgt[threadIdx.x] = S.lights[threadIdx.x];
   __syncthreads();
   // compacted work set: only items [0, *item_count) exist; their extension rays are [0, n), their shadow rays [shadow_begin, shadow_begin + n)
   const int n_items = A.item_count ? *A.item_count : 0x7fffffff;
   const int chunk0 = blockIdx.x * kAnalyticChunk;
   if (A.item_count && ((chunk0 >= n_items && chunk0 + kAnalyticChunk <= A.shadow_begin) || chunk0 >= A.shadow_begin + n_items)) return;   // nothing exists in this chunk
+  // Software pipeline over the rounds: the seven loads of round r + 1 are in flight while round r is intersected (one ray per lane has
+  // no other way to overlap its memory round trip with its ~250 instructions of arithmetic).
+  auto exists = [&](int i) { return (i < A.n_rays) && (!A.item_count || ((i < A.shadow_begin) ? (i < n_items) : (i - A.shadow_begin < n_items))); };
+  struct RayIn { float tfar, ox, oy, oz, dx, dy, dz, shm; };
+  auto fetch = [&](int i, bool ok) {
+    RayIn r = {-1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, -1.0f};
+    if (ok) {
+      r.tfar = A.ray_tfar[i]; r.ox = A.ray_ox[i]; r.oy = A.ray_oy[i]; r.oz = A.ray_oz[i]; r.dx = A.ray_dx[i]; r.dy = A.ray_dy[i]; r.dz = A.ray_dz[i];
+      r.shm = (A.sh_min != nullptr && i >= A.shadow_begin) ? A.sh_min[i - A.shadow_begin] : -1.0f;
+    }
+    return r;
+  };
+  RayIn nxt = fetch(chunk0 + (int)threadIdx.x, exists(chunk0 + (int)threadIdx.x));
   for (int k0 = 0; k0 < kAnalyticChunk; k0 += 256) {
     const int i = chunk0 + k0 + threadIdx.x;
     bool queue_it = false, live = false;
-    if ((i < A.n_rays) && (!A.item_count || ((i < A.shadow_begin) ? (i < n_items) : (i - A.shadow_begin < n_items)))) {
-      const float tfar = A.ray_tfar[i];
+    const RayIn cur = nxt;
+    if (k0 + 256 < kAnalyticChunk) nxt = fetch(i + 256, exists(i + 256));
+    {
+      const float tfar = cur.tfar;                       // a ray that does not exist reads as dead
+      const f3 o = mk3(cur.ox, cur.oy, cur.oz), d = mk3(cur.dx, cur.dy, cur.dz);
+      const float shm = cur.shm;
       if (tfar >= 0.0f) {
         live = true;
-        const f3 o = mk3(A.ray_ox[i], A.ray_oy[i], A.ray_oz[i]), d = mk3(A.ray_dx[i], A.ray_dy[i], A.ray_dz[i]);
         Cand best = cand_init(tfar);
-        for (int k = 0; k < S.n_spheres; ++k) isect_sphere(o, d, S.spheres[k], (uint32_t)k, best);
+        for (int k = 0; k < n_sph_lds; ++k) isect_sphere(o, d, s_sph[k], (uint32_t)k, best);
+        for (int k = n_sph_lds; k < S.n_spheres; ++k) isect_sphere(o, d, S.spheres[k], (uint32_t)k, best);
         if (S.has_cornell) isect_cornell(o, d, S, best);
-        for (int k = 0; k < S.n_lights; ++k)
+        for (int k = 0; k < n_lgt_lds; ++k)
+          if (s_lgt[k].shape == LIGHT_RECT) isect_quad(o, d, s_lgt[k], (uint32_t)k, best);
+        for (int k = n_lgt_lds; k < S.n_lights; ++k)
           if (S.lights[k].shape == LIGHT_RECT) isect_quad(o, d, S.lights[k], (uint32_t)k, best);
         isect_bf_mesh(o, d, S, best);
         A.hit_t[i] = best.t; A.hit_key[i] = best.key; A.hit_u[i] = best.u; A.hit_v[i] = best.v;
-        const float shm = (A.sh_min != nullptr && i >= A.shadow_begin) ? A.sh_min[i - A.shadow_begin] : -1.0f;
         const bool near_done = (shm >= 0.0f) && (best.key != KEY_MISS) && (best.t <= shm);   // shadow_rule: decided
         queue_it = (A.n_tris > 0) && !near_done;
       }
@@ -763,7 +788,7 @@ void launch_add_f32(hipStream_t st, const float* src, float* dst, size_t n) {
 
 size_t trace_coop_lds_bytes(int stack_entries, int width) { return (size_t)4 * (64 / width) * (stack_entries + 3) * sizeof(uint2); }   // + 2 guards + sink
 
-void launch_analytic(hipStream_t st, const DevScene* S, const TraceArgs& A, bool stats) {
+void launch_analytic(hipStream_t st, const DevScene& S, const TraceArgs& A, bool stats) {
   TraceArgs B = A;
   if (!stats) B.stats = nullptr;
   hipLaunchKernelGGL(k_analytic, dim3((A.n_rays + kAnalyticChunk - 1) / kAnalyticChunk), dim3(256), 0, st, S, B);
