@@ -1,0 +1,111 @@
+"""BASELINE configurations at their FULL size on the GPU (frame and triangle count of BASELINE.json), through the C ABI.
+
+A whole 1920x1080 or 4096x4096 frame is out of the CPU oracle's reach in a test, so parity at full size is shown in two ways:
+  * sampled pixels: a few thousand pixels spread over the full frame, each compared bit for bit with the oracle's own recursion for
+    exactly those camera samples (orc_sample_radiance, accumulated in the reference's order, integrators.adb:42-51).  The oracle's mesh
+    search walks the exported tree, which tests/test_gpu_parity.py::test_bench_scale_tree_is_sound_and_hits_equal_brute_force checks
+    on its own against the brute-force scan;
+  * size-independent properties of the full frame: pixel-tile shards sum to it, the batch size and the BVH builder do not change it.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import conv
+import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def oracle_pixels(osc, prm, xs, ys, vthreads, background=(0.0, 0.0, 0.0)):
+    """accum of one Render_Pass for the given pixels: per virtual thread color = (((bg + s0) + s1) + s2) + s3, acc = color + acc"""
+    L = orc.lib()
+    out = np.zeros((len(xs), 3), np.float32)
+    s = np.zeros(3, np.float32)
+    for k, (x, y) in enumerate(zip(xs, ys)):
+        acc = np.zeros(3, np.float32)
+        for t in range(vthreads):
+            color = np.array(background, np.float32)
+            for i in range(4):
+                L.orc_sample_radiance(C.byref(osc.scene), C.byref(prm), int(x), int(y), t * 4 + i, orc.fp(s))
+                color = (color + s).astype(np.float32)
+            acc = (color + acc).astype(np.float32)
+        out[k] = acc
+    return out
+
+
+CONFIGS = {
+    # name: (scene builder, width, height, sampled pixels)
+    "c3": (lambda sc: sc.synthetic_scene(100000, 3), 1024, 1024, 3000),
+    "c4": (lambda sc: sc.synthetic_scene(1000000, 4), 1920, 1080, 3000),
+    "c5": (lambda sc: sc.mixed_scene(20000, 5), 4096, 4096, 3000),
+}
+
+
+@pytest.mark.parametrize("config", ["c3", "c4", "c5"])
+def test_full_frame_sampled_pixels_equal_the_oracle(art, backend, config):
+    from ada_ray_tracer_amd import scenes
+    build, W, H, n = CONFIGS[config]
+    sd = build(scenes)
+    backend.upload_scene(sd)
+    backend.resize(W, H)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 1, seed=1)          # one Render_Pass with Threads_Num = 1: 4 spp
+    s0 = backend.stats()
+    accum, _, spp = backend.render_pass(p, 0)
+    assert spp == 4 and accum.shape == (H, W, 3)
+    assert backend.stats().samples - s0.samples == 4 * W * H
+    osc = conv.OracleScene(sd)
+    nodes, tris, info = backend.export_bvh()
+    osc.attach_bvh(nodes, tris, info.node_width)
+    prm = orc.make_params(W, H, orc.PT_MIS, True, 8, 1, seed=1)
+    rng = np.random.default_rng(1234 + len(config))
+    xs = rng.integers(0, W, n); ys = rng.integers(0, H, n)
+    xs[:4] = [0, W - 1, 0, W - 1]; ys[:4] = [0, 0, H - 1, H - 1]      # the frame's corners
+    ref = oracle_pixels(osc, prm, xs, ys, 1)
+    got = accum[ys, xs]
+    assert np.isfinite(ref).all()
+    assert np.abs(got - ref).max() / spp <= 1.0e-4                        # BASELINE's stated tolerance ...
+    assert np.array_equal(bits(got), bits(ref))                           # ... and in fact the same bits
+    assert (ref.sum(1) > 0).mean() > 0.2                                  # the sample is not a set of black pixels (the box fills about half of the frame)
+
+
+def test_c4_full_frame_is_independent_of_shards_batches_and_builder(art, backend):
+    """1M triangles, 1920x1080, 4 spp: the frame is the same bits whether it is rendered whole, in 1 M-path batches, as the sum of two
+    pixel-tile shards (what two GPUs would render), or on the tree of the GPU builder."""
+    from ada_ray_tracer_amd import scenes
+    W, H = 1920, 1080
+    sd = scenes.synthetic_scene(1000000, 4)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 1, seed=1)
+    backend.upload_scene(sd)
+    backend.resize(W, H)
+    full, _, _ = backend.render_pass(p, 0)
+    backend.set_option("batch_paths", 1 << 20)
+    try:
+        backend.resize(W, H)
+        small, _, _ = backend.render_pass(p, 0)
+    finally:
+        backend.set_option("batch_paths", 128 << 20)
+    assert np.array_equal(bits(small), bits(full))
+    total = np.zeros_like(full)
+    try:
+        for r in range(2):
+            backend.set_shard(r, 2, 32)
+            backend.resize(W, H)
+            part, _, _ = backend.render_pass(p, 0)
+            total += part
+    finally:
+        backend.set_shard(0, 1, 32)
+    assert np.array_equal(bits(total), bits(full))
+    backend.set_option("bvh_builder", 1)
+    try:
+        backend.upload_scene(sd)
+        backend.resize(W, H)
+        lbvh, _, _ = backend.render_pass(p, 0)
+    finally:
+        backend.set_option("bvh_builder", 0)
+    assert np.array_equal(bits(lbvh), bits(full))
