@@ -221,7 +221,8 @@ static void carve(DevPaths q[2], int P, int depth) {
     DevPaths& b = q[k];
     b.ray_ox = take(2 * p); b.ray_oy = take(2 * p); b.ray_oz = take(2 * p);
     b.ray_dx = take(2 * p); b.ray_dy = take(2 * p); b.ray_dz = take(2 * p); b.ray_tfar = take(2 * p);
-    b.hit_t = take(2 * p); b.hit_key = (uint32_t*)take(2 * p); b.hit_u = take(2 * p); b.hit_v = take(2 * p);
+    f += (4 - ((f - (float*)g_ctx.b_paths.p) & 3)) & 3;                       // 16-byte records (the allocation has the slack)
+    b.hit = (DevHit*)take(8 * p);
     b.prev_pdf = take(p); b.flags = (uint32_t*)take(p); b.sh_min_t = take(p);
     b.cand_r = take(p); b.cand_g = take(p); b.cand_b = take(p);
     b.slot_id = (const uint32_t*)take(p);
@@ -264,7 +265,7 @@ static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
   { int e; bool o; stack_plan(c.trace_kernel, e, o); a.stack_entries = e; a.stack_overflow = o ? 1 : 0; }
   a.node_min = c.node_min; a.refill_min = c.refill_min; a.segments = c.queue_segments; a.chunk = c.ray_chunk;
   a.ray_ox = q.ray_ox; a.ray_oy = q.ray_oy; a.ray_oz = q.ray_oz; a.ray_dx = q.ray_dx; a.ray_dy = q.ray_dy; a.ray_dz = q.ray_dz; a.ray_tfar = q.ray_tfar;
-  a.hit_t = q.hit_t; a.hit_key = q.hit_key; a.hit_u = q.hit_u; a.hit_v = q.hit_v;
+  a.hit = q.hit;
   a.nodes = c.scene.nodes; a.qnodes = (const uint32_t*)c.b_qnodes.p; a.tris = c.scene.tris; a.qtris = (const float*)c.b_qtris.p; a.n_tris = c.scene.n_tris;
   a.sh_min = (c.shadow_anyhit && q.sh_min_t && n_rays > q.P) ? q.sh_min_t : nullptr; a.shadow_begin = q.P;
   a.cursor = c.d_cursor; a.stats = c.d_counters + 3; a.live_rays = c.d_counters;
@@ -595,7 +596,7 @@ int trace_rays(const float* origins, const float* dirs, const float* tfar, int64
   if (n <= 0 || n > (1ll << 28) || !origins || !dirs || !out) return fail("art_trace_rays: bad arguments");
   if (kernel != TRACE_COOP && kernel != TRACE_SIMPLE) return fail("art_trace_rays: unknown kernel");
   const size_t N = (size_t)n;
-  if (ensure(c.b_rays, N * 11 * 4)) return 1;
+  if (ensure(c.b_rays, N * 12 * 4)) return 1;      // 7 N ray floats, N of padding, N 16-byte hit records
   std::vector<float> soa(7 * N);
   for (size_t i = 0; i < N; ++i) {
     soa[i] = origins[3 * i]; soa[N + i] = origins[3 * i + 1]; soa[2 * N + i] = origins[3 * i + 2];
@@ -604,26 +605,26 @@ int trace_rays(const float* origins, const float* dirs, const float* tfar, int64
   }
   float* d = (float*)c.b_rays.p;
   HIP_TRY(hipMemcpyAsync(d, soa.data(), 7 * N * 4, hipMemcpyHostToDevice, c.stream));
-  HIP_TRY(hipMemsetAsync(d + 7 * N, 0xff, 4 * N * 4, c.stream));
+  HIP_TRY(hipMemsetAsync(d + 8 * N, 0xff, 4 * N * 4, c.stream));
   if (st) HIP_TRY(hipMemsetAsync(c.d_counters + 3, 0, 8 * sizeof(unsigned long long), c.stream));
   DevPaths q; std::memset(&q, 0, sizeof q);
   q.ray_ox = d; q.ray_oy = d + N; q.ray_oz = d + 2 * N; q.ray_dx = d + 3 * N; q.ray_dy = d + 4 * N; q.ray_dz = d + 5 * N; q.ray_tfar = d + 6 * N;
-  q.hit_t = d + 7 * N; q.hit_key = (uint32_t*)(d + 8 * N); q.hit_u = d + 9 * N; q.hit_v = d + 10 * N;
+  q.hit = (DevHit*)(d + 8 * N);                                      // 16-byte aligned: the buffer is, and 8 N floats precede it
   const int saved_kernel = c.trace_kernel; const bool saved_count = c.count_tests;
   c.trace_kernel = kernel; c.count_tests = (st != nullptr);
   const int rc = trace(q, (int)n, /*timed=*/st != nullptr);       // without stats: no events, no counter read-back (the per-ray seam)
   c.trace_kernel = saved_kernel; c.count_tests = saved_count;
   if (rc) return 1;
-  std::vector<float> hits(4 * N);
-  HIP_TRY(hipMemcpyAsync(hits.data(), d + 7 * N, 4 * N * 4, hipMemcpyDeviceToHost, c.stream));
+  std::vector<DevHit> hits(N);
+  HIP_TRY(hipMemcpyAsync(hits.data(), d + 8 * N, N * sizeof(DevHit), hipMemcpyDeviceToHost, c.stream));
   HIP_TRY(hipStreamSynchronize(c.stream));
   HIP_TRY(hipGetLastError());
   HostScene& hs = c.host_scene;
   bind_host_pointers(hs);
   for (size_t i = 0; i < N; ++i) {
     ArtHit& h = out[i];
-    uint32_t key; std::memcpy(&key, &hits[N + i], 4);
-    h.t = hits[i]; h.u = hits[2 * N + i]; h.v = hits[3 * N + i];
+    const uint32_t key = hits[i].key;
+    h.t = hits[i].t; h.u = hits[i].u; h.v = hits[i].v;
     if (key == KEY_MISS) { h.is_hit = 0; h.prim_type = -1; h.prim_index = -1; h.mat_id = -1; h.mat = -1; h.normal[0] = h.normal[1] = h.normal[2] = 0.0f; continue; }
     const f3 o = mk3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), dd = mk3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
     const Surface sf = surface_at(hs.hdr, o, dd, h.t, key, h.u, h.v);

@@ -47,7 +47,7 @@ struct Ctx {
   int opt_blocks_per_cu = 0, blocks_per_cu = 0;
   bool count_tests = false;
   int node_min = 4;
-  int refill_min = 1;
+  int refill_min = 2;            // idle ray groups of a wave take new rays when two of them are idle (1: at once; measured 0.5-1 % slower)
   int queue_segments = 8;       // the live-ray queue is cut into this many contiguous segments, one per XCD (1 = a single cursor)
   int ray_chunk = 16;
   bool shadow_anyhit = true;   // shadow rays use the visibility rule instead of a full closest-hit search (same decision)

@@ -25,7 +25,7 @@ struct TraceArgs {
   // shadow rays (index >= shadow_begin) only feed Compute_Shadow's test  10*eps < t_closest < tfar  (ray_tracer.adb:122):
   // sh_min[i - shadow_begin] = 10*eps.  nullptr: every ray is a closest-hit query.
   const float* sh_min; int32_t shadow_begin;
-  float* hit_t; uint32_t* hit_key; float* hit_u; float* hit_v;
+  DevHit* hit;
   const float* nodes; const uint32_t* qnodes; const float* tris; const float* qtris; int32_t n_tris;   // qnodes: 64-byte quantised nodes (width 4, art_qnode.h)   // BVH of the closest-hit mesh (hot-loop operands)
   int32_t chunk;                // rays a wave claims per atomic on the cursor
   int* cursor;                  // work cursors, zeroed before every launch: segment k's cursor is cursor[32 * (k + 1)] (cursor[0] serves the

@@ -356,11 +356,9 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
     const mask_t done = has_ray & ~pend_valid & vcmp(sa == sb);
     if (done != 0) {
       if (lane_of(done)) {
-        const bool keep_far = far_found && best_key == KEY_MISS;      // shadow ray whose far hit is already stored
-        const uint32_t roff = (uint32_t)ray << 2;
-        if (j == 0 && !keep_far) { st_off(A.hit_t, roff, best_t); st_off(A.hit_key, roff, best_key); }
-        // barycentrics: only a BVH triangle found by this kernel needs storing (analytic / brute-force hits were stored by k_analytic)
-        if (shm < 0.0f && best_key != KEY_MISS && held_key == best_key) { st_off(A.hit_u, roff, held_u); st_off(A.hit_v, roff, held_v); }
+        // Only a hit found by THIS kernel needs storing, by the lane that holds it and as one 16-byte record: the starting bound (no hit,
+        // or an analytic / brute-force hit) was stored by k_analytic, a shadow ray's far hit at the moment it was found (below).
+        if (best_key != KEY_MISS && held_key == best_key) st_off(A.hit, (uint32_t)ray << 4, DevHit{best_t, best_key, held_u, held_v});
       }
       has_ray &= ~done;
     }
@@ -399,7 +397,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       if (ballot64(sh_hit) != 0) {                         // shadow_rule, group-uniform
         const bool near = sh_hit && (win_t <= shm);
         const bool far = sh_hit && !near;                  // first far hit (afterwards the bound is <= shm)
-        if (far && j == 0) { st_off(A.hit_t, (uint32_t)ray << 2, win_t); st_off(A.hit_key, (uint32_t)ray << 2, (uint32_t)win); }
+        if (far && j == 0) st_off(A.hit, (uint32_t)ray << 4, DevHit{win_t, (uint32_t)win, 0.0f, 0.0f});
         far_found = far_found || far;
         best_t = far ? next_up_pos(shm) : best_t;
         best_key = far ? KEY_MISS : best_key;
@@ -431,7 +429,7 @@ __global__ __launch_bounds__(256) void k_trace_overflow(const DevScene* __restri
     BvhStats st = {0, 0, 0, 0};
     const float shm = (A.sh_min != nullptr && i >= A.shadow_begin) ? A.sh_min[i - A.shadow_begin] : -1.0f;
     const Cand c = closest_hit<STATS>(S, mk3(A.ray_ox[i], A.ray_oy[i], A.ray_oz[i]), mk3(A.ray_dx[i], A.ray_dy[i], A.ray_dz[i]), A.ray_tfar[i], &st, shm);
-    A.hit_t[i] = c.t; A.hit_key[i] = c.key; A.hit_u[i] = c.u; A.hit_v[i] = c.v;
+    A.hit[i] = DevHit{c.t, c.key, c.u, c.v};
   }
 }
 
@@ -493,7 +491,7 @@ __global__ __launch_bounds__(256) void k_analytic(const DevScene S, const TraceA
         for (int k = n_lgt_lds; k < S.n_lights; ++k)
           if (S.lights[k].shape == LIGHT_RECT) isect_quad(o, d, S.lights[k], (uint32_t)k, best);
         isect_bf_mesh(o, d, S, best);
-        A.hit_t[i] = best.t; A.hit_key[i] = best.key; A.hit_u[i] = best.u; A.hit_v[i] = best.v;
+        A.hit[i] = DevHit{best.t, best.key, best.u, best.v};
         const bool near_done = (shm >= 0.0f) && (best.key != KEY_MISS) && (best.t <= shm);   // shadow_rule: decided
         queue_it = (A.n_tris > 0) && !near_done;
       }
@@ -521,7 +519,8 @@ __global__ __launch_bounds__(256) void k_analytic(const DevScene S, const TraceA
   for (int k = threadIdx.x; k < s_count; k += 256) {
     const int i = s_idx[k];
     const f3 o = mk3(A.ray_ox[i], A.ray_oy[i], A.ray_oz[i]), d = mk3(A.ray_dx[i], A.ray_dy[i], A.ray_dz[i]);
-    float bt = A.hit_t[i]; uint32_t bk = A.hit_key[i];                        // written above by this workgroup
+    const DevHit h0 = A.hit[i];                                                // written above by this workgroup
+    float bt = h0.t; uint32_t bk = h0.key;
     const float shm = (A.sh_min != nullptr && i >= A.shadow_begin) ? A.sh_min[i - A.shadow_begin] : -1.0f;
     f3 inv, noi; slab_setup(o, d, inv, noi);
     const bool far_found = (shm >= 0.0f) && (bk != KEY_MISS);               // a queued shadow ray with a hit has a far hit (near ones are not queued)
@@ -567,7 +566,7 @@ __global__ __launch_bounds__(256) void k_trace_simple(const DevScene* __restrict
   BvhStats st = {0, 0, 0, 0};
   const float shm = (A.sh_min != nullptr && i >= A.shadow_begin) ? A.sh_min[i - A.shadow_begin] : -1.0f;
   const Cand c = closest_hit<STATS>(S, mk3(A.ray_ox[i], A.ray_oy[i], A.ray_oz[i]), mk3(A.ray_dx[i], A.ray_dy[i], A.ray_dz[i]), tfar, &st, shm);
-  A.hit_t[i] = c.t; A.hit_key[i] = c.key; A.hit_u[i] = c.u; A.hit_v[i] = c.v;
+  A.hit[i] = DevHit{c.t, c.key, c.u, c.v};
   if (STATS) {
     atomicAdd(&A.stats[0], (unsigned long long)st.box_tests); atomicAdd(&A.stats[1], (unsigned long long)st.tri_tests);
     atomicAdd(&A.stats[2], (unsigned long long)st.node_visits); atomicAdd(&A.stats[3], (unsigned long long)st.leaf_visits);
@@ -677,12 +676,13 @@ __global__ __launch_bounds__(256) void k_debug(const DevFrame F, const DevScene 
   if (slot >= Q.P) return;
   uint32_t pixel, sample;
   slot_to_sample(Q, slot, pixel, sample);
-  const uint32_t key = Q.hit_key[slot];
+  const DevHit hq = Q.hit[slot];
+  const uint32_t key = hq.key;
   f3 col = mk3(0.0f, 0.0f, 0.0f);
   int32_t pi = -1, mi = -1, pt = -1;
   if (key != KEY_MISS) {
     const f3 o = mk3(Q.ray_ox[slot], Q.ray_oy[slot], Q.ray_oz[slot]), d = mk3(Q.ray_dx[slot], Q.ray_dy[slot], Q.ray_dz[slot]);
-    const Surface sf = surface_at(S, o, d, Q.hit_t[slot], key, Q.hit_u[slot], Q.hit_v[slot]);
+    const Surface sf = surface_at(S, o, d, hq.t, key, hq.u, hq.v);
     col = debug_palette(sf.mat_id);
     mi = sf.mat_id; pi = (int32_t)(key & KEY_INDEX_MASK);
     const uint32_t cls = key & ~KEY_INDEX_MASK;   // geometry.ads:55 Primitive'Pos: plane 0, sphere 1, triangle 2, quad 3

@@ -24,6 +24,9 @@ struct DevLight {
 
 struct DevSphere { float x, y, z, r; };
 
+// closest hit of a ray, one 16-byte record: every producer writes it and every consumer reads it with ONE 16-byte access
+struct alignas(16) DevHit { float t; uint32_t key; float u, v; };
+
 // Hit key: (class << 28) | index.  Class order == candidate order of Scene.Find_Closest_Hit
 // (scene.adb:62-78: spheres, Cornell box, flat light, mesh) so that the reference's strict-'<' merge
 // is the lexicographic minimum over (t, key).
@@ -83,7 +86,7 @@ struct DevPaths {
   float* ray_dx; float* ray_dy; float* ray_dz;
   float* ray_tfar;
   // hits, same indexing
-  float* hit_t; uint32_t* hit_key; float* hit_u; float* hit_v;
+  DevHit* hit;
   // per-path
   float* prev_pdf;              // MatSample.pdf of the previous bounce
   uint32_t* flags;              // bit0 alive, bit1 prev pureSpecular, bit2 shadow pending, bits 8.. levels recorded

@@ -323,7 +323,7 @@ ART_HD int item_slot(const DevPaths& q, int w) { return q.slot_id ? (int)q.slot_
 ART_HD bool item_survives(const DevFrame& f, const DevScene& s, const DevPaths& qi, int w, int bounce) {
   const uint32_t fl = qi.flags[w];
   if (!(fl & FLAG_ALIVE)) return false;                       // only owed a shadow test: resolved now
-  const uint32_t key = qi.hit_key[w];
+  const uint32_t key = qi.hit[w].key;
   if (key == KEY_MISS) return false;
   const uint32_t cls = key & ~KEY_INDEX_MASK, idx = key & KEY_INDEX_MASK;
   int32_t mat;
@@ -343,15 +343,17 @@ ART_HD void shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi,
   const size_t P = (size_t)qi.P;
   uint32_t fl = qi.flags[w];
   // ---- everything the item holds is read first
-  const uint32_t key = qi.hit_key[w];
+  const DevHit hw = qi.hit[w];
+  const uint32_t key = hw.key;
   const f3 o = mk3(qi.ray_ox[w], qi.ray_oy[w], qi.ray_oz[w]);
   const f3 d = mk3(qi.ray_dx[w], qi.ray_dy[w], qi.ray_dz[w]);
-  const float t = qi.hit_t[w], hu = qi.hit_u[w], hv = qi.hit_v[w];
+  const float t = hw.t, hu = hw.u, hv = hw.v;
   const float prev_pdf = qi.prev_pdf[w];
   if (fl & FLAG_SHADOW_PENDING) {
     // Compute_Shadow: hit and t < maxDist - eps2 (enforced by the ray's tfar clip) and t > 10*eps
     const size_t si = P + (size_t)w;
-    const bool in_shadow = (qi.hit_key[si] != KEY_MISS) && (qi.hit_t[si] > qi.sh_min_t[w]);
+    const DevHit hs = qi.hit[si];
+    const bool in_shadow = (hs.key != KEY_MISS) && (hs.t > qi.sh_min_t[w]);
     const size_t li = (size_t)(bounce - 1) * P + (size_t)slot;
     qi.e_r[li] = in_shadow ? 0.0f : qi.cand_r[w];
     qi.e_g[li] = in_shadow ? 0.0f : qi.cand_g[w];
@@ -483,7 +485,8 @@ ART_HD void resolve_last_shadow(const DevPaths& q, int w, int last_level) {
   if (!(fl & FLAG_SHADOW_PENDING)) return;
   const int slot = item_slot(q, w);
   const size_t si = (size_t)q.P + (size_t)w;
-  const bool in_shadow = (q.hit_key[si] != KEY_MISS) && (q.hit_t[si] > q.sh_min_t[w]);
+  const DevHit hs = q.hit[si];
+  const bool in_shadow = (hs.key != KEY_MISS) && (hs.t > q.sh_min_t[w]);
   const size_t li = (size_t)last_level * (size_t)q.P + (size_t)slot;
   q.e_r[li] = in_shadow ? 0.0f : q.cand_r[w];
   q.e_g[li] = in_shadow ? 0.0f : q.cand_g[w];

@@ -71,7 +71,7 @@ extern "C" int hs_render(const ArtSceneDesc* sd, const ArtPassParams* p, int w, 
   float* f = buf.data(); const size_t pp = (size_t)P;
   auto take = [&](size_t k) { float* r = f; f += k; return r; };
   q.ray_ox = take(2 * pp); q.ray_oy = take(2 * pp); q.ray_oz = take(2 * pp); q.ray_dx = take(2 * pp); q.ray_dy = take(2 * pp); q.ray_dz = take(2 * pp); q.ray_tfar = take(2 * pp);
-  q.hit_t = take(2 * pp); q.hit_key = (uint32_t*)take(2 * pp); q.hit_u = take(2 * pp); q.hit_v = take(2 * pp);
+  std::vector<DevHit> hitbuf(2 * pp); q.hit = hitbuf.data();
   q.prev_pdf = take(pp); q.flags = (uint32_t*)take(pp); q.sh_min_t = take(pp); q.cand_r = take(pp); q.cand_g = take(pp); q.cand_b = take(pp);
   q.e_r = take(D * pp); q.e_g = take(D * pp); q.e_b = take(D * pp); q.w_r = take(D * pp); q.w_g = take(D * pp); q.w_b = take(D * pp);
   q.term_r = take(pp); q.term_g = take(pp); q.term_b = take(pp); q.rad_r = take(pp); q.rad_g = take(pp); q.rad_b = take(pp);
@@ -84,7 +84,7 @@ extern "C" int hs_render(const ArtSceneDesc* sd, const ArtPassParams* p, int w, 
       rays++;
       const float shm = (i >= P) ? q.sh_min_t[i - P] : -1.0f;
       const Cand c = closest_hit<false>(hs.hdr, mk3(q.ray_ox[i], q.ray_oy[i], q.ray_oz[i]), mk3(q.ray_dx[i], q.ray_dy[i], q.ray_dz[i]), q.ray_tfar[i], nullptr, shm);
-      q.hit_t[i] = c.t; q.hit_key[i] = c.key; q.hit_u[i] = c.u; q.hit_v[i] = c.v;
+      q.hit[i] = DevHit{c.t, c.key, c.u, c.v};
     }
   };
 #pragma omp parallel for
