@@ -1,15 +1,19 @@
 // art_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the render backend.
 //
-//   k_trace_coop   the hot kernel.  Persistent workgroups; every wave runs 8 independent rays, one per
-//                  8-lane group.  A BVH8 node is one 256-byte packet: lane j of the group loads child j
-//                  (2 x 16 B, the group reads 2 x 128 contiguous bytes), all 64 lanes run one slab test,
-//                  the hits are ranked with DPP cross-lane compares and pushed far-to-near onto the
-//                  group's traversal stack in LDS.  Leaves hold <= 8 triangles: one Moeller-Trumbore
-//                  test per lane, then a 3-step DPP min-reduction.  Rays are pulled in chunks from a
-//                  global atomic cursor (one atomic per 64 rays) and handed to idle groups by ballot.
-//   k_trace_simple one ray per lane, private stack -- the reference traversal used to cross-check.
-//   k_raygen / k_shade / k_finish / k_accumulate / k_resolve / k_debug   wavefront path-tracing stages
-//                  (thin wrappers over the per-slot functions in art_shade.h).
+//   k_trace_coop   the hot kernel (about 88 % of the GPU time).  Persistent workgroups; a wave runs 64 / G independent rays, one per
+//                  G-lane group (G = 4 by default: a DPP quad; G = 8 is the option bvh_width=8).  G = 4: a node of the 4-wide tree is one
+//                  64-byte packet of four 16-byte lane records (art_qnode.h): lane j reads record j with ONE load, the quad reads 64
+//                  contiguous bytes, the node's origin / scale words are broadcast inside the quad by DPP, all 64 lanes run one slab test,
+//                  the hits are ranked by a DPP borrow chain and pushed far-to-near onto the ray's traversal stack in LDS.  A leaf holds
+//                  <= G triangles: one Moeller-Trumbore test (reference arithmetic) per lane, then a DPP min-reduction over (t, key).
+//                  Rays come as 64-byte trace records in queue order (prepared by k_analytic), pulled in 16-record chunks from one atomic
+//                  cursor per XCD segment, the whole chunk prefetched with one load per lane, handed to idle groups by ballot.
+//   k_analytic     one ray per lane: spheres, Cornell box, rect lights, the reference's brute-force mesh; writes the starting bound of
+//                  the BVH search and the trace record of every ray that needs it (incl. slab_setup's three divisions).
+//   k_trace_simple one ray per lane, private stack -- the traversal used to cross-check; k_trace_overflow finishes the rays whose
+//                  stack did not fit the capped LDS stack of k_trace_coop<.., OVF = true>.
+//   k_raygen / k_shade_compact / k_resolve_last / k_fold / k_accumulate / k_resolve / k_debug   wavefront path-tracing stages over
+//                  compacted work sets (per-item functions in art_shade.h); k_shade / k_finish: the plain in-place schedule.
 //
 // Replaces Scene.Find_Closest_Hit (scene.adb:56-86), the Embree bridge (embree_connect.cpp:196-238),
 // PathTrace (ray_tracer-integrators.adb:82-301) and the DoPass pixel loop (integrators.adb:25-71).
@@ -164,7 +168,7 @@ template <class T> __device__ __forceinline__ void st_off(T* base, uint32_t byte
 // G = lanes per ray = children per node = triangles per leaf (4 or 8); 64 / G rays per wave.  OVF: the LDS stack holds fewer entries
 // than the tree's worst-case bound, so a push is checked and a ray that would not fit is handed to k_trace_overflow.
 //
-// G = 4 walks the 64-byte quantised nodes (art_qnode.h): the kernel is bound by the bytes that miss in L2, and they halve.  A stack
+// G = 4 walks the 64-byte quantised nodes (art_qnode.h).  A stack
 // entry is { child entry word, bits(tmin) }: the entry word is the node's byte offset (inner child) or 0x80000000 | triangle byte
 // offset | count (leaf), exactly as stored in the node, so a pop needs no decoding.  G = 8 walks the binary32 256-byte nodes; its
 // entry word is (ref << 4) | count.

@@ -1,10 +1,10 @@
 // art_qnode.h -- the 64-byte quantised node of the 4-wide tree, the form k_trace_coop reads.
 //
-// Why: k_trace_coop is bound by the bytes it pulls through the L2-miss path (round-2 experiment: one more scattered 128-byte node
-// read per step made it 1.83x slower, 16 more VALU instructions per step 4 % slower), and node packets are ~90 % of those bytes.
-// A 4-wide node with binary32 child boxes is 128 B; the same node with the child boxes quantised to 8 bits per plane relative to
-// the node's own origin is 64 B.  The search result cannot depend on the boxes as long as they stay conservative, so the image and
-// every hit stay bit-identical; only the traversal counters move (slightly looser boxes).
+// Why: a 4-wide node with binary32 child boxes is 128 B; the same node with the child boxes quantised to 8 bits per plane relative to
+// the node's own origin is 64 B -- half the lines a ray pulls through L2 (measured when it went in, round 2: 77.5 -> 69.1 ms per trace
+// launch on the 1M-triangle scene) and, in the lane-record form below, ONE 16-byte load per lane and node step.  The search result
+// cannot depend on the boxes as long as they stay conservative, so the image and every hit stay bit-identical; only the traversal
+// counters move (slightly looser boxes: +2.5 % node visits).
 //
 //   bytes 16j..16j+15   lane record j (j = 0..3):  { qlo.x qlo.y qlo.z qhi.x | qhi.y qhi.z 0 0 | entry | header word j }
 //   header words   0: origin.x   1: origin.y   2: origin.z   3: scale        binary32; scale is a power of two, shared by the three axes
