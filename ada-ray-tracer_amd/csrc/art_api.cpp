@@ -279,7 +279,7 @@ static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
 static int trace(const DevPaths& q, int n_rays, bool timed = true, const int* item_count = nullptr) {
   Ctx& c = g_ctx;
   const bool coop = (c.trace_kernel == TRACE_COOP);
-  if (coop && ensure(c.b_queue, ((size_t)n_rays + 16) * kTraceRecBytes)) return 1;      // live-ray queue: one 64-byte trace record per queued ray (+ one chunk of slack for the chunk prefetch)
+  if (coop && ensure(c.b_queue, ((size_t)n_rays + 4096) * kTraceRecBytes)) return 1;      // live-ray queue: one 64-byte trace record per queued ray (+ one chunk of slack for the chunk prefetch)
   TraceArgs a; fill_trace_args(a, q, n_rays);
   a.item_count = item_count;
   if (coop && a.stack_overflow && ensure(c.b_ovf, (size_t)n_rays * sizeof(int))) return 1;
@@ -833,7 +833,7 @@ static int set_option_one(const std::string& n, int64_t value) {
   else if (n == "blocks_per_cu") { g_ctx.opt_blocks_per_cu = (int)value; g_ctx.blocks_per_cu = 0; }
   else if (n == "count_tests") { g_ctx.count_tests = value != 0; }
   else if (n == "shadow_anyhit") { g_ctx.shadow_anyhit = value != 0; }
-  else if (n == "ray_chunk") { if (value < 8 || value > 4096) return fail("ray_chunk: 8..4096"); g_ctx.ray_chunk = (int)value; }
+  else if (n == "ray_chunk") { if (value < 16 || value > 4096 || (value & 15)) return fail("ray_chunk: a multiple of 16, 16..4096"); g_ctx.ray_chunk = (int)value; }
   else if (n == "refill_min") { if (value < 1 || value > 8) return fail("refill_min: 1..8"); g_ctx.refill_min = (int)value; }
   else if (n == "node_min") { if (value < 1 || value > 8) return fail("node_min: 1..8"); g_ctx.node_min = (int)value; }
   else if (n == "bvh_width") { if (value != 4 && value != 8) return fail("bvh_width: 4 or 8"); g_ctx.bvh_params.width = (int)value; }

@@ -234,9 +234,9 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
           if (--segs_left == 0) { exhausted = true; break; }
           continue;
         }
-        // the chunk's records (16 x 64 B = one 16-byte load per lane) on their way into the cache before the first group asks for its own
+        // the chunk's records (16 x 64 B = one load per lane, per 16 records) on their way into the cache before the first group asks for its own
         // (the value is only "used" after the refill's own loads below, so that nothing waits for it alone)
-        if (A.chunk == 16) pf_keep = reinterpret_cast<const float*>(A.rec)[((size_t)chunk_pos * 4 + lane) * 4];
+        for (int c16 = 0; c16 < A.chunk; c16 += 16) pf_keep += reinterpret_cast<const float*>(A.rec)[((size_t)(chunk_pos + c16) * 4 + lane) * 4];
       }
       const int avail = chunk_end - chunk_pos;
       const int n_need = __popcll(need_mask);
