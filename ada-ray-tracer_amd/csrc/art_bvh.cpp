@@ -113,14 +113,14 @@ struct Builder {
     auto cen_of = [](const Ref& r, int a) { return 0.5f * r.box.lo[a] + 0.5f * r.box.hi[a]; };
 
     // ---- object split: binned SAH over the reference centroids
-    constexpr int NB = 32;
+    constexpr int NBMAX = 128; const int NB = prm.sah_bins;
     float best_cost = INFINITY; int best_axis = -1, best_bin = -1;
     Box best_lbox, best_rbox; best_lbox.reset(); best_rbox.reset();
     const float parent_area = nd.box.half_area();
     for (int a = 0; a < 3; ++a) {
       const float ext = cb.hi[a] - cb.lo[a];
       if (!(ext > 0.0f)) continue;
-      Box bb[NB]; int32_t bc[NB];
+      Box bb[NBMAX]; int32_t bc[NBMAX];
       for (int b = 0; b < NB; ++b) { bb[b].reset(); bc[b] = 0; }
       const float scale = (float)NB / ext;
       for (const Ref& r : refs) {
@@ -128,7 +128,7 @@ struct Builder {
         b = std::min(std::max(b, 0), NB - 1);
         bb[b].grow(r.box); bc[b]++;
       }
-      float la[NB]; int32_t lc[NB]; Box lb[NB];
+      float la[NBMAX]; int32_t lc[NBMAX]; Box lb[NBMAX];
       Box acc; acc.reset(); int32_t c = 0;
       for (int b = 0; b < NB - 1; ++b) { acc.grow(bb[b]); c += bc[b]; la[b] = acc.half_area(); lc[b] = c; lb[b] = acc; }
       acc.reset(); c = 0;

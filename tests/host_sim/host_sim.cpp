@@ -26,6 +26,8 @@ extern "C" void hs_set_bvh_param(const char* name, double v) {
   else if (n == "node_cost") g_bp.node_cost = (float)v;
   else if (n == "leaf_base") g_bp.leaf_base = (float)v;
   else if (n == "tri_cost") g_bp.tri_cost = (float)v;
+  else if (n == "sah_bins") g_bp.sah_bins = (int)v;
+
 }
 
 extern "C" const char* hs_last_error() { return g_err.c_str(); }
