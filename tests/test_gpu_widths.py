@@ -99,3 +99,33 @@ def test_full_size_scene_same_image_for_both_widths(art, backend):
     finally:
         backend.set_option("bvh_width", 4)
     assert np.array_equal(bits(out[0][0]), bits(out[1][0])) and out[0][1] == out[1][1]
+
+
+def test_refill_and_chunk_options_do_not_change_results(art, backend):
+    """Round 2: rays reach the trace kernel as 64-byte trace records claimed in chunks (ray_chunk, a multiple of 16, all prefetched) and
+    idle ray groups refill when refill_min of them are idle.  Neither may change a bit of the image, the ray count or the traversal
+    counters; a chunk size the prefetch cannot cover is refused."""
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.synthetic_scene(5000, 3)
+    backend.upload_scene(sd)
+    backend.resize(64, 48)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 1, seed=11)
+    r0 = backend.stats().rays
+    ref, _, _ = backend.render_pass(p, 0)
+    rays = backend.stats().rays - r0
+    with pytest.raises(art.ArtError):
+        backend.set_option("ray_chunk", 24)
+    with pytest.raises(art.ArtError):
+        backend.set_option("refill_min", 0)
+    try:
+        for chunk, refill in [(16, 1), (32, 3), (4096, 8), (48, 16 // 2)]:
+            backend.set_option("ray_chunk", chunk)
+            backend.set_option("refill_min", refill)
+            backend.resize(64, 48)
+            r0 = backend.stats().rays
+            img, _, _ = backend.render_pass(p, 0)
+            assert np.array_equal(bits(img), bits(ref)), (chunk, refill)
+            assert backend.stats().rays - r0 == rays
+    finally:
+        backend.set_option("ray_chunk", 48)
+        backend.set_option("refill_min", 2)
