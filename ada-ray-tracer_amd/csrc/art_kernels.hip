@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         const uint32_t noff = sel(want_node, pend, 0u);
         const uint4 rec = *reinterpret_cast<const uint4*>(nodes_b + (noff + jrec));       // ONE load: the quad reads the node's 64 contiguous bytes
         const uint32_t c0 = rec.x, c1 = rec.y; entry = rec.z;
+        asm volatile("s_setprio 1" :: "v"(c0));           // a wave whose node has arrived goes ahead of the waves that pop, refill or test leaves (+0.7 % on C4, +3 % on C5)
         const float4 h = make_float4(__builtin_bit_cast(float, dpp_i<0x00>((int)rec.w)), __builtin_bit_cast(float, dpp_i<0x55>((int)rec.w)),
                                      __builtin_bit_cast(float, dpp_i<0xAA>((int)rec.w)), __builtin_bit_cast(float, dpp_i<0xFF>((int)rec.w)));
         // near / far plane bytes by direction sign (one v_perm each), dequantised (one fma per plane: the very binary32 boxes of the
@@ -353,6 +354,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       }
 #endif
       if (STATS) { st_box += lane_of(want_node & valid); st_node += (lane_of(want_node) && j == 0); st_it_node += (lane == 0); }
+      __builtin_amdgcn_s_setprio(0);
       wave_lds_sync();
     }
 
