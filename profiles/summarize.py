@@ -28,8 +28,11 @@ def main(tag, name="c4"):
     os.makedirs(dst, exist_ok=True)
     shutil.copyfile(newest(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv")), os.path.join(dst, "kernel_stats.csv"))
     out = {}
-    for name in ("fetch", "write", "sq", "tcc"):
-        rows = list(csv.DictReader(open(newest(os.path.join(SRC, name, "*", "*_counter_collection.csv")))))
+    for name in ("fetch", "write", "sq", "tcc", "ta", "ta2", "tcp", "tcp2", "tcp3", "sq2"):
+        try:
+            rows = list(csv.DictReader(open(newest(os.path.join(SRC, name, "*", "*_counter_collection.csv")))))
+        except ValueError:
+            continue                                              # a pass this collection did not take
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         disp = collections.defaultdict(dict)
         for r in rows:
@@ -53,6 +56,19 @@ def main(tag, name="c4"):
                 o["effective_clock_GHz"] = o["GRBM_GUI_ACTIVE"] / 8.0 / o["total_ns_sq"]
             if "TCC_HIT_sum" in o:
                 o["l2_hit_rate"] = o["TCC_HIT_sum"] / (o["TCC_HIT_sum"] + o["TCC_MISS_sum"])
+            # utilisation of the units the kernel could be limited by (collect_util.sh).  GRBM_GUI_ACTIVE / 8 = busy cycles of one XCD summed
+            # over the launches; SQ_* are in quad-cycles summed over the waves (8 per SIMD); TA / TCP: one instance per CU (256).
+            if "GRBM_GUI_ACTIVE" in o and "TA_BUSY_avr" in o:
+                cyc = o["GRBM_GUI_ACTIVE"] / 8.0
+                u = {"ta_busy_avg": o["TA_BUSY_avr"] / cyc, "ta_busy_max_instance": o["TA_BUSY_max"] / cyc}
+                if "TCP_PENDING_STALL_CYCLES_sum" in o: u["tcp_pending_stall"] = o["TCP_PENDING_STALL_CYCLES_sum"] / 256.0 / cyc
+                if "TCP_TCC_READ_REQ_sum" in o: u["l1_to_l2_read_latency_cycles"] = o["TCP_TCC_READ_REQ_LATENCY_sum"] / o["TCP_TCC_READ_REQ_sum"]
+                if "SQ_WAVE_CYCLES" in o:
+                    u["valu_issue_slots_if_4_cycles_each"] = 8.0 * o["SQ_ACTIVE_INST_VALU"] / o["SQ_WAVE_CYCLES"]
+                    if "SQ_ACTIVE_INST_LDS" in o: u["lds_active"] = 8.0 * o["SQ_ACTIVE_INST_LDS"] / o["SQ_WAVE_CYCLES"]
+                if "SQ_INSTS_VMEM_RD" in o:
+                    u["vmem_read_insts_per_launch"] = o["SQ_INSTS_VMEM_RD"] / o["dispatches_sq2"]; u["lds_insts_per_launch"] = o["SQ_INSTS_LDS"] / o["dispatches_sq2"]
+                o["utilisation"] = u
     b = os.path.join(SRC, "bench_under_rocprof.json")
     if os.path.exists(b):
         shutil.copyfile(b, os.path.join(dst, "bench_under_rocprof.json"))
