@@ -279,6 +279,7 @@ static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
 static int trace(const DevPaths& q, int n_rays, bool timed = true, const int* item_count = nullptr) {
   Ctx& c = g_ctx;
   const bool coop = (c.trace_kernel == TRACE_COOP);
+  if ((int64_t)n_rays > (1ll << 28)) return fail("internal: more than 2^28 rays in one trace launch (32-bit byte offsets of the 16-byte hit records)");
   if (coop && ensure(c.b_queue, ((size_t)n_rays + 4096) * kTraceRecBytes)) return 1;      // live-ray queue: one 64-byte trace record per queued ray (+ one chunk of slack for the chunk prefetch)
   TraceArgs a; fill_trace_args(a, q, n_rays);
   a.item_count = item_count;
@@ -679,7 +680,7 @@ int art_init(int device_ordinal) {
   if (g_ctx.device_ready && device_ordinal >= 0 && device_ordinal != g_ctx.device) return fail("art_init: already bound to another device; call art_shutdown first");
   g_ctx.device = device_ordinal;
   if (const char* e = getenv("ART_TRACE_KERNEL")) g_ctx.trace_kernel = (std::strcmp(e, "simple") == 0) ? TRACE_SIMPLE : TRACE_COOP;
-  if (const char* e = getenv("ART_BATCH_PATHS")) g_ctx.batch_paths = std::max<int64_t>(1024, atoll(e));
+  if (const char* e = getenv("ART_BATCH_PATHS")) g_ctx.batch_paths = std::min<int64_t>(1ll << 27, std::max<int64_t>(1024, atoll(e)));
   return ensure_device();
 }
 
@@ -829,7 +830,7 @@ int art_set_option(const char* name, int64_t value) {      // applies to every d
 static int set_option_one(const std::string& n, int64_t value) {
   if (n == "trace_kernel") { if (value != TRACE_COOP && value != TRACE_SIMPLE) return fail("trace_kernel: 0 (cooperative) or 1 (simple)"); g_ctx.trace_kernel = (int)value; }
   else if (n == "queue_segments") { if (value != 1 && value != 2 && value != 4 && value != 8) return fail("queue_segments: 1, 2, 4 or 8"); g_ctx.queue_segments = (int)value; }
-  else if (n == "batch_paths") { if (value < 1024 || value > (1ll << 29)) return fail("batch_paths: 1024..2^29 (ray indices are 32-bit: 2 rays per path slot)"); g_ctx.batch_paths = value; }
+  else if (n == "batch_paths") { if (value < 1024 || value > (1ll << 27)) return fail("batch_paths: 1024..2^27 (2 rays per path slot; the trace kernel addresses a ray's 16-byte hit record by a 32-bit byte offset)"); g_ctx.batch_paths = value; }
   else if (n == "blocks_per_cu") { g_ctx.opt_blocks_per_cu = (int)value; g_ctx.blocks_per_cu = 0; }
   else if (n == "count_tests") { g_ctx.count_tests = value != 0; }
   else if (n == "shadow_anyhit") { g_ctx.shadow_anyhit = value != 0; }
