@@ -21,16 +21,16 @@ struct TraceArgs {
   const float* ray_ox; const float* ray_oy; const float* ray_oz;
   const float* ray_dx; const float* ray_dy; const float* ray_dz;
   const float* ray_tfar;        // < 0: skip
-  float4* rec;                  // k_analytic -> k_trace_coop: one 64-byte record per QUEUED ray, in queue order (kTraceRec* below); n_rays + 16 records
+  float4* rec;                  // k_analytic -> k_trace_coop: one 64-byte record per QUEUED ray, in queue order (layout below); n_rays + 4096 records (slack for the chunk prefetch)
   // shadow rays (index >= shadow_begin) only feed Compute_Shadow's test  10*eps < t_closest < tfar  (ray_tracer.adb:122):
   // sh_min[i - shadow_begin] = 10*eps.  nullptr: every ray is a closest-hit query.
   const float* sh_min; int32_t shadow_begin;
   DevHit* hit;
   const float* nodes; const uint32_t* qnodes; const float* tris; const float* qtris; int32_t n_tris;   // qnodes: 64-byte quantised nodes (width 4, art_qnode.h)   // BVH of the closest-hit mesh (hot-loop operands)
-  int32_t chunk;                // rays a wave claims per atomic on the cursor
+  int32_t chunk;                // trace records a wave claims per atomic on the cursor (a multiple of 16: prefetched 16 records per load)
   int* cursor;                  // work cursors, zeroed before every launch: segment k's cursor is cursor[32 * (k + 1)] (cursor[0] serves the
                                 // kernels with a single cursor)
-  int* queue; int* queue_count; // live-ray queue filled by k_analytic (indices into the ray arrays), count zeroed before every launch
+  int* queue; int* queue_count; // queue_count: number of trace records k_analytic queued, zeroed before every launch (queue: the same buffer as rec)
   int* ovf_queue; int* ovf_count;   // stack_overflow: rays handed to k_trace_overflow, count zeroed before every launch
   unsigned long long* stats;    // [box, tri, node, leaf, rays] when counting
   unsigned long long* live_rays;   // += closest-hit queries actually issued by this launch (Mrays/s numerator)

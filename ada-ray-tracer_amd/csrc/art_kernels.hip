@@ -219,8 +219,8 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
     while (!exhausted) {
       const mask_t need_mask = ~has_ray & leaders;
       if (need_mask == 0) break;
-      // a refill costs the whole wave ~120 instructions (ray fetch, three correctly rounded divisions, retire stores) whatever the number
-      // of rays it brings in: wait until refill_min groups are idle, unless the wave has nothing else to do
+      // a refill costs the whole wave its instructions (four record loads, ~30 VALU) whatever the number of rays it brings in: wait until
+      // refill_min groups are idle, unless the wave has nothing else to do
       if (__popcll(need_mask) < A.refill_min && has_ray != 0) break;
       if (chunk_pos == chunk_end) {
         const int seg_lo = (int)(((int64_t)n_queue * seg) >> seg_shift), seg_hi = (int)(((int64_t)n_queue * (seg + 1)) >> seg_shift);   // n_seg is a power of two
