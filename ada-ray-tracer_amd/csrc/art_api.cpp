@@ -101,8 +101,7 @@ static int upload_scene_arrays(HostScene& hs) {
   if (upload(c.b_spheres, hs.spheres) || upload(c.b_sphere_mat, hs.sphere_mat) || upload(c.b_lights, hs.lights) ||
       upload(c.b_materials, hs.materials) || upload(c.b_bf_pos, hs.bf_pos) || upload(c.b_bf_nrm, hs.bf_nrm) ||
       upload(c.b_bf_uv, hs.bf_uv) || upload(c.b_bf_idx, hs.bf_idx) || (!hs.gpu_built && upload(c.b_nodes, hs.bvh.nodes)) || (!hs.gpu_built && upload(c.b_qnodes, hs.bvh.qnodes)) ||
-      (!hs.gpu_built && upload(c.b_tris, hs.bvh.tris)) || upload(c.b_m_nrm, hs.m_nrm) || upload(c.b_m_uv, hs.m_uv) ||
-      upload(c.b_m_idx, hs.m_idx) || upload(c.b_m_matid, hs.m_matid))
+      (!hs.gpu_built && upload(c.b_tris, hs.bvh.tris)) || upload(c.b_m_shade, hs.m_shade))
     return 1;
   DevScene& s = c.scene;
   s = hs.hdr;
@@ -110,7 +109,7 @@ static int upload_scene_arrays(HostScene& hs) {
   s.lights = (const DevLight*)c.b_lights.p; s.materials = (const DevMaterial*)c.b_materials.p;
   s.bf_pos = (const float*)c.b_bf_pos.p; s.bf_nrm = (const float*)c.b_bf_nrm.p; s.bf_uv = (const float*)c.b_bf_uv.p; s.bf_idx = (const int32_t*)c.b_bf_idx.p;
   s.nodes = (const float*)c.b_nodes.p; s.tris = (const float*)c.b_tris.p;
-  s.m_nrm = (const float*)c.b_m_nrm.p; s.m_uv = (const float*)c.b_m_uv.p; s.m_idx = (const int32_t*)c.b_m_idx.p; s.m_matid = (const int32_t*)c.b_m_matid.p;
+  s.m_shade = (const float*)c.b_m_shade.p;
   if (!c.d_scene) HIP_TRY(hipMalloc(&c.d_scene, sizeof(DevScene)));
   HIP_TRY(hipMemcpy(c.d_scene, &s, sizeof(DevScene), hipMemcpyHostToDevice));
   return 0;
@@ -651,7 +650,7 @@ void shutdown() {
     if (c.device >= 0) (void)hipSetDevice(c.device);
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c.b_spheres, &c.b_sphere_mat, &c.b_lights, &c.b_materials, &c.b_bf_pos, &c.b_bf_nrm, &c.b_bf_uv, &c.b_bf_idx,
-                      &c.b_nodes, &c.b_qnodes, &c.b_tris, &c.b_qtris, &c.b_m_nrm, &c.b_m_uv, &c.b_m_idx, &c.b_m_matid, &c.b_accum, &c.b_screen, &c.b_stage,
+                      &c.b_nodes, &c.b_qnodes, &c.b_tris, &c.b_qtris, &c.b_m_shade, &c.b_accum, &c.b_screen, &c.b_stage,
                       &c.b_pixmap, &c.b_paths, &c.b_rays, &c.b_ids, &c.b_queue, &c.b_ovf};
     for (DevBuf* b : bufs) b->release();
     if (c.d_cursor) (void)hipFree(c.d_cursor);

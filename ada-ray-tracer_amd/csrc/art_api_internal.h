@@ -26,7 +26,7 @@ struct Ctx {
   DevScene scene;
   DevScene* d_scene = nullptr;                 // the same header in HBM (the trace kernels take it by pointer)
   BvhBuildParams bvh_params;
-  DevBuf b_spheres, b_sphere_mat, b_lights, b_materials, b_bf_pos, b_bf_nrm, b_bf_uv, b_bf_idx, b_nodes, b_qnodes, b_tris, b_qtris, b_m_nrm, b_m_uv, b_m_idx, b_m_matid;
+  DevBuf b_spheres, b_sphere_mat, b_lights, b_materials, b_bf_pos, b_bf_nrm, b_bf_uv, b_bf_idx, b_nodes, b_qnodes, b_tris, b_qtris, b_m_shade;
   int bvh_stack_bound = 8;      // worst-case traversal stack of the uploaded tree
   int lds_stack_cap = 0;        // option: force the LDS stack size (tests of the overflow path)
   // frame

@@ -76,10 +76,12 @@ bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& o
       if (!m.matid) { err = "scene: CLOSEST mesh needs material_ids"; return false; }
       for (int i = 0; i < m.ntris; ++i) if (!mat_ok(m.matid[i])) { err = "scene: triangle material id out of range"; return false; }
       out.m_pos.assign(m.pos, m.pos + 3 * (size_t)m.nverts);
-      out.m_nrm.assign(m.nrm, m.nrm + 3 * (size_t)m.nverts);
-      if (m.uv) out.m_uv.assign(m.uv, m.uv + 2 * (size_t)m.nverts); else out.m_uv.assign(2 * (size_t)m.nverts, 0.0f);
-      out.m_idx.assign(m.idx, m.idx + 3 * (size_t)m.ntris);
-      out.m_matid.assign(m.matid, m.matid + m.ntris);
+      out.m_shade.assign((size_t)kTriShadeFloats * (size_t)m.ntris, 0.0f);        // texcoords are zeroed by the reference's loader and never read
+      for (int i = 0; i < m.ntris; ++i) {
+        float* r = &out.m_shade[(size_t)kTriShadeFloats * (size_t)i];
+        for (int k = 0; k < 3; ++k) std::memcpy(r + 3 * k, m.nrm + 3 * (size_t)m.idx[3 * (size_t)i + k], 12);
+        std::memcpy(r + 9, &m.matid[i], 4);
+      }
       std::vector<float> tri9(9 * (size_t)m.ntris);
       for (int i = 0; i < m.ntris; ++i)
         for (int k = 0; k < 3; ++k) std::memcpy(&tri9[9 * (size_t)i + 3 * k], m.pos + 3 * (size_t)m.idx[3 * (size_t)i + k], 12);
@@ -113,7 +115,7 @@ void bind_host_pointers(HostScene& hs) {
   h.lights = hs.lights.data(); h.materials = hs.materials.data();
   h.bf_pos = hs.bf_pos.data(); h.bf_nrm = hs.bf_nrm.data(); h.bf_uv = hs.bf_uv.data(); h.bf_idx = hs.bf_idx.data();
   h.nodes = hs.bvh.nodes.data(); h.tris = hs.bvh.tris.data();
-  h.m_nrm = hs.m_nrm.data(); h.m_uv = hs.m_uv.data(); h.m_idx = hs.m_idx.data(); h.m_matid = hs.m_matid.data();
+  h.m_shade = hs.m_shade.data();
 }
 
 }  // namespace art

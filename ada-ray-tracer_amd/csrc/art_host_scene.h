@@ -17,7 +17,7 @@ struct HostScene {
   std::vector<float> bf_pos, bf_nrm, bf_uv; std::vector<int32_t> bf_idx;
   int32_t bf_ntris = 0;
   // closest-hit mesh
-  std::vector<float> m_nrm, m_uv; std::vector<int32_t> m_idx, m_matid;
+  std::vector<float> m_shade;   // kTriShadeFloats per triangle: vertex normals of A, B, C and the material id (art_scene.h)
   std::vector<float> m_pos;   // kept for gcore-style geometric normals / export
   Bvh8 bvh;
   std::vector<float> deferred_tri9;   // builder == 1: triangle corners for the GPU build (bvh stays empty until then)

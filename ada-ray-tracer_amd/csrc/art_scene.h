@@ -43,6 +43,7 @@ constexpr uint32_t KEY_INDEX_MASK = (1u << 28) - 1u;
 constexpr int kNodeFloats = 64;      // W = 8; a node of width W has node_floats(W) floats
 constexpr int node_floats(int width) { return 8 * width; }
 constexpr int kTriFloats = 12;
+constexpr int kTriShadeFloats = 16;  // nA.xyz nB.xyz nC.xyz matId, padded to 64 bytes
 constexpr int kMaxLeafTris = 8;
 constexpr int kStackEntries = 160;  // private stack of the one-ray-per-lane traversal; art_upload_scene rejects deeper trees
 
@@ -61,7 +62,9 @@ struct DevScene {
   // closest-hit mesh behind the BVH
   int32_t n_tris; int32_t n_nodes; int32_t node_width;   // node_width: 8 or 4 children per node
   const float* nodes; const float* tris;
-  const float* m_nrm; const float* m_uv; const int32_t* m_idx; const int32_t* m_matid;
+  // shading data of the closest-hit mesh, one 64-byte record per triangle (by prim index): the three vertex normals and the material id --
+  // ONE line fetch per shaded hit instead of five scattered ones (index triple, three normals, material id)
+  const float* m_shade;
   // camera (scene.ads:27-32)
   float cam_pos[3];
   float cam_matrix[16];

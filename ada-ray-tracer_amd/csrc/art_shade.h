@@ -266,12 +266,17 @@ ART_HD Surface surface_at(const DevScene& s, f3 o, f3 d, float t, uint32_t key, 
     sf.normal = mk3(0.0f, -1.0f, 0.0f);
     sf.mat = s.lights[idx].mat; sf.mat_id = 0;
   } else {
-    const bool bf = (cls == KEY_BFTRI);
-    const int32_t* ix = (bf ? s.bf_idx : s.m_idx) + 3 * (size_t)idx;
-    const float* nr = bf ? s.bf_nrm : s.m_nrm;
     const float w = 1.0f - u - v;                               // geometry.adb:301
-    sf.normal = (w * ld3(nr + 3 * (size_t)ix[0]) + v * ld3(nr + 3 * (size_t)ix[1])) + u * ld3(nr + 3 * (size_t)ix[2]);
-    sf.mat_id = bf ? 2 : s.m_matid[idx];                        // geometry.adb:311 hard-codes 2
+    if (cls == KEY_BFTRI) {
+      const int32_t* ix = s.bf_idx + 3 * (size_t)idx;
+      const float* nr = s.bf_nrm;
+      sf.normal = (w * ld3(nr + 3 * (size_t)ix[0]) + v * ld3(nr + 3 * (size_t)ix[1])) + u * ld3(nr + 3 * (size_t)ix[2]);
+      sf.mat_id = 2;                                            // geometry.adb:311 hard-codes 2
+    } else {
+      const float* r = s.m_shade + (size_t)kTriShadeFloats * (size_t)idx;      // the triangle's own record: normals of A, B, C and the material id
+      sf.normal = (w * ld3(r) + v * ld3(r + 3)) + u * ld3(r + 6);
+      sf.mat_id = __builtin_bit_cast(int32_t, r[9]);
+    }
     sf.mat = sf.mat_id;
   }
   return sf;
@@ -331,7 +336,7 @@ ART_HD bool item_survives(const DevFrame& f, const DevScene& s, const DevPaths& 
   else if (cls == KEY_CORNELL) mat = s.cb_mat[idx];
   else if (cls == KEY_QUAD) mat = s.lights[idx].mat;
   else if (cls == KEY_BFTRI) mat = 2;
-  else mat = s.m_matid[idx];
+  else mat = __builtin_bit_cast(int32_t, s.m_shade[(size_t)kTriShadeFloats * (size_t)idx + 9]);
   if (mat < 0 || mat >= s.n_materials) return false;
   const int32_t type = s.materials[mat].type;
   if (type == MAT_NULL || type == MAT_LIGHT) return false;
