@@ -1,7 +1,9 @@
 set -e
 cd $GRAFT_REPO_ROOT
 bash profiles/collect.sh c4
+bash profiles/collect_util.sh c4
 bash profiles/collect.sh c3 --scene c3 --width 1024 --height 1024
+bash profiles/collect_util.sh c3 --scene c3 --width 1024 --height 1024
 mkdir -p gpurun_out/cfg3
 python bench.py --scene c2 --width 512 --height 512 --vthreads 4 --steps 1 --warmup 1 > gpurun_out/cfg3/c2.json 2> gpurun_out/cfg3/c2.err
 python bench.py --scene c3 --width 1024 --height 1024 --steps 1 --warmup 1 > gpurun_out/cfg3/c3.json 2> gpurun_out/cfg3/c3.err
