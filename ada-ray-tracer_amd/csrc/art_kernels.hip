@@ -449,7 +449,8 @@ constexpr int kAnalyticChunk = 4096;   // rays per workgroup: ONE global atomic 
                                        // serves only ~88 atomics/us on this chip, so per-wave atomics were the bottleneck)
 
 __global__ __launch_bounds__(256) void k_analytic(const DevScene S, const TraceArgs A) {   // the scene by value: kernel arguments are invariant, so its fields are fetched once, not once per round
-  __shared__ int s_idx[kAnalyticChunk];
+  __shared__ uint16_t s_idx[kAnalyticChunk];            // queued rays of this chunk, as offsets from chunk0
+  __shared__ float4 s_rec[4][256 + 1];                  // [piece][thread] staging of the trace records (+1: the read-back of 4 consecutive lanes hits 4 different banks)
   __shared__ int s_count, s_live, s_base;
   __shared__ DevLight s_lgt[kAnalyticLdsLights];       // ... and its lights (the rect ones are intersected here)
   __shared__ DevSphere s_sph[kAnalyticLdsSpheres];     // the scene's spheres, fetched once per workgroup: every ray tests every sphere, and a global
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(256) void k_analytic(const DevScene S, const TraceA
       if (lv) atomicAdd(&s_live, (int)__popcll(lv));
     }
     base = __builtin_amdgcn_readfirstlane(base);
-    if (queue_it) s_idx[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = i;
+    if (queue_it) s_idx[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(i - chunk0);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -521,25 +522,39 @@ __global__ __launch_bounds__(256) void k_analytic(const DevScene S, const TraceA
     if (A.stats != nullptr && s_live) atomicAdd(&A.stats[4], (unsigned long long)s_live);
   }
   __syncthreads();
-  // the queue entry of a ray is its trace record (art_kernels.h): the trace kernel's per-ray setup, done here at one ray per lane
-  for (int k = threadIdx.x; k < s_count; k += 256) {
-    const int i = s_idx[k];
-    const f3 o = mk3(A.ray_ox[i], A.ray_oy[i], A.ray_oz[i]), d = mk3(A.ray_dx[i], A.ray_dy[i], A.ray_dz[i]);
-    const DevHit h0 = A.hit[i];                                                // written above by this workgroup
-    float bt = h0.t; uint32_t bk = h0.key;
-    const float shm = (A.sh_min != nullptr && i >= A.shadow_begin) ? A.sh_min[i - A.shadow_begin] : -1.0f;
-    f3 inv, noi; slab_setup(o, d, inv, noi);
-    const bool far_found = (shm >= 0.0f) && (bk != KEY_MISS);               // a queued shadow ray with a hit has a far hit (near ones are not queued)
-    bt = far_found ? next_up_pos(shm) : bt;
-    bk = far_found ? KEY_MISS : bk;
-    // width 4, child bytes: c0 = { lo.x lo.y lo.z hi.x } (selector values 0..3), c1 = { hi.y hi.z - - } (4, 5); 0x0c = constant 0
-    const uint32_t sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
-    const uint32_t sel_near = (sx ? 3u : 0u) | ((sy ? 4u : 1u) << 8) | ((sz ? 5u : 2u) << 16) | 0x0c000000u;
-    float4* r = A.rec + 4 * (size_t)(s_base + k);
-    r[0] = make_float4(o.x, o.y, o.z, bt);
-    r[1] = make_float4(d.x, d.y, d.z, __builtin_bit_cast(float, bk));
-    r[2] = make_float4(inv.x, inv.y, inv.z, shm);
-    r[3] = make_float4(__builtin_bit_cast(float, sel_near), __builtin_bit_cast(float, i), __builtin_bit_cast(float, far_found ? 1u : 0u), 0.0f);
+  // the queue entry of a ray is its trace record (art_kernels.h): the trace kernel's per-ray setup, done here at one ray per lane.
+  // A lane builds the four 16-byte pieces of its ray's record; they go through LDS so that every store instruction of a wave writes
+  // 1 KB of contiguous bytes (64 lanes storing 16 bytes at a 64-byte stride cost the vector-memory path 4x as much, profiles/ta_rate.hip;
+  // the kernel's TA units were 81 % busy: 3.1-3.3 -> 2.7 ms per launch on C4).
+  const int lane2 = threadIdx.x & 63, wave2 = threadIdx.x >> 6;
+  for (int k0 = 0; k0 < s_count; k0 += 256) {
+    const int k = k0 + threadIdx.x;
+    if (k < s_count) {
+      const int i = chunk0 + (int)s_idx[k];
+      const f3 o = mk3(A.ray_ox[i], A.ray_oy[i], A.ray_oz[i]), d = mk3(A.ray_dx[i], A.ray_dy[i], A.ray_dz[i]);
+      const DevHit h0 = A.hit[i];
+      float bt = h0.t; uint32_t bk = h0.key;
+      const float shm = (A.sh_min != nullptr && i >= A.shadow_begin) ? A.sh_min[i - A.shadow_begin] : -1.0f;
+      f3 inv, noi; slab_setup(o, d, inv, noi);
+      const bool far_found = (shm >= 0.0f) && (bk != KEY_MISS);
+      bt = far_found ? next_up_pos(shm) : bt;
+      bk = far_found ? KEY_MISS : bk;
+      const uint32_t sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+      const uint32_t sel_near = (sx ? 3u : 0u) | ((sy ? 4u : 1u) << 8) | ((sz ? 5u : 2u) << 16) | 0x0c000000u;
+      s_rec[0][threadIdx.x] = make_float4(o.x, o.y, o.z, bt);
+      s_rec[1][threadIdx.x] = make_float4(d.x, d.y, d.z, __builtin_bit_cast(float, bk));
+      s_rec[2][threadIdx.x] = make_float4(inv.x, inv.y, inv.z, shm);
+      s_rec[3][threadIdx.x] = make_float4(__builtin_bit_cast(float, sel_near), __builtin_bit_cast(float, i), __builtin_bit_cast(float, far_found ? 1u : 0u), 0.0f);
+    }
+    wave_lds_sync();                                                          // a wave only reads back the 64 records it wrote itself
+    const int w0 = k0 + wave2 * 64;
+    float4* out = A.rec + 4 * (size_t)(s_base + w0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int q = it * 64 + lane2;                                          // piece (q & 3) of the wave's record (q >> 2)
+      if (w0 + (q >> 2) < s_count) out[q] = s_rec[q & 3][wave2 * 64 + (q >> 2)];
+    }
+    wave_lds_sync();
   }
 }
 
