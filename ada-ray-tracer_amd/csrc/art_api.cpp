@@ -373,15 +373,23 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
   int pc = 0, sc = 0;
   if (npix > 0) {
     int64_t cap = std::max<int64_t>(c.batch_paths, per);
+    // Two buffers belong to a batch: the path state and the live-ray queue (one 64-byte trace record for each of the up to 2 rays of a path).
+    auto try_alloc = [&](DevBuf& b, size_t bytes, hipError_t& e) {          // true: b holds at least `bytes`
+      e = hipSuccess;
+      if (b.p && b.bytes >= bytes) return true;
+      b.release();
+      e = hipMalloc(&b.p, bytes);
+      if (e == hipSuccess) { b.bytes = bytes; return true; }
+      b.p = nullptr; (void)hipGetLastError();
+      return false;
+    };
+    const bool need_queue = (c.trace_kernel == TRACE_COOP) && c.scene.n_tris > 0;
     for (;;) {
       pc = (int)std::min<int64_t>(npix, std::max<int64_t>(1, cap / per));
       sc = (int)std::min<int64_t>(S, std::max<int64_t>(per, (cap / pc) / per * per));
-      if (g_ctx.b_paths.p && g_ctx.b_paths.bytes >= path_floats((size_t)pc * sc, p->max_depth) * 4 + 256) break;
-      g_ctx.b_paths.release();
-      const hipError_t e = hipMalloc(&g_ctx.b_paths.p, path_floats((size_t)pc * sc, p->max_depth) * 4 + 256);
-      if (e == hipSuccess) { g_ctx.b_paths.bytes = path_floats((size_t)pc * sc, p->max_depth) * 4 + 256; break; }
-      g_ctx.b_paths.p = nullptr;
-      (void)hipGetLastError();
+      hipError_t e;
+      if (try_alloc(g_ctx.b_paths, path_floats((size_t)pc * sc, p->max_depth) * 4 + 256, e) &&
+          (!need_queue || try_alloc(c.b_queue, ((size_t)2 * pc * sc + 4096) * kTraceRecBytes, e))) break;
       if (e != hipErrorOutOfMemory || cap <= 65536) return fail(std::string("path buffers: ") + hipGetErrorString(e));
       cap /= 2;
     }

@@ -109,3 +109,40 @@ def test_c4_full_frame_is_independent_of_shards_batches_and_builder(art, backend
     finally:
         backend.set_option("bvh_builder", 0)
     assert np.array_equal(bits(lbvh), bits(full))
+
+
+def test_batch_is_halved_when_hbm_is_short(art, backend):
+    """A 64-spp 1080p pass wants one batch of 133 M paths: 60 GB of path state + 17 GB of trace records.  With most of the HBM taken by
+    someone else the batch is halved until both buffers fit, and the image is the same bits (the RNG is keyed by pixel, sample, bounce)."""
+    import ctypes as C
+    from ada_ray_tracer_amd import scenes
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    W, H = 1920, 1080
+    sd = scenes.synthetic_scene(2000, 3)
+    backend.upload_scene(sd)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 16, seed=3)      # 64 spp: 133 M paths
+    backend.set_option("batch_paths", 8 << 20)                         # reference: 16 batches of 8 M paths (buffers of a few GB at most)
+    try:
+        backend.resize(W, H)
+        ref, _, _ = backend.render_pass(p, 0)
+    finally:
+        backend.set_option("batch_paths", 128 << 20)
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    keep = 30 << 30                 # 30 GB left: 60 + 17 GB cannot fit, 30 + 8.5 GB cannot, 15 + 4.3 GB can
+    if free.value <= keep + (8 << 30):
+        pytest.skip("not enough free HBM to take away")
+    hog = C.c_void_p(None)
+    assert hip.hipMalloc(C.byref(hog), free.value - keep) == 0
+    try:
+        backend.resize(W, H)
+        img, _, spp = backend.render_pass(p, 0)
+        after = C.c_size_t(0)
+        hip.hipMemGetInfo(C.byref(after), C.byref(total))
+    finally:
+        hip.hipFree(hog)
+    assert spp == 64 and np.array_equal(bits(img), bits(ref))
+    assert after.value < (20 << 30)                                     # the render did take a batch's worth of what was left
