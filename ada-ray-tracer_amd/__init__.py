@@ -18,6 +18,8 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.environ.get("ART_LIB", os.path.join(PKG_DIR, "libart_hip.so"))   # ART_LIB: A/B builds of the same source
+# the C++ mirror of the Ada host layer (host/); ART_ASAN=1: its AddressSanitizer + UBSan build (tests/run_sanitizers.sh, CPU only)
+HOST_LIB_PATH = os.path.join(PKG_DIR, "libart_host_asan.so" if os.environ.get("ART_ASAN", "") not in ("", "0") else "libart_host.so")
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
@@ -29,6 +31,8 @@ MESH_REFERENCE_BF, MESH_CLOSEST = 0, 1
 RT_DEBUG, RT_WHITTED, PT_STUPID, PT_SHADOW, PT_MIS = range(5)
 LAYOUT_ADA_XY, LAYOUT_ROW_MAJOR = 0, 1
 TRACE_COOP, TRACE_SIMPLE = 0, 1
+BVH_HOST_SAH, BVH_GPU_LBVH, BVH_GPU_PLOC, BVH_GPU_SAH = 0, 1, 2, 3     # option "bvh_builder"
+DEFAULT_BVH_BUILDER = BVH_GPU_SAH
 
 
 class ArtError(RuntimeError):

@@ -33,6 +33,7 @@ std::mutex g_mu;
 static ncclComm_t g_comms[kMaxDevices];
 static bool g_comms_ready = false;     // distinct GPUs: the framebuffer reduce goes through RCCL
 static bool g_same_gpu = false;        // rehearsal: several contexts on ONE physical GPU, the reduce is a local sum (no collective possible)
+static const bool g_debug_live = getenv("ART_DEBUG_LIVE") != nullptr;   // development aid: work-set sizes per stage on stderr (syncs the stream); read once
 static thread_local std::string t_err;
 static std::string g_err;
 
@@ -423,7 +424,7 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
             HIP_TRY(hipMemsetAsync(c.d_live + 32 * out, 0, sizeof(int), c.stream));
             launch_shade_compact(c.stream, F, c.scene, qi, bank[out], b, b == 0 ? nullptr : c.d_live + 32 * in, c.d_live + 32 * out,
                                  const_cast<uint32_t*>(bank[out].slot_id), c.d_counters + 15);
-            if (getenv("ART_DEBUG_LIVE")) {
+            if (g_debug_live) {
               int n = -1; unsigned long long r0 = 0;
               (void)hipStreamSynchronize(c.stream); (void)hipMemcpy(&n, c.d_live + 32 * out, 4, hipMemcpyDeviceToHost); (void)hipMemcpy(&r0, c.d_counters, 8, hipMemcpyDeviceToHost);
               std::fprintf(stderr, "stage %d: items out %d of %d, rays so far %llu\n", b, n, q.P, r0);
@@ -506,6 +507,12 @@ static int reduce_accum(const float** out) {
       (void)hipEventDestroy(e);
       launch_add_f32(c0.stream, (const float*)g_devs[k].b_accum.p, (float*)c0.b_reduced.p, count);
     }
+    // the adds read every context's accum on c0.stream: a later render pass on stream k must not overwrite it before they are done
+    hipEvent_t done;
+    HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(done, c0.stream));
+    for (int k = 1; k < g_ndev; ++k) HIP_TRY(hipStreamWaitEvent(g_devs[k].stream, done, 0));
+    (void)hipEventDestroy(done);
   } else return fail("internal: multi-device mode without a reduce path");
   *out = (const float*)c0.b_reduced.p;
   return 0;
@@ -818,6 +825,7 @@ int art_get_stats(ArtStats* out) {
     const ArtStats& t = g_devs[k].stats;
     out->rays += t.rays; out->samples += t.samples; out->box_tests += t.box_tests; out->tri_tests += t.tri_tests;
     out->node_visits += t.node_visits; out->leaf_visits += t.leaf_visits; out->traced_rays += t.traced_rays;
+    out->lost_paths += t.lost_paths;      // the compacted work set's self-check ("must stay 0") covers every device
     out->pass_ms = std::max(out->pass_ms, t.pass_ms);
   }
   return 0;
@@ -848,7 +856,7 @@ static int set_option_one(const std::string& n, int64_t value) {
   else if (n == "lds_stack_cap") { if (value < 0 || value > kStackEntries) return fail("lds_stack_cap: 0 (automatic) .. 160"); g_ctx.lds_stack_cap = (int)value; }
   else if (n == "bvh_max_leaf") { if (value < 0 || value > kMaxLeafTris) return fail("bvh_max_leaf: 1..8, 0 = defaults"); g_ctx.bvh_params.max_leaf = value ? (int)value : BvhBuildParams().max_leaf; g_ctx.bvh_params.gpu_max_leaf = (int)value; }
   else if (n == "bvh_spatial_splits") { g_ctx.bvh_params.spatial_alpha = value ? 1.0e-5f : -1.0f; }   // host builder: SBVH reference splitting
-  else if (n == "bvh_builder") { if (value < 0 || value > 2) return fail("bvh_builder: 0 host SAH, 1 GPU LBVH, 2 GPU PLOC"); g_ctx.bvh_params.builder = (int)value; }
+  else if (n == "bvh_builder") { if (value < 0 || value > 3) return fail("bvh_builder: 0 host SAH, 1 GPU LBVH, 2 GPU PLOC, 3 GPU SAH"); g_ctx.bvh_params.builder = (int)value; }
   else if (n == "bvh_ploc_radius") { if (value < 1 || value > 64) return fail("bvh_ploc_radius: 1..64"); g_ctx.bvh_params.ploc_radius = (int)value; }
   else if (n == "bvh_leaf_base_milli") { g_ctx.bvh_params.leaf_base = (float)value / 1000.0f; }
   else if (n == "bvh_tri_cost_milli") { g_ctx.bvh_params.tri_cost = (float)value / 1000.0f; }

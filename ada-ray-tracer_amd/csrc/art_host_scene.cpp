@@ -86,7 +86,8 @@ bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& o
       for (int i = 0; i < m.ntris; ++i)
         for (int k = 0; k < 3; ++k) std::memcpy(&tri9[9 * (size_t)i + 3 * k], m.pos + 3 * (size_t)m.idx[3 * (size_t)i + k], 12);
       h.node_width = bp.width;
-      if (bp.builder >= 1 && m.ntris >= 2) { out.deferred_tri9 = std::move(tri9); h.n_tris = m.ntris; continue; }   // built on the GPU by the caller
+      const bool host_only = (bp.builder == 3 && bp.spatial_alpha >= 0.0f);        // reference splitting exists in the host builder only
+      if (bp.builder >= 1 && m.ntris >= 2 && !host_only) { out.deferred_tri9 = std::move(tri9); h.n_tris = m.ntris; continue; }   // built on the GPU by the caller
       const auto t0 = std::chrono::steady_clock::now();
       if (!build_bvh8(tri9.data(), nullptr, m.ntris, bp, out.bvh, err)) return false;
       out.bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

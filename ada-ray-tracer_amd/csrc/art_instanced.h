@@ -29,6 +29,8 @@ struct InstScene {
   int32_t n_inst, width;
 };
 
+constexpr int kInstTopStack = 96;   // top-level traversal stack of instanced_closest; build_two_level_host refuses a deeper instance tree
+
 struct InstHit { float t; int32_t inst, prim; float u, v; };   // inst < 0: miss; prim = record index inside the mesh (2k front, 2k+1 back)
 
 ART_HD f3 xform_dir(const float* m, f3 v) { return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z); }
@@ -38,7 +40,7 @@ ART_HD InstHit instanced_closest(const InstScene& T, f3 o, f3 d, float tfar) {
   if (T.n_inst <= 0) return best;
   f3 inv, noi;
   slab_setup(o, d, inv, noi);
-  constexpr int kTop = 96;
+  constexpr int kTop = kInstTopStack;   // the build checked tlas.max_stack <= kTop and every mesh tree's bound <= kStackEntries (bvh_closest's private stack)
   int32_t stk_ref[kTop]; float stk_t[kTop];
   int sp = 0;
   stk_ref[sp] = 0; stk_t[sp] = 0.0f; ++sp;

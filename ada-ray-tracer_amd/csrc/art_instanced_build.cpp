@@ -42,6 +42,9 @@ bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vect
     }
     Bvh8 b;
     if (!build_bvh8(tri9.data(), nullptr, (int32_t)(2 * m.n_tris), bp, b, err)) return false;
+    // instanced_closest walks a mesh tree with bvh_closest's private stack of kStackEntries entries and pushes unchecked (like the
+    // flattened upload, which art_upload_scene refuses for the same reason)
+    if (b.max_stack > kStackEntries) { err = "mesh tree stack bound " + std::to_string(b.max_stack) + " exceeds " + std::to_string(kStackEntries); return false; }
     node_base[mi] = (int32_t)(T.blas_nodes.size() / node_floats(4));
     tri_base[mi] = (int32_t)(T.blas_tris.size() / kTriFloats);
     ntris[mi] = b.n_tris;
@@ -79,7 +82,9 @@ bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vect
   }
   if (T.inst.empty()) { err = "no valid instances"; return false; }
   BvhBuildParams tp; tp.width = 4; tp.max_leaf = 1;
-  return build_bvh8(proxy9.data(), proxy_id.data(), (int32_t)proxy_id.size(), tp, T.tlas, err);
+  if (!build_bvh8(proxy9.data(), proxy_id.data(), (int32_t)proxy_id.size(), tp, T.tlas, err)) return false;
+  if (T.tlas.max_stack > kInstTopStack) { err = "instance tree stack bound " + std::to_string(T.tlas.max_stack) + " exceeds " + std::to_string(kInstTopStack); return false; }
+  return true;
 }
 
 }  // namespace art

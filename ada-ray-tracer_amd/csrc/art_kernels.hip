@@ -6,8 +6,9 @@
 //                  contiguous bytes, the node's origin / scale words are broadcast inside the quad by DPP, all 64 lanes run one slab test,
 //                  the hits are ranked by a DPP borrow chain and pushed far-to-near onto the ray's traversal stack in LDS.  A leaf holds
 //                  <= G triangles: one Moeller-Trumbore test (reference arithmetic) per lane, then a DPP min-reduction over (t, key).
-//                  Rays come as 64-byte trace records in queue order (prepared by k_analytic), pulled in 16-record chunks from one atomic
-//                  cursor per XCD segment, the whole chunk prefetched with one load per lane, handed to idle groups by ballot.
+//                  Rays come as 64-byte trace records in queue order (prepared by k_analytic), pulled in chunks of `ray_chunk` records
+//                  (48 by default) from one atomic cursor per XCD segment, the whole chunk prefetched (one load per lane per 16 records),
+//                  handed to idle groups by ballot.
 //   k_analytic     one ray per lane: spheres, Cornell box, rect lights, the reference's brute-force mesh; writes the starting bound of
 //                  the BVH search and the trace record of every ray that needs it (incl. slab_setup's three divisions).
 //   k_trace_simple one ray per lane, private stack -- the traversal used to cross-check; k_trace_overflow finishes the rays whose
@@ -271,6 +272,10 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
 
     // ---------------- inner loop: pop + node phase, as long as enough of the wave's groups have a node to expand
     mask_t want_leaf = 0;
+    // The refill above may have been refused (fewer than refill_min idle groups).  Then "not exhausted" is no reason to leave the inner
+    // loop with node work pending: nothing outside it could make progress either (node_min = 8 or refill_min >= 6 at width 8
+    // spun forever).  Only a refill that would really happen ends the node phase early.
+    const bool refill_possible = !exhausted && (__popcll(~has_ray & leaders) >= A.refill_min);
     for (;;) {
       // next stack entry; an entry culled by the current hit is dropped (its group then sits this step out).  Popping two entries
       // per iteration to skip a culled one costs 12 more instructions in every iteration and saves 0.6 % of the steps: slower.
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       const mask_t want_node = active & ~is_leaf;
       // leave when fewer than node_min groups still expand nodes (the others wait on a leaf, are finished, or idle)
       if (__popcll(want_node) < 8 * A.node_min) {
-        if (want_node == 0 || !exhausted || (want_leaf | (has_ray & ~active & vcmp(sa == sb))) != 0) break;
+        if (want_node == 0 || refill_possible || (want_leaf | (has_ray & ~active & vcmp(sa == sb))) != 0) break;
       }
       // ---- node phase: lane j tests child j; groups not taking part read the root node and discard the result
       float tmn, tmx; uint32_t entry; mask_t valid;
@@ -304,7 +309,8 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
                                      __builtin_bit_cast(float, dpp_i<0xAA>((int)rec.w)), __builtin_bit_cast(float, dpp_i<0xFF>((int)rec.w)));
         // near / far plane bytes by direction sign (one v_perm each), dequantised (one fma per plane: the very binary32 boxes of the
         // exported tree), then the slab distances.  An empty slot holds lo = 255, hi = 0 on every axis: its near plane lies behind
-        // its far plane for every ray, so it can never be hit and needs no validity test.
+        // its far plane for every ray, so it needs no validity test (and its entry word is a leaf of zero triangles: harmless
+        // even if a degenerate node's planes round onto each other).
         const uint32_t nb = __builtin_amdgcn_perm(c1, c0, sel_near), fb = __builtin_amdgcn_perm(c1, c0, sel_far);
         const f3 pn = mk3(__builtin_fmaf((float)(nb & 255u), h.w, h.x), __builtin_fmaf((float)((nb >> 8) & 255u), h.w, h.y), __builtin_fmaf((float)((nb >> 16) & 255u), h.w, h.z));
         const f3 pf = mk3(__builtin_fmaf((float)(fb & 255u), h.w, h.x), __builtin_fmaf((float)((fb >> 8) & 255u), h.w, h.y), __builtin_fmaf((float)((fb >> 16) & 255u), h.w, h.z));

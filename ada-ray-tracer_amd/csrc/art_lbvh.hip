@@ -342,7 +342,12 @@ struct Scratch {
 
 }  // namespace
 
+void launch_quantise_nodes(hipStream_t st, float* nodes, int n_nodes, void* qnodes) {
+  hipLaunchKernelGGL(k_quantise_nodes, dim3((n_nodes + 255) / 256), dim3(256), 0, st, nodes, n_nodes, (QNode*)qnodes);
+}
+
 bool build_bvh8_gpu(const float* d_tri9, int n, const BvhBuildParams& prm, hipStream_t st, GpuBvh& out, std::string& err) {
+  if (prm.builder == 3) return build_bvh_sah_gpu(d_tri9, n, prm, st, out, err);
   if (n < 2) { err = "build_bvh8_gpu needs at least 2 triangles"; return false; }
   if (prm.width != 4 && prm.width != 8) { err = "BVH width must be 4 or 8"; return false; }
   const int max_leaf = std::min(prm.gpu_max_leaf > 0 ? prm.gpu_max_leaf : (prm.width == 4 ? 1 : 2), prm.width);
@@ -442,7 +447,7 @@ bool build_bvh8_gpu(const float* d_tri9, int n, const BvhBuildParams& prm, hipSt
   }
   if (prm.width == 4 && prm.quantise) {
     LB_TRY(hipMalloc(&out.qnodes, (size_t)out.n_nodes * kQNodeBytes));
-    hipLaunchKernelGGL(k_quantise_nodes, dim3((out.n_nodes + 255) / 256), dim3(256), 0, st, out.nodes, out.n_nodes, (QNode*)out.qnodes);
+    launch_quantise_nodes(st, out.nodes, out.n_nodes, out.qnodes);
   }
   LB_TRY(hipEventRecord(e1, st));
   LB_TRY(hipEventSynchronize(e1));

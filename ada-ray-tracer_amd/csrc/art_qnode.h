@@ -14,7 +14,8 @@
 //                  12-byte lane stride 15 + 45.
 //   entry          inner child: node_index * 64               (bit 31 clear, low 6 bits clear)
 //                  leaf:        0x80000000 | first_triangle * 64 | count   (count 1..4 in the low 4 bits; 64-byte padded triangle records)
-//                  empty slot:  0xffffffff
+//                  empty slot:  0x80000000   (a leaf of zero triangles: should rounding ever let an empty slot's inverted planes
+//                               pass the slab test, the leaf step it causes loads nothing and accepts nothing)
 //   child box      lo = fma(float(qlo), scale, origin)   hi = fma(float(qhi), scale, origin)      one rounding each
 //
 // "The tree" everybody else sees (art_export_bvh, the one-ray-per-lane kernels, the host simulation, the oracle's walker) is the
@@ -26,7 +27,7 @@
 namespace art {
 
 constexpr int kQNodeBytes = 64;
-constexpr uint32_t kQEntryEmpty = 0xffffffffu, kQEntryLeaf = 0x80000000u;
+constexpr uint32_t kQEntryEmpty = 0x80000000u, kQEntryLeaf = 0x80000000u;
 constexpr int kTriBytes = kTriFloats * 4;
 constexpr int kQTriBytes = 64;       // the 4-wide kernel reads triangle records padded to 64 bytes: a record never straddles a 128-byte L2 line
 

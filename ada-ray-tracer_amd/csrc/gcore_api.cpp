@@ -149,9 +149,10 @@ void gcore_commit_scene(void) {
     if (g.insts.empty()) { std::printf("[c_gcore]: gcore_commit_scene, no instances\n"); return; }
     std::string err;
     if (art::ensure_device()) { std::printf("[c_gcore]: %s\n", art_last_error()); return; }
-    if (!build_two_level(err)) { std::printf("[c_gcore]: two-level build: %s\n", err.c_str()); return; }
-    g.committed = true;
-    return;
+    if (build_two_level(err)) { g.committed = true; return; }
+    // e.g. a tree deeper than the two-level search's stacks: the flattened upload below has its own (checked) limits
+    std::printf("[c_gcore]: two-level build: %s; flattening the instances instead\n", err.c_str());
+    g.two.release(); g.two.on = false; g.tri_inst.clear();
   }
   for (size_t ii = 0; ii < g.insts.size(); ++ii) {
     const GInst& in = g.insts[ii];

@@ -151,8 +151,8 @@ class HostSceneDesc:
     def __init__(self, vsgf_path=None, cam_pos=None):
         import ctypes as C
         import os
-        from . import PKG_DIR, ArtError, ArtSceneDesc
-        lib = C.CDLL(os.path.join(PKG_DIR, "libart_host.so"))
+        from . import HOST_LIB_PATH, ArtError, ArtSceneDesc
+        lib = C.CDLL(HOST_LIB_PATH)
         lib.art_host_scene_init.restype = C.POINTER(ArtSceneDesc)
         lib.art_host_scene_init.argtypes = [C.c_char_p]
         p = lib.art_host_scene_init((vsgf_path or PYRAMID_VSGF).encode())

@@ -159,16 +159,16 @@ int  art_download(float* accum_host, uint32_t* screen_host, int32_t layout, int3
 int  art_synchronize(void);
 
 /* Scene.Find_Closest_Hit for a list of rays (host arrays of 3*n floats; tfar may be NULL = unbounded).
- * kernel: 0 = cooperative 8-lane kernel, 1 = one-ray-per-lane kernel.  stats may be NULL. */
+ * kernel: 0 = cooperative kernel (bvh_width lanes per ray: 4 by default, 8 as an option), 1 = one-ray-per-lane kernel.  stats may be NULL. */
 int  art_trace_rays(const float* origins, const float* dirs, const float* tfar, int64_t n,
                     ArtHit* out, int32_t kernel, ArtStats* stats);
 
 int  art_export_bvh(float* nodes, int64_t node_floats_cap, float* tris, int64_t tri_floats_cap, ArtBvhInfo* info);
 int  art_get_stats(ArtStats* out);
 /* Tuning / test options (defaults in brackets):  "trace_kernel" [0] 0 cooperative, 1 one ray per lane;  "batch_paths" [128M];
- * "blocks_per_cu" [occupancy];  "count_tests" [0];  "node_min" [4];  "ray_chunk" [16];  "queue_segments" [8];  "shadow_anyhit" [1];
+ * "blocks_per_cu" [occupancy];  "count_tests" [0];  "node_min" [4];  "refill_min" [2];  "ray_chunk" [48];  "queue_segments" [8];  "shadow_anyhit" [1];
  * "lds_stack_cap" [0 = automatic];  BVH build (take effect at the next art_upload_scene): "bvh_width" [4] lanes per ray = children
- * per node, 4 or 8;  "bvh_builder" [0] 0 binned SAH on the host, 1 LBVH on the GPU, 2 PLOC on the GPU;  "bvh_ploc_radius" [8];  "bvh_spatial_splits" [0];  "bvh_max_leaf" [width];
+ * per node, 4 or 8;  "bvh_builder" [3] 3 binned SAH on the GPU (the tree of 0, built in milliseconds), 0 binned SAH on the host, 1 LBVH on the GPU, 2 PLOC on the GPU;  "bvh_ploc_radius" [8];  "bvh_spatial_splits" [0];  "bvh_max_leaf" [width];
  * "bvh_leaf_base_milli", "bvh_node_cost_milli", "bvh_tri_cost_milli". */
 int  art_set_option(const char* name, int64_t value);
 const char* art_last_error(void);

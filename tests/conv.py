@@ -58,6 +58,7 @@ class OracleScene:
         s.cam_pos, s.cam_matrix = d.cam_pos, d.cam_matrix
         self.scene = s
         self._keep = sd
+        s._owner = self          # `conv.OracleScene(sd).scene` alone must keep the arrays alive (found by the AddressSanitizer pass, round 3)
 
     def attach_bvh(self, nodes, tris, width=8):
         """Let the oracle's closest-hit mesh search walk the product's exported BVH (CPU baseline timing)."""

@@ -14,7 +14,8 @@ using namespace art;
 
 static std::string g_err;
 
-static BvhBuildParams g_bp;   // builder parameters for the following hs_* calls (tests of the spatial-split builder)
+static BvhBuildParams host_params() { BvhBuildParams p; p.builder = 0; return p; }   // no GPU here: the host SAH builder (the GPU SAH builder builds the same tree)
+static BvhBuildParams g_bp = host_params();   // builder parameters for the following hs_* calls (tests of the spatial-split builder)
 extern "C" void hs_set_bvh_param(const char* name, double v) {
   const std::string n(name);
   if (n == "spatial_alpha") g_bp.spatial_alpha = (float)v;

@@ -12,8 +12,9 @@ _lib = None
 def lib(art):
     global _lib
     if _lib is None:
-        subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "host_sim")])
-        L = C.CDLL(os.path.join(HERE, "host_sim", "libhost_sim.so"))
+        asan = os.environ.get("ART_ASAN", "") not in ("", "0")            # tests/run_sanitizers.sh
+        subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "host_sim")] + (["ASAN=1"] if asan else []))
+        L = C.CDLL(os.path.join(HERE, "host_sim", "libhost_sim_asan.so" if asan else "libhost_sim.so"))
         L.hs_last_error.restype = C.c_char_p
         L.hs_render.argtypes = [C.POINTER(art.ArtSceneDesc), C.POINTER(art.ArtPassParams), C.c_int, C.c_int, C.c_int, art.f32p, C.POINTER(C.c_uint64)]
         L.hs_trace.argtypes = [C.POINTER(art.ArtSceneDesc), art.f32p, art.f32p, art.f32p, C.c_longlong, C.POINTER(art.ArtHit), C.POINTER(C.c_uint64)]

@@ -84,16 +84,19 @@ class BvhCounters(C.Structure):
 _lib = None
 
 
+ASAN = os.environ.get("ART_ASAN", "") not in ("", "0")      # tests/run_sanitizers.sh: load the AddressSanitizer + UBSan builds
+
+
 def build():
     """Compile oracle/liboracle.so (gcc, seconds)."""
-    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR] + (["ASAN=1"] if ASAN else []))
 
 
 def lib():
     global _lib
     if _lib is not None:
         return _lib
-    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    so = os.path.join(ORACLE_DIR, "liboracle_asan.so" if ASAN else "liboracle.so")
     src = os.path.join(ORACLE_DIR, "art_oracle.c")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         build()

@@ -8,7 +8,19 @@ picture shows (85..938 and 280..745 of 1024).  Everything else is as at HEAD: PT
 
 Used by the CPU test of the oracle (tests/test_oracle_image_pin.py) and by the GPU test of the product
 (tests/test_gpu_reference_picture.py): both are compared with the same fixture, block by block and region by region.
-A Monte Carlo picture can only be pinned statistically; the tolerances below are a few LDR levels on 16x16-pixel block means."""
+A Monte Carlo picture can only be pinned statistically; the tolerances below are a few LDR levels on 16x16-pixel block means.
+
+PIN HISTORY (what was changed after the pin first went in, and why -- DESIGN.md section 3 carries the same text):
+  * round 2, commit 461385f: region pyramid_shadow = (400, 850, half size 8) was REMOVED and the brightness tolerance went from
+    0.01 to 0.02, inside a performance commit and without a note.  Cause, measured afterwards (oracle 512^2 x 512 spp and the product
+    at 1024^2 x 1024 spp): the 16-pixel window sits ON the pyramid's base edge -- the picture's 8x8 block means jump 20 -> 8 -> 60
+    LDR levels within 24 pixels there -- so a half-pixel shift between render resolutions moved its mean by 9 % (19.7 / 27.3 against
+    21.5 / 30.1) although every 16x16 block around it agrees within 1.6 levels.  An alignment effect of a badly placed window, not a
+    shading difference.  Round 3 restores the check as pyramid_base_and_shadow with half size 16 (the window then averages over the edge
+    instead of sitting on it: 3.8 % at 512^2).
+  * brightness tolerance 0.02: the sum of LDR block means of a gamma-2 picture depends on the sample count (E[sqrt x] < sqrt E[x]):
+    1.0015 for the oracle at 512^2 x 256 spp, 0.990 for the product at 1024^2 x 128 spp; the picture's own sample count is unknown.
+    0.01 was the first measurement plus nothing; 0.02 covers the sample counts the tests use."""
 import numpy as np
 
 import orc
@@ -30,6 +42,7 @@ REGIONS = dict(
     caustic=(762, 862, 24),                   # light focused on the floor by the glass sphere
     pyramid_left_face=(390, 810, 12),         # pyramid2.vsgf through IntersectMeshBF
     pyramid_right_face=(455, 815, 8),
+    pyramid_base_and_shadow=(400, 850, 16),   # the pyramid's front base edge with the contact shadow under it (see PIN HISTORY below)
     green_wall=(180, 520, 24), red_wall=(845, 520, 24), floor_front=(512, 900, 24), ceiling_front=(512, 130, 16),
     outside=(40, 40, 24))                     # Cornell box face 5 is open, nothing behind: background
 

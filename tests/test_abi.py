@@ -41,7 +41,7 @@ def test_host_mirror_scene_init_equals_oracle(art):
     """C++ mirror of Scene.Init (host/art_host.cpp, scene.adb:89-217) builds the same numbers as the oracle."""
     import numpy as np
     import orc
-    so = os.path.join(art.PKG_DIR, "libart_host.so")
+    so = art.HOST_LIB_PATH
     L = C.CDLL(so)
     sph = np.zeros((3, 5), np.float32); light = np.zeros(16, np.float32); mats = np.zeros((11, 10), np.float32)
     pos = np.zeros((64, 3), np.float32); bbox = np.zeros(6, np.float32); counts = (C.c_int * 4)()

@@ -21,7 +21,7 @@ def _scene(art, pos, idx):
     return art.SceneDesc([], light, scenes.cornell_materials(), [mesh], None, scenes.REFERENCE_CAMERA)
 
 
-@pytest.mark.parametrize("builder", [0, 1, 2])
+@pytest.mark.parametrize("builder", [0, 1, 2, 3])
 @pytest.mark.parametrize("width", [4, 8])
 def test_degenerate_meshes(art, backend, builder, width):
     rng = np.random.default_rng(5)
@@ -46,5 +46,5 @@ def test_degenerate_meshes(art, backend, builder, width):
                 hit = [h for h in want if h.is_hit]
                 assert len(hit) > 50 and all(h.prim_index == 0 for h in hit)       # ties on t: the lowest triangle index wins
     finally:
-        backend.set_option("bvh_builder", 0)
+        backend.set_option("bvh_builder", art.DEFAULT_BVH_BUILDER)
         backend.set_option("bvh_width", 4)

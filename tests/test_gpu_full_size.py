@@ -107,7 +107,7 @@ def test_c4_full_frame_is_independent_of_shards_batches_and_builder(art, backend
         backend.resize(W, H)
         lbvh, _, _ = backend.render_pass(p, 0)
     finally:
-        backend.set_option("bvh_builder", 0)
+        backend.set_option("bvh_builder", art.DEFAULT_BVH_BUILDER)
     assert np.array_equal(bits(lbvh), bits(full))
 
 

@@ -129,3 +129,30 @@ def test_refill_and_chunk_options_do_not_change_results(art, backend):
     finally:
         backend.set_option("ray_chunk", 48)
         backend.set_option("refill_min", 2)
+
+
+def test_node_min_and_refill_gate_cannot_stall_a_wave(art, backend):
+    """with node_min = 8 (every group of a wave must want a node) or, at width 8, refill_min >= 6, a wave could sit with
+    too few groups for the node phase, too few idle groups for the refill gate and rays still queued: it spun forever.  The node
+    phase now only yields to a refill that will really happen.  Both settings, both widths, bit-equal to the defaults.  (A hang
+    would be killed by the test's own timeout, not by the box.)"""
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.synthetic_scene(3000, 3)
+    p = art.Backend.pass_params(art.PT_MIS, True, 6, 1, seed=5)
+    ref = None
+    try:
+        for width in (4, 8):
+            backend.set_option("bvh_width", width)
+            backend.upload_scene(sd)
+            for node_min, refill in [(4, 2), (8, 2), (4, 8), (8, 8), (8, 6)]:
+                backend.set_option("node_min", node_min)
+                backend.set_option("refill_min", refill)
+                backend.resize(40, 32)
+                img, _, _ = backend.render_pass(p, 0)
+                if ref is None:
+                    ref = img
+                assert np.array_equal(bits(img), bits(ref)), (width, node_min, refill)
+    finally:
+        backend.set_option("bvh_width", 4)
+        backend.set_option("node_min", 4)
+        backend.set_option("refill_min", 2)

@@ -19,7 +19,7 @@ MATS = [np.array([[1, 0, 0, -1.5], [0, 1, 0, 0.25], [0, 0, 1, 2], [0, 0, 0, 1]],
 
 
 def _host(art):
-    L = C.CDLL(os.path.join(art.PKG_DIR, "libart_host.so"))
+    L = C.CDLL(art.HOST_LIB_PATH)
     L.art_host_hydra_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), art.f32p, art.f32p]
     L.art_host_hydra_init.argtypes = [C.c_char_p]
     L.art_host_hydra_closest_hits.argtypes = [art.f32p, art.f32p, C.c_int, C.POINTER(art.HitCpp), C.POINTER(C.c_int)]
