@@ -299,6 +299,40 @@ bool build_bvh8(const float* tri9, const int32_t* prim_ids, int32_t n, const Bvh
 
   const int32_t root8 = new_node8();   // a single-leaf tree still gets a root node with one child
 
+  // prm.collapse == 1: cost-optimal collapse (the dynamic programme of Ylitie, Karras, Laine 2017, section 4.1, restricted to the
+  // leaves the SAH build chose).  cst[n][i-1] = least expected number of wide-node visits below BVH2 node n when n's subtree may take up
+  // to i slots of the wide node above it: either n becomes a wide node itself (one slot: area(n) + the best distribution of W slots
+  // over its two children), or n is dissolved and its children share the i slots.  The greedy rule (open the child with the largest
+  // area) is the usual approximation of exactly this minimum.
+  std::vector<float> cst; std::vector<uint8_t> cut;     // cut[n][i-1]: slots given to the left child when n is dissolved into i slots; 0 = n is a wide node
+  std::vector<uint8_t> root_cut;                        // [n]: left child's share of the W slots when n is a wide node
+  const bool optimal = prm.collapse == 1 && B.nodes[0].count == 0;
+  if (optimal) {
+    const size_t nn = (size_t)B.next_node.load();
+    cst.assign(nn * W, 0.0f); cut.assign(nn * W, 0); root_cut.assign(nn, 0);
+    // children have larger... no ordering guarantee on ids (parallel build): explicit post-order
+    std::vector<int32_t> order; order.reserve(nn);
+    { std::vector<int32_t> stk; stk.push_back(0);
+      while (!stk.empty()) { const int32_t n = stk.back(); stk.pop_back(); order.push_back(n); const Node2& nd2 = B.nodes[n]; if (nd2.count == 0) { stk.push_back(nd2.left); stk.push_back(nd2.right); } } }
+    for (size_t q = order.size(); q-- > 0;) {
+      const int32_t n = order[q]; const Node2& nd2 = B.nodes[n];
+      float* c = &cst[(size_t)n * W];
+      if (nd2.count > 0) { for (int i = 0; i < W; ++i) c[i] = 0.0f; continue; }          // fixed leaves: their cost is the same in every collapse
+      const float* cl = &cst[(size_t)nd2.left * W]; const float* cr = &cst[(size_t)nd2.right * W];
+      auto distribute = [&](int slots, uint8_t& k_best) {
+        float best = INFINITY; k_best = 1;
+        for (int k = 1; k < slots; ++k) { const float v = cl[k - 1] + cr[slots - k - 1]; if (v < best) { best = v; k_best = (uint8_t)k; } }
+        return best;
+      };
+      const float as_node = nd2.box.half_area() + distribute(W, root_cut[n]);
+      c[0] = as_node; cut[(size_t)n * W] = 0;
+      for (int i = 2; i <= W; ++i) {
+        uint8_t k; const float d = distribute(i, k);
+        if (d < as_node) { c[i - 1] = d; cut[(size_t)n * W + i - 1] = k; } else { c[i - 1] = as_node; cut[(size_t)n * W + i - 1] = 0; }
+      }
+    }
+  }
+
   int32_t max_stack = 1;
   struct Pending { int32_t n2, n8, stack_before; };
   std::vector<Pending> todo; todo.push_back({0, root8, 0});
@@ -308,8 +342,22 @@ bool build_bvh8(const float* tri9, const int32_t* prim_ids, int32_t n, const Bvh
     std::vector<int32_t> ch;
     const Node2& top = B.nodes[p.n2];
     if (top.count > 0) ch.push_back(p.n2);
+    else if (optimal) {
+      // hand out the W slots top-down along the recorded minimum: in order, so BVH2 siblings stay neighbours
+      struct Give { int32_t n; int slots; };
+      std::vector<Give> st2;
+      const int kl = root_cut[p.n2];
+      st2.push_back({top.right, W - kl}); st2.push_back({top.left, kl});
+      while (!st2.empty()) {
+        const Give g = st2.back(); st2.pop_back();
+        const Node2& c = B.nodes[g.n];
+        const int k = (c.count > 0) ? 0 : cut[(size_t)g.n * W + g.slots - 1];
+        if (c.count > 0 || k == 0) { ch.push_back(g.n); continue; }
+        st2.push_back({c.right, g.slots - k}); st2.push_back({c.left, k});
+      }
+    }
     else { ch.push_back(top.left); ch.push_back(top.right); }
-    while ((int)ch.size() < W) {
+    while (!optimal && (int)ch.size() < W) {
       int best = -1; float best_a = -1.0f;
       for (int i = 0; i < (int)ch.size(); ++i) {
         const Node2& c = B.nodes[ch[i]];

@@ -27,6 +27,7 @@ struct BvhBuildParams {
   int   spatial_bins = 16;
   int   builder = 3;             // 3 (default since round 3): binned SAH on the GPU (art_sah.hip) -- the tree of builder 0, built in milliseconds;
                                  // 0: binned SAH on the host (art_bvh.cpp; also used below 2 triangles and for spatial splits); 1 LBVH, 2 PLOC on the GPU (art_lbvh.hip)
+  int   collapse = 0;            // BVH2 -> wide: 0 open the child with the largest area until the node is full; 1 cost-optimal (fewest expected wide-node visits)
   int   ploc_radius = 8;         // PLOC: neighbours searched on either side
   int   gpu_max_leaf = 0;        // GPU builders: a subtree of at most this many triangles becomes one leaf; 0 = measured optimum
                                  // (1 for width 4, 2 for width 8: their trees have no SAH leaf term, small leaves cull better)

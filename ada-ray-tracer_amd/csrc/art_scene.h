@@ -27,6 +27,16 @@ struct DevSphere { float x, y, z, r; };
 // closest hit of a ray, one 16-byte record: every producer writes it and every consumer reads it with ONE 16-byte access
 struct alignas(16) DevHit { float t; uint32_t key; float u, v; };
 
+// one 16-byte quarter of a 64-byte trace record (art_kernels.h): what the cooperative trace kernel starts a ray from
+struct alignas(16) Rec4 { float x, y, z, w; };
+// Which rays a work item of a bank owns a trace record for (round 3: the wavefront stages write the records themselves, at positions
+// given by the item index -- no queue, no atomics, no separate pass over the rays):
+//   REC_NONE    the plain layout: rays as SoA arrays, k_analytic prepares the queue (one-ray-per-lane schedule, host simulation, debug pass)
+//   REC_EXT     one extension ray per item, record w            (after raygen; PT_STUPID)
+//   REC_BOTH    extension ray at record 2w, shadow ray at 2w+1  (the two rays of a surface point next to each other in the queue)
+//   REC_SHADOW  one shadow ray per item, record w               (after the last bounce: the path itself has ended)
+enum RecMode : int32_t { REC_NONE = 0, REC_EXT = 1, REC_BOTH = 2, REC_SHADOW = 3 };
+
 // Hit key: (class << 28) | index.  Class order == candidate order of Scene.Find_Closest_Hit
 // (scene.adb:62-78: spheres, Cornell box, flat light, mesh) so that the reference's strict-'<' merge
 // is the lexicographic minimum over (t, key).
@@ -107,6 +117,14 @@ struct DevPaths {
   // flags word a path ended with (levels recorded, bits 8..) for the fold; with the identity layout it is the flags array itself.
   const uint32_t* slot_id;
   uint32_t* final_flags;
+  // Trace records of this bank's rays (round 3), 4 x Rec4 per record, or nullptr (REC_NONE: the SoA ray arrays above are used).
+  // A stage reads the extension ray of its input item from the input bank's records ({origin, .} {direction, .}: the first two
+  // quarters) and writes the records of the rays it emits -- analytic primitives already intersected (the starting bound), slab set-up
+  // done -- straight into the output bank's, where the trace kernel picks them up in item order.
+  Rec4* rec;
+  int32_t rec_mode;             // RecMode of `rec`
+  int32_t shadow_rule;          // shadow rays carry Compute_Shadow's 10*eps so that the search may use the visibility rule (option shadow_anyhit)
+  int32_t has_bvh;              // the scene has a BVH mesh: records are only worth writing if a trace kernel will read them
 };
 
 constexpr uint32_t FLAG_ALIVE = 1u, FLAG_PREV_SPEC = 2u, FLAG_SHADOW_PENDING = 4u;

@@ -3,7 +3,10 @@
 
 Workload (N=1 and N>1): BASELINE config C4 -- synthetic 1M random triangles + 3 sphere lights inside the Cornell
 box (SURVEY 8d generator, seed 0xADA5EED0+4), 1920x1080, PT_MIS, Max_Trace_Depth 8, 2x2 AA.  One "step" is one
-Render_Pass of `--vthreads` x 4 samples per pixel (default 64 spp); the full 256-spp render of C4 is the default 4 steps.
+Render_Pass of `--vthreads` x 4 samples per pixel: by default Threads_Num = 64, i.e. ONE STEP IS THE WHOLE 256-spp RENDER OF C4
+(round 3; rounds 1-2 cut it into four 64-spp passes.  On one GPU nothing changes -- a pass is run in batches of at most 128 M
+paths = 64 spp of the full frame either way -- but a GPU that owns 1/8 of the pixels now gets 66 M-path batches instead of 17 M-path
+ones, so its late bounces still fill the chip).
 Rays = closest-hit queries actually issued (camera + bounce + shadow).  Scene upload and BVH build are
 outside the timed region and reported separately in `config`.
 
@@ -39,7 +42,8 @@ import numpy as np  # noqa: E402
 import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_TAG = "r2_final"
+GATHER_CEILING_GBPS = 8000.0   # MI355X_MICROARCH.md "Indexed rows": random rows out of the Infinity Cache, 8.6 TB/s (38 MB table) .. 7.4-7.9 (151 MB)
+PROFILE_TAG = "r3_final"
 
 
 def build_scene(art, args):
@@ -153,13 +157,13 @@ def cpu_baseline(art, sd, args, be):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scene", default="c4", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--tris", type=int, default=1000000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--vthreads", type=int, default=16, help="Threads_Num of the pass: spp per step = 4 * vthreads (default 64: 4 steps = the 256-spp C4 render)")
+    ap.add_argument("--vthreads", type=int, default=64, help="Threads_Num of the pass: spp per step = 4 * vthreads (default 64 -> 256 spp: one step = the whole C4 render)")
     ap.add_argument("--kernel", default="coop", choices=["coop", "simple"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -266,7 +270,7 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel (trace): algorithmic bytes / HIP-event time, device 0's launches
         roofline = None
-        if not args.no_counters and not in_library and info.n_tris > 0:      # a scene without a BVH mesh never launches the trace kernel
+        if not args.no_counters and info.n_tris > 0:      # a scene without a BVH mesh never launches the trace kernel; one-process N-GPU mode: device 0's launches
             be.set_option("count_tests", 1)
             c0 = be.stats()
             be.render_pass_device(art.Backend.pass_params(art.PT_MIS, True, 8, 1, seed=1), spp)   # untimed, counting variant
@@ -288,9 +292,21 @@ def main():
             bytes_per_ray = node_bytes * NV + 48.0 * T + 64.0
             achieved = rays_dev0 * bytes_per_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
             fp = workload_fingerprint(args, W, H, info, args.opt)
-            prof = profiled(args, fp)
+            prof = None if in_library else profiled(args, fp)
+            # What the kernel is limited by, from the committed counter passes of THIS build (profiles/summarize.py), next to the contract figure:
+            #   issue       = fraction of the SIMDs' time spent issuing VALU instructions = SQ_INSTS_VALU per launch / 1024 SIMDs x the mean
+            #                 issue time of the kernel's own instruction mix (profiles/valu_mix.py x profiles/valu_rate2.hip) / launch time
+            #   fabric_frac = bytes that left L2 (traffic) / the guide's ceiling for random multi-line gathers out of the Infinity Cache
+            #                 (8.6 TB/s for a 38 MB table, 7.4-7.9 for 151 MB; the 89 MB working set of C4 is priced at 8.0)
+            issue = round(prof["valu_issue_frac"], 4) if prof and "valu_issue_frac" in prof else None
+            fabric = round(prof["traffic_GBps_fetch_x2"] / GATHER_CEILING_GBPS, 4) if prof else None
             over = achieved > HBM_PEAK_GBPS      # only the 8-wide option: its 256-byte binary32 nodes are mostly served by L2, so the
-            roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",   # algorithmic rate is no HBM rate
+            cands = [("hbm", 0.0 if over else achieved / HBM_PEAK_GBPS)] + ([("issue", issue)] if issue is not None else []) + ([("fabric", fabric)] if fabric is not None else [])
+            bound = max(cands, key=lambda kv: kv[1])[0] if prof else "hbm"
+            roofline = {"bound": bound, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",   # algorithmic rate is no HBM rate
+                        "bound_note": "the largest of frac (algorithmic bytes / HBM peak: the contract figure), issue (VALU issue time / SIMD time) and fabric_frac (bytes past L2 / gather ceiling); 'hbm' when no profile of this build is committed",
+                        "issue": issue, "fabric_frac": fabric,
+                        "device": ("device 0 of %d (one process, art_init_devices); counters summed over the devices" % n_gpus) if in_library else None,
                         "frac": None if over else round(achieved / HBM_PEAK_GBPS, 4),
                         "frac_note": "algorithmic bytes exceed the HBM peak (cache hits): not a roofline fraction" if over else None,
                         "traffic": round(prof["traffic_GBps_fetch_x2"], 1) if prof else None,
@@ -310,17 +326,24 @@ def main():
         cpu = None
         if not args.no_cpu and n_gpus == 1:          # timed on rank 0 at N = 1 only
             cpu = cpu_baseline(art, sd, args, be)
+        elif n_gpus > 1:
+            cpu = {"value": None, "note": "the CPU leg is timed at N = 1 only (bench contract); see the N = 1 line"}
         value = total_rays / elapsed / 1e6
+        spp_step = 4 * args.vthreads
+        render_256_s = elapsed / max(1, args.steps) * (256.0 / spp_step)
         line = {
-            "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": (1 if args.contexts > 1 else n_gpus), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / max(1, args.steps), 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, %dx%d, PT_MIS depth 8, 2x2 AA, %d spp per step" % (scene_name, W, H, 4 * args.vthreads),
                        "spp_per_step": 4 * args.vthreads, "rays_per_sample": round(total_rays / max(1.0, total_samples), 3),
                        "Msamples_per_s": round(total_samples / elapsed / 1e6, 3),
                        "parallelism": ("pixel-tiles x%d, %s" % (n_gpus, "one process (art_init_devices)" if in_library else "one process per GPU (torch.distributed)")) if n_gpus > 1 else "pixel-tiles x1",
+                       "contexts_on_one_gpu": args.contexts if args.contexts > 1 else None,
                        "bvh_width": info.node_width, "bvh_nodes": info.n_nodes, "bvh_build_ms": round(info.build_ms, 1), "bvh_max_stack": info.max_stack, "scene_gen_s": round(t_gen, 2),
-                       "scene_upload_s": round(t_upload, 2), "fingerprint": workload_fingerprint(args, W, H, info, args.opt)},
+                       "scene_upload_s": round(t_upload, 3),
+                       # what a caller waits for: scene upload incl. the BVH build (outside the timed region) + the 256-spp render at the measured rate
+                       "end_to_end_s": round(t_upload + render_256_s, 3), "render_256spp_s": round(render_256_s, 3), "fingerprint": workload_fingerprint(args, W, H, info, args.opt)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -86,4 +86,7 @@ def test_bench_one_process_many_contexts(art):
                         "--warmup", "1", "--vthreads", "1", "--contexts", "4", "--no-cpu"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 4 and line["value"] > 0 and "art_init_devices" in line["config"]["parallelism"]
+    # four contexts on ONE physical GPU are reported as that: n_gpus 1, contexts_on_one_gpu 4; the roofline object is
+    # there in this mode too (device 0's launches), not null
+    assert line["n_gpus"] == 1 and line["config"]["contexts_on_one_gpu"] == 4 and line["value"] > 0 and "art_init_devices" in line["config"]["parallelism"]
+    assert line["roofline"] is not None and line["roofline"]["device"].startswith("device 0 of 4") and line["config"]["end_to_end_s"] > 0
