@@ -203,29 +203,42 @@ static int resize_one(int w, int h) {
 static float* accum_ptr() { return g_ctx.ext_accum ? g_ctx.ext_accum : (float*)g_ctx.b_accum.p; }
 static int download_from(const float* acc_dev, float* accum_host, uint32_t* screen_host, int layout, int spp);
 
-// path arrays for P slots and `depth` fold levels, carved out of one allocation
-// Path arrays for P slots and `depth` fold levels, carved out of one allocation.  Hot state (rays, hits, per-path words, item -> slot
-// map: 29 words per item) exists in TWO banks: every bounce reads one and writes the survivors densely into the other (k_shade_compact);
-// cold state (fold stack, terminal value, per-sample radiance, final flags) is indexed by slot.
-static size_t hot_floats(size_t P) { return (14 + 8 + 1 + 1 + 1 + 3 + 1) * P; }
-static size_t path_floats(size_t P, int depth) { return 2 * hot_floats(P) + (6 * (size_t)depth + 3 + 3 + 1) * P; }
+// Path arrays for P slots and `depth` fold levels, carved out of one allocation.  Hot state exists in TWO banks: every bounce reads one
+// and writes the survivors densely into the other (k_shade_compact); cold state (fold stack, terminal value, per-sample radiance, final
+// flags) is indexed by slot.  Hot state per item, record layout (round 3, the cooperative schedule): the trace records of its two rays
+// (2 x 64 B; the next stage reads the extension ray from there), their hit records (2 x 16 B), prev pdf, flags, shadow epsilon, pending
+// explicit colour, item -> slot map, and the extension ray once more as six SoA words for the next stage: 53 words.  Plain layout (one-ray-per-lane schedule, debug pass): rays as SoA arrays, 29 words.
+constexpr size_t kRecSlack = 4096;       // records past the last one the trace kernel's chunk prefetch may touch
+static size_t hot_floats(size_t P, bool rec) { return (rec ? (32 + 6 + 8 + 7) : (14 + 8 + 7)) * P; }
+static size_t path_floats(size_t P, int depth, bool rec) { return 2 * hot_floats(P, rec) + (6 * (size_t)depth + 3 + 3 + 1) * P + (rec ? 2 * (kRecSlack * 16 + 16) : 0) + 64; }
 
-static int ensure_paths(size_t P, int depth) { return ensure(g_ctx.b_paths, path_floats(P, depth) * 4 + 256); }
+static int ensure_paths(size_t P, int depth, bool rec) { return ensure(g_ctx.b_paths, path_floats(P, depth, rec) * 4 + 256); }
 
 // q[0], q[1]: the two banks (slot_id = their own map); both share the cold arrays.  An identity-layout user takes q[0] with slot_id = nullptr
 // and final_flags = flags.
-static void carve(DevPaths q[2], int P, int depth) {
-  float* f = (float*)g_ctx.b_paths.p; const size_t p = (size_t)P;
+static void carve(DevPaths q[2], int P, int depth, bool rec) {
+  float* const f0 = (float*)g_ctx.b_paths.p;
+  float* f = f0; const size_t p = (size_t)P;
   auto take = [&](size_t n) { float* r = f; f += n; return r; };
+  auto align = [&](size_t floats) { f += (floats - ((size_t)(f - f0) & (floats - 1))) & (floats - 1); };
   for (int k = 0; k < 2; ++k) {
     DevPaths& b = q[k];
-    b.ray_ox = take(2 * p); b.ray_oy = take(2 * p); b.ray_oz = take(2 * p);
-    b.ray_dx = take(2 * p); b.ray_dy = take(2 * p); b.ray_dz = take(2 * p); b.ray_tfar = take(2 * p);
-    f += (4 - ((f - (float*)g_ctx.b_paths.p) & 3)) & 3;                       // 16-byte records (the allocation has the slack)
+    if (rec) {
+      align(16);                                                                // 64-byte records
+      b.rec = (Rec4*)take(32 * p + kRecSlack * 16);
+      b.ray_ox = take(p); b.ray_oy = take(p); b.ray_oz = take(p); b.ray_dx = take(p); b.ray_dy = take(p); b.ray_dz = take(p);   // the extension ray, for the next stage
+      b.ray_tfar = nullptr;
+    } else {
+      b.rec = nullptr; b.rec_mode = REC_NONE;
+      b.ray_ox = take(2 * p); b.ray_oy = take(2 * p); b.ray_oz = take(2 * p);
+      b.ray_dx = take(2 * p); b.ray_dy = take(2 * p); b.ray_dz = take(2 * p); b.ray_tfar = take(2 * p);
+    }
+    align(4);                                                                   // 16-byte hit records
     b.hit = (DevHit*)take(8 * p);
     b.prev_pdf = take(p); b.flags = (uint32_t*)take(p); b.sh_min_t = take(p);
     b.cand_r = take(p); b.cand_g = take(p); b.cand_b = take(p);
     b.slot_id = (const uint32_t*)take(p);
+    b.shadow_rule = g_ctx.shadow_anyhit ? 1 : 0; b.has_bvh = g_ctx.scene.n_tris > 0 ? 1 : 0;
   }
   DevPaths& a = q[0];
   a.e_r = take(depth * p); a.e_g = take(depth * p); a.e_b = take(depth * p);
@@ -273,16 +286,21 @@ static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
   a.rec = (float4*)c.b_queue.p;
   a.ovf_queue = (int*)c.b_ovf.p; a.ovf_count = c.d_cursor + 2;
   a.item_count = nullptr;
+  a.queue_fixed = -1; a.queue_items = nullptr; a.queue_mul = 1;
 }
 
-// one trace launch, bracketed by HIP events on the launch stream
-static int trace(const DevPaths& q, int n_rays, bool timed = true, const int* item_count = nullptr) {
+// one trace launch, bracketed by HIP events on the launch stream.  records != nullptr: the bank's rays are already trace records in item
+// order (DevPaths::rec, written by the stage that emitted them): no k_analytic pass, the queue is the record array itself.
+struct RecordQueue { int fixed; const int* items; int mul; };
+static int trace(const DevPaths& q, int n_rays, bool timed = true, const int* item_count = nullptr, const RecordQueue* records = nullptr) {
   Ctx& c = g_ctx;
   const bool coop = (c.trace_kernel == TRACE_COOP);
   if ((int64_t)n_rays > (1ll << 28)) return fail("internal: more than 2^28 rays in one trace launch (32-bit byte offsets of the 16-byte hit records)");
-  if (coop && ensure(c.b_queue, ((size_t)n_rays + 4096) * kTraceRecBytes)) return 1;      // live-ray queue: one 64-byte trace record per queued ray (+ one chunk of slack for the chunk prefetch)
+  if (records && !coop) return fail("internal: trace records without the cooperative kernel");
+  if (coop && !records && ensure(c.b_queue, ((size_t)n_rays + kRecSlack) * kTraceRecBytes)) return 1;      // live-ray queue: one 64-byte trace record per queued ray (+ one chunk of slack for the chunk prefetch)
   TraceArgs a; fill_trace_args(a, q, n_rays);
   a.item_count = item_count;
+  if (records) { a.rec = (float4*)q.rec; a.queue_fixed = records->fixed; a.queue_items = records->items; a.queue_mul = records->mul; }
   if (coop && a.stack_overflow && ensure(c.b_ovf, (size_t)n_rays * sizeof(int))) return 1;
   a.ovf_queue = (int*)c.b_ovf.p;
   if (coop) {
@@ -293,7 +311,7 @@ static int trace(const DevPaths& q, int n_rays, bool timed = true, const int* it
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     c.ev_pool.push_back(e0); c.ev_pool.push_back(e1);
   }
-  if (coop) launch_analytic(c.stream, c.scene, a, c.count_tests);   // outside the trace-kernel event pair
+  if (coop && !records) launch_analytic(c.stream, c.scene, a, c.count_tests);   // outside the trace-kernel event pair
   if (timed) HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used], c.stream));
   // a workgroup keeps 4 waves x (64 / width) rays in flight: a handful of rays (the legacy per-ray seam) gets a handful of workgroups
   const int rays_per_block = 4 * (64 / std::max(1, c.scene.node_width));
@@ -384,13 +402,16 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
       b.p = nullptr; (void)hipGetLastError();
       return false;
     };
-    const bool need_queue = (c.trace_kernel == TRACE_COOP) && c.scene.n_tris > 0;
+    const bool rec_layout = (c.trace_kernel == TRACE_COOP);              // the cooperative schedule keeps its rays as trace records inside the path state
     for (;;) {
       pc = (int)std::min<int64_t>(npix, std::max<int64_t>(1, cap / per));
       sc = (int)std::min<int64_t>(S, std::max<int64_t>(per, (cap / pc) / per * per));
       hipError_t e;
-      if (try_alloc(g_ctx.b_paths, path_floats((size_t)pc * sc, p->max_depth) * 4 + 256, e) &&
-          (!need_queue || try_alloc(c.b_queue, ((size_t)2 * pc * sc + 4096) * kTraceRecBytes, e))) break;
+      if (try_alloc(g_ctx.b_paths, path_floats((size_t)pc * sc, p->max_depth, rec_layout) * 4 + 256, e)) {
+        if (g_debug_live) std::fprintf(stderr, "path state: %d pixels x %d samples per batch, %.2f GB\n", pc, sc, (double)g_ctx.b_paths.bytes / 1e9);
+        break;
+      }
+      if (g_debug_live) std::fprintf(stderr, "path state: %.2f GB refused (%s)\n", (double)(path_floats((size_t)pc * sc, p->max_depth, rec_layout) * 4 + 256) / 1e9, hipGetErrorString(e));
       if (e != hipErrorOutOfMemory || cap <= 65536) return fail(std::string("path buffers: ") + hipGetErrorString(e));
       cap /= 2;
     }
@@ -408,33 +429,45 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
         const int sn = std::min(sc, S - s0);
         DevPaths bank[2]; std::memset(bank, 0, sizeof bank);
         for (DevPaths& b : bank) { b.P = pn * sn; b.npix = pn; b.pixmap = (const uint32_t*)c.b_pixmap.p + px0; b.sample_base = (uint32_t)(c.spp + s0); }
-        carve(bank, bank[0].P, p->max_depth);
+        carve(bank, bank[0].P, p->max_depth, c.trace_kernel == TRACE_COOP);
         c.camera_rays += (uint64_t)bank[0].P;
-        DevPaths q = bank[0];                            // identity layout for raygen / the plain schedule
-        q.slot_id = nullptr;
         if (c.trace_kernel == TRACE_COOP) {
           // Compacted work sets: raygen fills bank 0 (one item per slot); stage b shades the items of bank b & 1 and writes the survivors
-          // densely into the other bank, which k_analytic + the trace kernel then serve.  d_live[0] / d_live[32]: the banks' item counts.
+          // densely into the other bank.  d_live[0] / d_live[32]: the banks' item counts.  Every stage leaves its rays as trace records in
+          // its output bank (round 3), at positions given by the item index; the trace kernel reads them from there in item order.
           if (!c.d_live) HIP_TRY(hipMalloc(&c.d_live, 64 * sizeof(int)));
+          unsigned long long* const rays_b = c.count_tests ? c.d_counters + 7 : nullptr;          // the counting pass's ray count (stats[4])
+          bank[0].rec_mode = REC_EXT;
+          DevPaths q = bank[0];                            // identity layout for raygen
+          q.slot_id = nullptr;
           launch_raygen(c.stream, F, c.scene, q);
-          if (trace(q, q.P)) return 1;
+          launch_bump(c.stream, c.d_counters, rays_b, (unsigned long long)q.P);
+          { const RecordQueue rq = {q.P, nullptr, 1}; if (trace(q, q.P, true, nullptr, &rq)) return 1; }
           for (int b = 0; b < p->max_depth; ++b) {
             const int in = b & 1, out = in ^ 1;
             const DevPaths& qi = (b == 0) ? q : bank[in];
+            const bool last = b + 1 >= p->max_depth;
+            bank[out].rec_mode = (p->render_type == ART_PT_STUPID) ? REC_EXT : (last ? REC_SHADOW : REC_BOTH);
             HIP_TRY(hipMemsetAsync(c.d_live + 32 * out, 0, sizeof(int), c.stream));
             launch_shade_compact(c.stream, F, c.scene, qi, bank[out], b, b == 0 ? nullptr : c.d_live + 32 * in, c.d_live + 32 * out,
-                                 const_cast<uint32_t*>(bank[out].slot_id), c.d_counters + 15);
+                                 const_cast<uint32_t*>(bank[out].slot_id), c.d_counters + 15, c.d_counters, rays_b);
             if (g_debug_live) {
               int n = -1; unsigned long long r0 = 0;
               (void)hipStreamSynchronize(c.stream); (void)hipMemcpy(&n, c.d_live + 32 * out, 4, hipMemcpyDeviceToHost); (void)hipMemcpy(&r0, c.d_counters, 8, hipMemcpyDeviceToHost);
               std::fprintf(stderr, "stage %d: items out %d of %d, rays so far %llu\n", b, n, q.P, r0);
             }
-            if (b + 1 < p->max_depth || p->render_type != ART_PT_STUPID) { if (trace(bank[out], 2 * q.P, true, c.d_live + 32 * out)) return 1; }
+            if (!last || p->render_type != ART_PT_STUPID) {
+              const RecordQueue rq = {-1, c.d_live + 32 * out, bank[out].rec_mode == REC_BOTH ? 2 : 1};
+              if (trace(bank[out], 2 * q.P, true, c.d_live + 32 * out, &rq)) return 1;
+            }
           }
           const int last = p->max_depth & 1;              // the bank the last stage wrote
           launch_resolve_last(c.stream, bank[last], c.d_live + 32 * last, p->max_depth - 1);
           launch_fold(c.stream, F, bank[last]);
+          launch_accumulate(c.stream, F, q, sn, accum_ptr());
         } else {                                          // one-ray-per-lane cross-check kernel: the plain schedule over all slots, in place
+          DevPaths q = bank[0];
+          q.slot_id = nullptr;
           q.final_flags = q.flags;
           launch_raygen(c.stream, F, c.scene, q);
           for (int b = 0; b < p->max_depth; ++b) {
@@ -443,8 +476,8 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
           }
           if (p->render_type != ART_PT_STUPID) { if (trace(q, 2 * q.P)) return 1; }
           launch_finish(c.stream, F, q, p->max_depth - 1);
+          launch_accumulate(c.stream, F, q, sn, accum_ptr());
         }
-        launch_accumulate(c.stream, F, q, sn, accum_ptr());
         HIP_TRY(hipGetLastError());
       }
     }
@@ -576,11 +609,11 @@ static int debug_pass_one(const ArtPassParams* p, float* accum_host, uint32_t* s
   HIP_TRY(hipMemsetAsync(c.b_ids.p, 0xff, n * 12, c.stream));
   int32_t* d_pi = (int32_t*)c.b_ids.p; int32_t* d_mi = d_pi + n; int32_t* d_pt = d_mi + n;
   const int pc = (int)std::min<int64_t>(npix, c.batch_paths);
-  if (npix > 0 && ensure_paths((size_t)pc, 1)) return 1;
+  if (npix > 0 && ensure_paths((size_t)pc, 1, false)) return 1;
   for (int px0 = 0; px0 < npix; px0 += pc) {
     const int pn = std::min(pc, npix - px0);
     DevPaths bank[2]; std::memset(bank, 0, sizeof bank);
-    carve(bank, pn, 1);
+    carve(bank, pn, 1, false);
     DevPaths q = bank[0];
     q.P = pn; q.npix = pn; q.pixmap = (const uint32_t*)c.b_pixmap.p + px0; q.sample_base = 0; q.slot_id = nullptr; q.final_flags = q.flags;
     launch_raygen(c.stream, F, c.scene, q);

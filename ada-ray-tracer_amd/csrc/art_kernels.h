@@ -31,6 +31,9 @@ struct TraceArgs {
   int* cursor;                  // work cursors, zeroed before every launch: segment k's cursor is cursor[32 * (k + 1)] (cursor[0] serves the
                                 // kernels with a single cursor)
   int* queue; int* queue_count; // queue_count: number of trace records k_analytic queued, zeroed before every launch (queue: the same buffer as rec)
+  // round 3: the wavefront stages write the records themselves, in item order (DevPaths::rec).  Then the queue length is
+  // queue_fixed (>= 0: known on the host), or *queue_items x queue_mul (the output item count of the stage, 1 or 2 records per item)
+  int32_t queue_fixed; const int* queue_items; int32_t queue_mul;
   int* ovf_queue; int* ovf_count;   // stack_overflow: rays handed to k_trace_overflow, count zeroed before every launch
   unsigned long long* stats;    // [box, tri, node, leaf, rays] when counting
   unsigned long long* live_rays;   // += closest-hit queries actually issued by this launch (Mrays/s numerator)
@@ -43,11 +46,13 @@ struct TraceArgs {
 constexpr int kTraceRecBytes = 64;
 
 void launch_raygen(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q);
+void launch_bump(hipStream_t st, unsigned long long* a, unsigned long long* b, unsigned long long n);    // *a += n; if (b) *b += n
 void launch_shade(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q, int bounce);
 void launch_finish(hipStream_t st, const DevFrame& F, const DevPaths& Q, int last_level);
 // compacted work sets (k_shade_compact): shade the items of Qi, write the survivors densely to Qo (+ their slot ids); n_in nullptr: all Qi.P items
+// rays_a / rays_b: += the rays the stage emits as trace records (Qo.rec != nullptr); rays_b may be nullptr
 void launch_shade_compact(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Qi, const DevPaths& Qo, int bounce,
-                          const int* n_in, int* n_out, uint32_t* slot_out, unsigned long long* lost);
+                          const int* n_in, int* n_out, uint32_t* slot_out, unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b);
 void launch_resolve_last(hipStream_t st, const DevPaths& Q, const int* n, int last_level);
 void launch_fold(hipStream_t st, const DevFrame& F, const DevPaths& Q);
 void launch_accumulate(hipStream_t st, const DevFrame& F, const DevPaths& Q, int samples_in_batch, float* accum);

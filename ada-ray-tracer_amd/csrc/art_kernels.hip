@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
   const char* const tris_b = reinterpret_cast<const char*>(G == 4 ? (const void*)A.qtris : (const void*)A.tris);
   const uint32_t jrec = 16u * (uint32_t)j;     // this lane's child record inside a node
   const uint32_t jtri = (uint32_t)j * (uint32_t)(G == 4 ? kQTriBytes : kTriBytes);
-  const int n_queue = *A.queue_count;
+  const int n_queue = (A.queue_fixed >= 0) ? A.queue_fixed : (A.queue_items ? *A.queue_items * A.queue_mul : *A.queue_count);
 
   int chunk_pos = 0, chunk_end = 0;   // wave-uniform
   bool exhausted = false;             // wave-uniform
@@ -205,6 +205,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
   int seg = (int)blockIdx.x & (n_seg - 1), segs_left = n_seg;   // wave-uniform
   mask_t has_ray = 0, pend_valid = 0;                 // group-uniform bits: the group holds a ray / a popped entry waiting for its phase
   uint32_t sa = sb; int ray = 0;
+  int rec_i = 0;                                      // OVF: the ray's record, for k_trace_overflow
   f3 o = mk3(0, 0, 0), d = o, inv = o, noi = o;
   float best_t = 0.0f; uint32_t best_key = KEY_MISS;
   uint32_t pend = 0;                                  // the popped entry word
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         best_t = r0.w; best_key = __builtin_bit_cast(uint32_t, r1.w); shm = r2.w;
         sel_near = __builtin_bit_cast(uint32_t, r3.x); sel_far = 0x18070503u - sel_near;      // per byte: near + far = 3, 5, 7, 0x18 (0x0c + 0x0c)
         ray = __builtin_bit_cast(int, r3.y); far_found = __builtin_bit_cast(uint32_t, r3.z) != 0u;
+        if (OVF) rec_i = chunk_pos + my_rank;
         held_key = KEY_MISS;
         sa = sb; pend = 0u;                                       // entry word 0 = root node (both encodings)
       }
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       sa = OVF ? sel(ovf, sb, top) : top;
       if (OVF) {
         if (ovf != 0) {
-          if (lane_of(ovf) && j == 0) A.ovf_queue[atomicAdd(A.ovf_count, 1)] = ray;
+          if (lane_of(ovf) && j == 0) A.ovf_queue[atomicAdd(A.ovf_count, 1)] = rec_i;
           has_ray &= ~ovf;
         }
       }
@@ -431,17 +433,25 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
 // ------------------------------------------------------------------------------------------------
 // overflow path of k_trace_coop
 // ------------------------------------------------------------------------------------------------
-// rays k_trace_coop<.., OVF = true> gave up on (capped LDS stack): one ray per lane, full search with the private full-size stack
+// rays k_trace_coop<.., OVF = true> gave up on (capped LDS stack): one ray per lane, the BVH search again from the ray's trace record
+// (the starting bound and the shadow rule's starting state are in it) with the private full-size stack.  What ends up in the hit record
+// is what k_trace_coop would have left there: a hit found in the BVH, else the first far hit of a shadow ray, else the starting bound
+// its producer stored.
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_trace_overflow(const DevScene* __restrict__ Sp, const TraceArgs A) {
   const DevScene& S = *Sp;
   const int n = *A.ovf_count;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-    const int i = A.ovf_queue[k];
+    const float4* r = A.rec + 4 * (size_t)A.ovf_queue[k];
+    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+    const int i = __builtin_bit_cast(int, r3.y);
+    const bool far0 = __builtin_bit_cast(uint32_t, r3.z) != 0u;
     BvhStats st = {0, 0, 0, 0};
-    const float shm = (A.sh_min != nullptr && i >= A.shadow_begin) ? A.sh_min[i - A.shadow_begin] : -1.0f;
-    const Cand c = closest_hit<STATS>(S, mk3(A.ray_ox[i], A.ray_oy[i], A.ray_oz[i]), mk3(A.ray_dx[i], A.ray_dy[i], A.ray_dz[i]), A.ray_tfar[i], &st, shm);
-    A.hit[i] = DevHit{c.t, c.key, c.u, c.v};
+    Cand best; best.t = r0.w; best.key = __builtin_bit_cast(uint32_t, r1.w); best.u = 0.0f; best.v = 0.0f;
+    ShadowState sh; sh.shm = r2.w; sh.far = far0; sh.rep = best;
+    bvh_closest<STATS>(S, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), best, &st, sh);
+    if (best.key != KEY_MISS && (best.key & ~KEY_INDEX_MASK) == KEY_TRI) A.hit[i] = DevHit{best.t, best.key, best.u, best.v};
+    else if (sh.far && !far0) A.hit[i] = DevHit{sh.rep.t, sh.rep.key, 0.0f, 0.0f};
   }
 }
 
@@ -615,8 +625,17 @@ __global__ __launch_bounds__(64) void k_trace_instanced(const InstScene T, const
 // wavefront stages
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_raygen(const DevFrame F, const DevScene S, const DevPaths Q) {
+  __shared__ DevSphere s_sph[kAnalyticLdsSpheres];
+  __shared__ DevLight s_lgt[kAnalyticLdsLights];
+  StageCtx cx;
+  if (Q.rec != nullptr && S.n_spheres <= kAnalyticLdsSpheres && S.n_lights <= kAnalyticLdsLights) {      // record mode: the camera ray's analytic intersection happens here
+    if ((int)threadIdx.x < S.n_spheres) s_sph[threadIdx.x] = S.spheres[threadIdx.x];
+    if ((int)threadIdx.x < S.n_lights) s_lgt[threadIdx.x] = S.lights[threadIdx.x];
+    __syncthreads();
+    cx.spheres = s_sph; cx.lights = s_lgt;
+  }
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot < Q.P) raygen_slot(F, S, Q, slot);
+  if (slot < Q.P) raygen_slot(F, S, Q, slot, cx);
 }
 
 __global__ __launch_bounds__(256) void k_shade(const DevFrame F, const DevScene S, const DevPaths Q, int bounce) {
@@ -636,9 +655,20 @@ constexpr int kShadeChunk = 4096, kShadePerThread = kShadeChunk / 256;
 
 __global__ __launch_bounds__(256) void k_shade_compact(const DevFrame F, const DevScene S, const DevPaths Qi, const DevPaths Qo, int bounce,
                                                        const int* __restrict__ n_in_ptr, int* __restrict__ n_out_ptr, uint32_t* __restrict__ slot_out,
-                                                       unsigned long long* lost) {
+                                                       unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b) {
   __shared__ int s_cnt[kShadePerThread * 4];      // survivors per (round k, wave)
-  __shared__ int s_base;
+  __shared__ int s_base, s_rays;
+  // record mode: a wave's trace records of one round, [quarter][record] (+1: four consecutive records' quarters fall into four banks)
+  constexpr int kStagePitch = 2 * 64 + 1;
+  __shared__ Rec4 s_stage[4][4 * kStagePitch];
+  __shared__ DevSphere s_sph[kAnalyticLdsSpheres];      // the scene's spheres and lights, fetched once per workgroup (emit_ray tests every ray against them)
+  __shared__ DevLight s_lgt[kAnalyticLdsLights];
+  const bool tables_in_lds = (S.n_spheres <= kAnalyticLdsSpheres) && (S.n_lights <= kAnalyticLdsLights);
+  if (tables_in_lds) {
+    if ((int)threadIdx.x < S.n_spheres) s_sph[threadIdx.x] = S.spheres[threadIdx.x];
+    if ((int)threadIdx.x < S.n_lights) s_lgt[threadIdx.x] = S.lights[threadIdx.x];
+  }
+  if (threadIdx.x == 0) s_rays = 0;
   const int n_in = n_in_ptr ? *n_in_ptr : Qi.P;
   const int c0 = blockIdx.x * kShadeChunk;
   if (c0 >= n_in) return;
@@ -659,17 +689,42 @@ __global__ __launch_bounds__(256) void k_shade_compact(const DevFrame F, const D
   }
   __syncthreads();
   const int base = s_base;
+  int n_rays = 0;
   for (int k = 0; k < kShadePerThread; ++k) {
     const int w = c0 + k * 256 + threadIdx.x;
     const bool keep = (keep_bits >> k) & 1u;
     const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
     const int wo = keep ? base + s_cnt[k * 4 + wave] + (int)__popcll(m & ((1ull << lane) - 1ull)) : -1;
+    const bool staged = (Qo.rec != nullptr) && Qo.has_bvh;
     if (w < n_in) {
       if (keep) slot_out[wo] = (uint32_t)item_slot(Qi, w);
-      shade_item(F, S, Qi, Qo, w, wo, bounce, lost);
+      StageCtx cx;
+      if (tables_in_lds) { cx.spheres = s_sph; cx.lights = s_lgt; }
+      if (staged) { cx.stage = s_stage[wave]; cx.stage_pitch = kStagePitch; cx.stage_item = (int)__popcll(m & ((1ull << lane) - 1ull)); }
+      n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cx);
+    }
+    if (staged && m != 0) {
+      // the kept items of the wave are consecutive output items, so their records are one contiguous piece of the output bank: every
+      // store instruction writes 64 x 16 consecutive bytes
+      wave_lds_sync();
+      const int per = (Qo.rec_mode == REC_BOTH) ? 2 : 1;
+      const int n_pieces = 4 * per * (int)__popcll(m);
+      const int wo_first = base + s_cnt[k * 4 + wave];
+      Rec4* out = Qo.rec + 4 * rec_slot(Qo.rec_mode, wo_first, false);
+      for (int pc = lane; pc < n_pieces; pc += 64) out[pc] = s_stage[wave][(pc & 3) * kStagePitch + (pc >> 2)];
+      wave_lds_sync();
     }
   }
+  // record mode: the rays just emitted are the closest-hit queries of the next trace launch (k_analytic counts them in the plain layout)
+  if (Qo.rec != nullptr && rays_a != nullptr) {
+    for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_xor(n_rays, off);
+    if (lane == 0 && n_rays) atomicAdd(&s_rays, n_rays);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_rays) { atomicAdd(rays_a, (unsigned long long)s_rays); if (rays_b) atomicAdd(rays_b, (unsigned long long)s_rays); }
+  }
 }
+
+__global__ void k_bump(unsigned long long* a, unsigned long long* b, unsigned long long n) { *a += n; if (b) *b += n; }
 
 // the shadow tests still owed after the last trace, over the last work set; then the fold over all slots
 __global__ __launch_bounds__(256) void k_resolve_last(const DevPaths Q, const int* __restrict__ n_ptr, int last_level) {
@@ -770,9 +825,10 @@ void launch_shade(hipStream_t st, const DevFrame& F, const DevScene& S, const De
   hipLaunchKernelGGL(k_shade, dim3(blocks_for(Q.P)), dim3(256), 0, st, F, S, Q, bounce);
 }
 void launch_shade_compact(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Qi, const DevPaths& Qo, int bounce,
-                          const int* n_in, int* n_out, uint32_t* slot_out, unsigned long long* lost) {
-  hipLaunchKernelGGL(k_shade_compact, dim3((Qi.P + kShadeChunk - 1) / kShadeChunk), dim3(256), 0, st, F, S, Qi, Qo, bounce, n_in, n_out, slot_out, lost);
+                          const int* n_in, int* n_out, uint32_t* slot_out, unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b) {
+  hipLaunchKernelGGL(k_shade_compact, dim3((Qi.P + kShadeChunk - 1) / kShadeChunk), dim3(256), 0, st, F, S, Qi, Qo, bounce, n_in, n_out, slot_out, lost, rays_a, rays_b);
 }
+void launch_bump(hipStream_t st, unsigned long long* a, unsigned long long* b, unsigned long long n) { hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, st, a, b, n); }
 void launch_resolve_last(hipStream_t st, const DevPaths& Q, const int* n, int last_level) {
   hipLaunchKernelGGL(k_resolve_last, dim3(blocks_for(Q.P)), dim3(256), 0, st, Q, n, last_level);
 }

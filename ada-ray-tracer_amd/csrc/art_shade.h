@@ -282,6 +282,63 @@ ART_HD Surface surface_at(const DevScene& s, f3 o, f3 d, float t, uint32_t key, 
   return sf;
 }
 
+// ---------------------------------------------------------------- rays leave a stage as trace records (round 3)
+// Candidates 1-4 of Scene.Find_Closest_Hit (scene.adb:62-69: spheres, Cornell box, rect lights, the reference's brute-force mesh):
+// the starting bound of the BVH search.  The same calls in the same order as k_analytic and closest_hit().
+// What a kernel may hand to the per-item code besides the scene: copies of the sphere and light tables it keeps in LDS (every ray
+// tests every sphere, and a global load per sphere and ray is a round trip per sphere: that alone kept the first fused stage at
+// 3.3 TB/s), and the LDS staging of the records a wave emits (emit_ray).  All optional: the host simulation passes none.
+struct StageCtx {
+  const DevSphere* spheres = nullptr; const DevLight* lights = nullptr;   // nullptr: the scene's own tables
+  Rec4* stage = nullptr; int stage_pitch = 0; int stage_item = 0;
+};
+
+ART_HD Cand analytic_bound(const DevScene& s, const StageCtx& cx, f3 o, f3 d, float tfar) {
+  const DevSphere* sph = cx.spheres ? cx.spheres : s.spheres;
+  const DevLight* lgt = cx.lights ? cx.lights : s.lights;
+  Cand best = cand_init(tfar);
+  for (int i = 0; i < s.n_spheres; ++i) isect_sphere(o, d, sph[i], (uint32_t)i, best);
+  if (s.has_cornell) isect_cornell(o, d, s, best);
+  for (int i = 0; i < s.n_lights; ++i)
+    if (lgt[i].shape == LIGHT_RECT) isect_quad(o, d, lgt[i], (uint32_t)i, best);
+  isect_bf_mesh(o, d, s, best);
+  return best;
+}
+
+ART_HD size_t rec_slot(int mode, int w, bool shadow_ray) { return (mode == REC_BOTH) ? 2 * (size_t)w + (shadow_ray ? 1u : 0u) : (size_t)w; }
+
+// One ray of an output item: its hit record (the starting bound: what stands if the BVH finds nothing nearer) and its 64-byte trace
+// record (art_kernels.h) at position `rq` of the output bank -- everything k_analytic does for the plain layout, done where the ray
+// is born.  shm >= 0: a shadow ray under the visibility rule (art_isect.h shadow_rule).  A ray that does not exist (live = false) or
+// is already decided leaves a record whose bound is negative: the trace kernel takes it and retires it at once.
+// stage != nullptr: the four quarters go to stage[quarter * stage_pitch + stage_slot] instead (LDS: k_shade_compact then writes a wave's
+// records out as contiguous kilobytes -- 64 lanes storing 16 bytes at a 64- or 128-byte stride cost the vector-memory path four times as much).
+ART_HD void emit_ray(const DevScene& s, const DevPaths& qo, size_t hit_index, size_t rq, bool live, f3 o, f3 d, float tfar, float shm,
+                     const StageCtx& cx = StageCtx(), int stage_slot = 0) {
+  Rec4* const stage = cx.stage; const int stage_pitch = cx.stage_pitch;
+  Rec4 r0 = {0.0f, 0.0f, 0.0f, -1.0f}, r1 = {0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, KEY_MISS)}, r2 = {0.0f, 0.0f, 0.0f, -1.0f};
+  Rec4 r3 = {0.0f, __builtin_bit_cast(float, (uint32_t)hit_index), 0.0f, 0.0f};
+  if (live) {
+    const Cand best = analytic_bound(s, cx, o, d, tfar);
+    qo.hit[hit_index] = DevHit{best.t, best.key, best.u, best.v};
+    const bool near_done = (shm >= 0.0f) && (best.key != KEY_MISS) && (best.t <= shm);       // shadow_rule: decided
+    if (!near_done && qo.has_bvh) {
+      f3 inv, noi; slab_setup(o, d, inv, noi);
+      const bool far_found = (shm >= 0.0f) && (best.key != KEY_MISS);
+      const float bt = far_found ? next_up_pos(shm) : best.t;
+      const uint32_t bk = far_found ? KEY_MISS : best.key;
+      const uint32_t sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+      const uint32_t sel_near = (sx ? 3u : 0u) | ((sy ? 4u : 1u) << 8) | ((sz ? 5u : 2u) << 16) | 0x0c000000u;
+      r0 = Rec4{o.x, o.y, o.z, bt}; r1 = Rec4{d.x, d.y, d.z, __builtin_bit_cast(float, bk)}; r2 = Rec4{inv.x, inv.y, inv.z, shm};
+      r3.x = __builtin_bit_cast(float, sel_near); r3.z = __builtin_bit_cast(float, far_found ? 1u : 0u);
+    }
+  }
+  if (!qo.has_bvh) return;                              // no trace kernel will run: the hit record above is the whole answer
+  if (stage) { stage[stage_slot] = r0; stage[stage_pitch + stage_slot] = r1; stage[2 * stage_pitch + stage_slot] = r2; stage[3 * stage_pitch + stage_slot] = r3; return; }
+  Rec4* out = qo.rec + 4 * rq;
+  out[0] = r0; out[1] = r1; out[2] = r2; out[3] = r3;
+}
+
 // ---------------------------------------------------------------- camera (ray_tracer.adb:61-97, integrators.adb:37-58)
 ART_HD void slot_to_sample(const DevPaths& q, int slot, uint32_t& pixel, uint32_t& sample) {
   const int sl = slot / q.npix, pl = slot - sl * q.npix;
@@ -303,14 +360,17 @@ ART_HD f3 camera_dir(const DevFrame& f, const DevScene& s, uint32_t pixel, uint3
   return normalize(xform_point(s.cam_matrix, normalize(r)));
 }
 
-ART_HD void raygen_slot(const DevFrame& f, const DevScene& s, const DevPaths& q, int slot) {
+ART_HD void raygen_slot(const DevFrame& f, const DevScene& s, const DevPaths& q, int slot, const StageCtx& cx = StageCtx()) {
   uint32_t pixel, sample;
   slot_to_sample(q, slot, pixel, sample);
   const f3 d = camera_dir(f, s, pixel, sample);
   q.ray_ox[slot] = s.cam_pos[0]; q.ray_oy[slot] = s.cam_pos[1]; q.ray_oz[slot] = s.cam_pos[2];
   q.ray_dx[slot] = d.x; q.ray_dy[slot] = d.y; q.ray_dz[slot] = d.z;
-  q.ray_tfar[slot] = kInfinity;
-  q.ray_tfar[q.P + slot] = -1.0f;
+  if (q.rec) emit_ray(s, q, (size_t)slot, (size_t)slot, true, ld3(s.cam_pos), d, kInfinity, -1.0f, cx);     // REC_EXT: record `slot`
+  else {
+    q.ray_tfar[slot] = kInfinity;
+    q.ray_tfar[q.P + slot] = -1.0f;
+  }
   q.prev_pdf[slot] = 1.0f;                         // StartSample (materials.ads:25)
   q.flags[slot] = FLAG_ALIVE | FLAG_PREV_SPEC;
   q.term_r[slot] = 0.0f; q.term_g[slot] = 0.0f; q.term_b[slot] = 0.0f;
@@ -343,13 +403,17 @@ ART_HD bool item_survives(const DevFrame& f, const DevScene& s, const DevPaths& 
   return (f.render_type != PT_STUPID) || (bounce + 1 < f.max_depth);
 }
 
-ART_HD void shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, const DevPaths& qo, int w, int wo, int bounce, unsigned long long* lost = nullptr) {
+// Returns the number of rays the item emits (the closest-hit queries of the next trace: Mrays/s counts them).
+ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, const DevPaths& qo, int w, int wo, int bounce, unsigned long long* lost = nullptr,
+                      const StageCtx& cx = StageCtx()) {
   const int slot = item_slot(qi, w);
   const size_t P = (size_t)qi.P;
   uint32_t fl = qi.flags[w];
   // ---- everything the item holds is read first
   const DevHit hw = qi.hit[w];
   const uint32_t key = hw.key;
+  // (the extension ray is kept as six SoA words next to its trace record: reading it back out of the record would pull the whole
+  // 128-byte line of the item's two records for 24 useful bytes)
   const f3 o = mk3(qi.ray_ox[w], qi.ray_oy[w], qi.ray_oz[w]);
   const f3 d = mk3(qi.ray_dx[w], qi.ray_dy[w], qi.ray_dz[w]);
   const float t = hw.t, hu = hw.u, hv = hw.v;
@@ -415,7 +479,7 @@ ART_HD void shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi,
           light = (int)(u01(r1.x) * (float)s.n_lights);
           if (light > s.n_lights - 1) light = s.n_lights - 1;
         }
-        const LightSample ls = light_sample(s.lights[light], u01(rnd.x), u01(rnd.y), hpos);
+        const LightSample ls = light_sample((cx.lights ? cx.lights : s.lights)[light], u01(rnd.x), u01(rnd.y), hpos);
         const f3 sdir = normalize(ls.pos - hpos);
         const float lp = ls.pdf * sel_pdf;
         f3 bx; float bp;
@@ -462,27 +526,44 @@ ART_HD void shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi,
       atomicAdd(lost, 1ull);
 #endif
     }
-    return;
+    return 0;
   }
   const size_t so_i = (size_t)qo.P + (size_t)wo;
   qo.flags[wo] = fl;
   qo.prev_pdf[wo] = new_pdf;
-  qo.ray_tfar[wo] = alive ? kInfinity : -1.0f;
+  if (shadow) {
+    qo.sh_min_t[wo] = sh_min;
+    qo.cand_r[wo] = cand.x; qo.cand_g[wo] = cand.y; qo.cand_b[wo] = cand.z;
+  }
   if (alive) {
     qo.ray_ox[wo] = no.x; qo.ray_oy[wo] = no.y; qo.ray_oz[wo] = no.z;
     qo.ray_dx[wo] = nd.x; qo.ray_dy[wo] = nd.y; qo.ray_dz[wo] = nd.z;
   }
+  if (qo.rec) {
+    // the item's rays go out as trace records, at positions given by the item index (REC_BOTH: 2 wo and 2 wo + 1).  A ray the bank's
+    // mode has no record for cannot exist (the modes follow the integrator: art_api.cpp); should it ever, the self-check counts it.
+    const int mode = qo.rec_mode;
+    const int per = (mode == REC_BOTH) ? 2 : 1;
+    if (mode != REC_SHADOW) emit_ray(s, qo, (size_t)wo, rec_slot(mode, wo, false), alive, no, nd, kInfinity, -1.0f, cx, per * cx.stage_item);
+    if (mode != REC_EXT) emit_ray(s, qo, so_i, rec_slot(mode, wo, true), shadow, so, sd, s_tfar, qo.shadow_rule ? sh_min : -1.0f, cx, per * cx.stage_item + (per - 1));
+    if (lost != nullptr && ((mode == REC_SHADOW && alive) || (mode == REC_EXT && shadow))) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      atomicAdd(lost, 1ull);
+#endif
+    }
+    return (alive ? 1 : 0) + (shadow ? 1 : 0);
+  }
+  qo.ray_tfar[wo] = alive ? kInfinity : -1.0f;
   qo.ray_tfar[so_i] = s_tfar;
   if (shadow) {
     qo.ray_ox[so_i] = so.x; qo.ray_oy[so_i] = so.y; qo.ray_oz[so_i] = so.z;
     qo.ray_dx[so_i] = sd.x; qo.ray_dy[so_i] = sd.y; qo.ray_dz[so_i] = sd.z;
-    qo.sh_min_t[wo] = sh_min;
-    qo.cand_r[wo] = cand.x; qo.cand_g[wo] = cand.y; qo.cand_b[wo] = cand.z;
   }
+  return (alive ? 1 : 0) + (shadow ? 1 : 0);
 }
 
 // the plain layout: one item per slot, updated in place
-ART_HD void shade_slot(const DevFrame& f, const DevScene& s, const DevPaths& q, int slot, int bounce) { shade_item(f, s, q, q, slot, slot, bounce); }
+ART_HD void shade_slot(const DevFrame& f, const DevScene& s, const DevPaths& q, int slot, int bounce) { (void)shade_item(f, s, q, q, slot, slot, bounce); }
 
 // after the last trace: resolve the shadow test item w still owes ...
 ART_HD void resolve_last_shadow(const DevPaths& q, int w, int last_level) {

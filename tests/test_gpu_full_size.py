@@ -112,8 +112,10 @@ def test_c4_full_frame_is_independent_of_shards_batches_and_builder(art, backend
 
 
 def test_batch_is_halved_when_hbm_is_short(art, backend):
-    """A 64-spp 1080p pass wants one batch of 133 M paths: 60 GB of path state + 17 GB of trace records.  With most of the HBM taken by
-    someone else the batch is halved until both buffers fit, and the image is the same bits (the RNG is keyed by pixel, sample, bounce)."""
+    """A 64-spp 1080p pass wants one batch of 133 M paths: 79 GB of path state (596 B per slot at depth 8, the trace records of both rays of
+    an item included since round 3).  With most of the HBM taken by someone else the batch is halved until the buffer fits, and the image
+    is the same bits (the RNG is keyed by pixel, sample, bounce).  The backend is re-initialised first: its buffers only ever grow, and
+    what an earlier test left allocated would decide what fits."""
     import ctypes as C
     from ada_ray_tracer_amd import scenes
     hip = C.CDLL("libamdhip64.so")
@@ -122,6 +124,8 @@ def test_batch_is_halved_when_hbm_is_short(art, backend):
     hip.hipFree.argtypes = [C.c_void_p]
     W, H = 1920, 1080
     sd = scenes.synthetic_scene(2000, 3)
+    backend.shutdown()
+    backend.__init__(0)
     backend.upload_scene(sd)
     p = art.Backend.pass_params(art.PT_MIS, True, 8, 16, seed=3)      # 64 spp: 133 M paths
     backend.set_option("batch_paths", 8 << 20)                         # reference: 16 batches of 8 M paths (buffers of a few GB at most)
@@ -132,7 +136,7 @@ def test_batch_is_halved_when_hbm_is_short(art, backend):
         backend.set_option("batch_paths", 128 << 20)
     free, total = C.c_size_t(0), C.c_size_t(0)
     assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
-    keep = 30 << 30                 # 30 GB left: 60 + 17 GB cannot fit, 30 + 8.5 GB cannot, 15 + 4.3 GB can
+    keep = 30 << 30                 # 30 GB left (+ the 5 GB of the reference render's buffer): 79 GB cannot fit, 39.6 GB cannot, 19.8 GB can
     if free.value <= keep + (8 << 30):
         pytest.skip("not enough free HBM to take away")
     hog = C.c_void_p(None)
