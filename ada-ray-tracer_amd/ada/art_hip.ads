@@ -82,6 +82,22 @@ package Art_Hip is
   end record;
   pragma Convention (C, Art_Pass_Params);
 
+  type Art_Hit is record               --  geometry.ads:57-67 flattened (include/art_hip.h ArtHit, 44 bytes)
+    t          : C_float;
+    is_hit     : int;
+    prim_type  : int;                  --  Primitive'Pos: 0 plane, 1 sphere, 2 triangle, 3 quad; -1 miss
+    prim_index : int;
+    mat_id     : int;
+    mat        : int;
+    normal     : Float3_C;
+    u, v       : C_float;              --  triangle barycentrics (weight of C, weight of B; geometry.adb:245-246)
+  end record;
+  pragma Convention (C, Art_Hit);
+
+  ART_TRACE_COOP : constant := 0;  ART_TRACE_SIMPLE : constant := 1;
+  --  option "bvh_builder": 3 binned SAH on the GPU (default), 0 binned SAH on the host, 1 LBVH, 2 PLOC on the GPU
+  ART_BVH_GPU_SAH : constant := 3;  ART_BVH_HOST_SAH : constant := 0;  ART_BVH_GPU_LBVH : constant := 1;  ART_BVH_GPU_PLOC : constant := 2;
+
   function art_init (device_ordinal : int) return int;
   pragma Import (C, art_init, "art_init");
 
@@ -102,6 +118,18 @@ package Art_Hip is
   function art_debug_hit_pass (p : access constant Art_Pass_Params; accum_host, screen_host : System.Address;
                                prim_index, mat_id, prim_type : System.Address) return int;
   pragma Import (C, art_debug_hit_pass, "art_debug_hit_pass");
+
+  --  Tuning / build options by name (include/art_hip.h lists them), e.g.
+  --    rc := art_set_option (Interfaces.C.Strings.New_String ("bvh_builder"), ART_BVH_HOST_SAH);
+  --  BVH options take effect at the next art_upload_scene.
+  function art_set_option (name : Interfaces.C.Strings.chars_ptr; value : Interfaces.Integer_64) return int;
+  pragma Import (C, art_set_option, "art_set_option");
+
+  --  Scene.Find_Closest_Hit for a list of rays -- SURVEY 8(b)'s "per-ray fallback for debugging": origins / dirs are 3 * n C floats
+  --  ('Address of element 0), tfar may be Null_Address (unbounded), hits points at n Art_Hit records, stats may be Null_Address.
+  function art_trace_rays (origins, dirs, tfar : System.Address; n : Interfaces.Integer_64; hits : System.Address;
+                           kernel : int; stats : System.Address) return int;
+  pragma Import (C, art_trace_rays, "art_trace_rays");
 
   function art_last_error return Interfaces.C.Strings.chars_ptr;
   pragma Import (C, art_last_error, "art_last_error");

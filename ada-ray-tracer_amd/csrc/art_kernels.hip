@@ -635,7 +635,21 @@ __global__ __launch_bounds__(256) void k_raygen(const DevFrame F, const DevScene
     cx.spheres = s_sph; cx.lights = s_lgt;
   }
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  // record mode: a wave's 64 records are 4 KB of consecutive bytes; staged through LDS so that every store instruction writes one
+  // contiguous kilobyte (as in k_shade_compact)
+  constexpr int kPitch = 64 + 1;
+  __shared__ Rec4 s_stage[4][4 * kPitch];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool staged = (Q.rec != nullptr) && Q.has_bvh;
+  if (staged) { cx.stage = s_stage[wave]; cx.stage_pitch = kPitch; cx.stage_item = lane; }
   if (slot < Q.P) raygen_slot(F, S, Q, slot, cx);
+  if (staged) {
+    wave_lds_sync();
+    const int first = slot - lane;
+    const int n_pieces = 4 * max(0, min(64, Q.P - first));
+    Rec4* out = Q.rec + 4 * (size_t)first;
+    for (int pc = lane; pc < n_pieces; pc += 64) out[pc] = s_stage[wave][(pc & 3) * kPitch + (pc >> 2)];
+  }
 }
 
 __global__ __launch_bounds__(256) void k_shade(const DevFrame F, const DevScene S, const DevPaths Q, int bounce) {
@@ -663,20 +677,24 @@ __global__ __launch_bounds__(256) void k_shade_compact(const DevFrame F, const D
   __shared__ Rec4 s_stage[4][4 * kStagePitch];
   __shared__ DevSphere s_sph[kAnalyticLdsSpheres];      // the scene's spheres and lights, fetched once per workgroup (emit_ray tests every ray against them)
   __shared__ DevLight s_lgt[kAnalyticLdsLights];
+  const int n_in = n_in_ptr ? *n_in_ptr : Qi.P;
+  const int c0 = blockIdx.x * kShadeChunk;
+  if (c0 >= n_in) return;                                // the grid covers Qi.P items; the work set has shrunk to n_in
+  // (the material table stays in global memory: a 40-byte per-lane-indexed record out of LDS measured 7 % slower than the cached global read)
   const bool tables_in_lds = (S.n_spheres <= kAnalyticLdsSpheres) && (S.n_lights <= kAnalyticLdsLights);
   if (tables_in_lds) {
     if ((int)threadIdx.x < S.n_spheres) s_sph[threadIdx.x] = S.spheres[threadIdx.x];
     if ((int)threadIdx.x < S.n_lights) s_lgt[threadIdx.x] = S.lights[threadIdx.x];
+    __syncthreads();
   }
+  StageCtx tables;
+  if (tables_in_lds) { tables.spheres = s_sph; tables.lights = s_lgt; }
   if (threadIdx.x == 0) s_rays = 0;
-  const int n_in = n_in_ptr ? *n_in_ptr : Qi.P;
-  const int c0 = blockIdx.x * kShadeChunk;
-  if (c0 >= n_in) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t keep_bits = 0;
   for (int k = 0; k < kShadePerThread; ++k) {
     const int w = c0 + k * 256 + threadIdx.x;
-    const bool keep = (w < n_in) && item_survives(F, S, Qi, w, bounce);
+    const bool keep = (w < n_in) && item_survives(F, S, Qi, w, bounce, tables);
     keep_bits |= keep ? (1u << k) : 0u;
     const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
     if (lane == 0) s_cnt[k * 4 + wave] = (int)__popcll(m);
@@ -698,8 +716,7 @@ __global__ __launch_bounds__(256) void k_shade_compact(const DevFrame F, const D
     const bool staged = (Qo.rec != nullptr) && Qo.has_bvh;
     if (w < n_in) {
       if (keep) slot_out[wo] = (uint32_t)item_slot(Qi, w);
-      StageCtx cx;
-      if (tables_in_lds) { cx.spheres = s_sph; cx.lights = s_lgt; }
+      StageCtx cx = tables;
       if (staged) { cx.stage = s_stage[wave]; cx.stage_pitch = kStagePitch; cx.stage_item = (int)__popcll(m & ((1ull << lane) - 1ull)); }
       n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cx);
     }

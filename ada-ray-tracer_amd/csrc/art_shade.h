@@ -15,6 +15,14 @@ constexpr float kEpsDiv = 1.0e-20f;       // materials.adb:15 / lights.adb:39
 constexpr float kEpsCos = 1.0e-6f;        // materials.adb:16
 constexpr float kPhongClamp = 0x1.921eaep+0f;  // static M_PI*0.499995 (materials.adb:374)
 
+// What a kernel may hand to the per-item code besides the scene: copies of the small scene tables it keeps in LDS (every ray tests
+// every sphere and every shaded hit reads its material: a global load each is a round trip each -- that alone kept the first fused
+// stage at 3.3 TB/s), and the LDS staging of the records a wave emits (emit_ray).  All optional: the host simulation passes none.
+struct StageCtx {
+  const DevSphere* spheres = nullptr; const DevLight* lights = nullptr; const DevMaterial* materials = nullptr;   // nullptr: the scene's own tables
+  Rec4* stage = nullptr; int stage_pitch = 0; int stage_item = 0;
+};
+
 // ---------------------------------------------------------------- sampling helpers
 ART_HD f3 perpendicular(f3 a) {   // GetPerpendicular
   const float xp = fabsf(a.x), yp = fabsf(a.y), zp = fabsf(a.z);
@@ -252,11 +260,11 @@ ART_HD void bsdf_eval(const DevMaterial& m, f3 l, f3 v, f3 n, f3& bxdf, float& p
 // ---------------------------------------------------------------- hit record -> shading frame
 struct Surface { f3 normal; int32_t mat; int32_t mat_id; };
 
-ART_HD Surface surface_at(const DevScene& s, f3 o, f3 d, float t, uint32_t key, float u, float v) {
+ART_HD Surface surface_at(const DevScene& s, f3 o, f3 d, float t, uint32_t key, float u, float v, const StageCtx& cx = StageCtx()) {
   Surface sf;
   const uint32_t cls = key & ~KEY_INDEX_MASK, idx = key & KEY_INDEX_MASK;
   if (cls == KEY_SPHERE) {                                      // geometry.adb:88,95-96
-    const DevSphere sp = s.spheres[idx];
+    const DevSphere sp = (cx.spheres ? cx.spheres : s.spheres)[idx];
     sf.normal = normalize((o + d * t) - mk3(sp.x, sp.y, sp.z));
     sf.mat = s.sphere_mat[idx]; sf.mat_id = 0;
   } else if (cls == KEY_CORNELL) {                              // geometry.adb:215-224 + scene.adb:80-82
@@ -264,7 +272,7 @@ ART_HD Surface surface_at(const DevScene& s, f3 o, f3 d, float t, uint32_t key, 
     sf.mat_id = s.cb_mat[idx]; sf.mat = sf.mat_id;
   } else if (cls == KEY_QUAD) {                                 // geometry.adb:132-141
     sf.normal = mk3(0.0f, -1.0f, 0.0f);
-    sf.mat = s.lights[idx].mat; sf.mat_id = 0;
+    sf.mat = (cx.lights ? cx.lights : s.lights)[idx].mat; sf.mat_id = 0;
   } else {
     const float w = 1.0f - u - v;                               // geometry.adb:301
     if (cls == KEY_BFTRI) {
@@ -285,14 +293,6 @@ ART_HD Surface surface_at(const DevScene& s, f3 o, f3 d, float t, uint32_t key, 
 // ---------------------------------------------------------------- rays leave a stage as trace records (round 3)
 // Candidates 1-4 of Scene.Find_Closest_Hit (scene.adb:62-69: spheres, Cornell box, rect lights, the reference's brute-force mesh):
 // the starting bound of the BVH search.  The same calls in the same order as k_analytic and closest_hit().
-// What a kernel may hand to the per-item code besides the scene: copies of the sphere and light tables it keeps in LDS (every ray
-// tests every sphere, and a global load per sphere and ray is a round trip per sphere: that alone kept the first fused stage at
-// 3.3 TB/s), and the LDS staging of the records a wave emits (emit_ray).  All optional: the host simulation passes none.
-struct StageCtx {
-  const DevSphere* spheres = nullptr; const DevLight* lights = nullptr;   // nullptr: the scene's own tables
-  Rec4* stage = nullptr; int stage_pitch = 0; int stage_item = 0;
-};
-
 ART_HD Cand analytic_bound(const DevScene& s, const StageCtx& cx, f3 o, f3 d, float tfar) {
   const DevSphere* sph = cx.spheres ? cx.spheres : s.spheres;
   const DevLight* lgt = cx.lights ? cx.lights : s.lights;
@@ -366,7 +366,7 @@ ART_HD void raygen_slot(const DevFrame& f, const DevScene& s, const DevPaths& q,
   const f3 d = camera_dir(f, s, pixel, sample);
   q.ray_ox[slot] = s.cam_pos[0]; q.ray_oy[slot] = s.cam_pos[1]; q.ray_oz[slot] = s.cam_pos[2];
   q.ray_dx[slot] = d.x; q.ray_dy[slot] = d.y; q.ray_dz[slot] = d.z;
-  if (q.rec) emit_ray(s, q, (size_t)slot, (size_t)slot, true, ld3(s.cam_pos), d, kInfinity, -1.0f, cx);     // REC_EXT: record `slot`
+  if (q.rec) emit_ray(s, q, (size_t)slot, (size_t)slot, true, ld3(s.cam_pos), d, kInfinity, -1.0f, cx, cx.stage_item);     // REC_EXT: record `slot`
   else {
     q.ray_tfar[slot] = kInfinity;
     q.ray_tfar[q.P + slot] = -1.0f;
@@ -385,7 +385,7 @@ ART_HD int item_slot(const DevPaths& q, int w) { return q.slot_id ? (int)q.slot_
 // Will item w still need an item after shade_item(bounce)?  (It will if the path goes on, or if it emits a shadow ray whose test is
 // resolved at the next stage.)  Used to number the output items before shading; it must never say no where shade_item says yes --
 // shade_item reports that case (lost != nullptr) -- while a needless yes only costs an idle item.
-ART_HD bool item_survives(const DevFrame& f, const DevScene& s, const DevPaths& qi, int w, int bounce) {
+ART_HD bool item_survives(const DevFrame& f, const DevScene& s, const DevPaths& qi, int w, int bounce, const StageCtx& cx = StageCtx()) {
   const uint32_t fl = qi.flags[w];
   if (!(fl & FLAG_ALIVE)) return false;                       // only owed a shadow test: resolved now
   const uint32_t key = qi.hit[w].key;
@@ -394,11 +394,11 @@ ART_HD bool item_survives(const DevFrame& f, const DevScene& s, const DevPaths& 
   int32_t mat;
   if (cls == KEY_SPHERE) mat = s.sphere_mat[idx];
   else if (cls == KEY_CORNELL) mat = s.cb_mat[idx];
-  else if (cls == KEY_QUAD) mat = s.lights[idx].mat;
+  else if (cls == KEY_QUAD) mat = (cx.lights ? cx.lights : s.lights)[idx].mat;
   else if (cls == KEY_BFTRI) mat = 2;
   else mat = __builtin_bit_cast(int32_t, s.m_shade[(size_t)kTriShadeFloats * (size_t)idx + 9]);
   if (mat < 0 || mat >= s.n_materials) return false;
-  const int32_t type = s.materials[mat].type;
+  const int32_t type = (cx.materials ? cx.materials : s.materials)[mat].type;
   if (type == MAT_NULL || type == MAT_LIGHT) return false;
   return (f.render_type != PT_STUPID) || (bounce + 1 < f.max_depth);
 }
@@ -442,21 +442,22 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     alive = false;
   };
   if (alive) {
-    const Surface sf = (key != KEY_MISS) ? surface_at(s, o, d, t, key, hu, hv) : Surface{zero, -1, -1};
+    const Surface sf = (key != KEY_MISS) ? surface_at(s, o, d, t, key, hu, hv, cx) : Surface{zero, -1, -1};
+    const DevLight* const lights = cx.lights ? cx.lights : s.lights;
     const bool mat_ok = (key != KEY_MISS) && sf.mat >= 0 && sf.mat < s.n_materials;
-    const DevMaterial m = mat_ok ? s.materials[sf.mat] : DevMaterial{MAT_NULL, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
+    const DevMaterial m = mat_ok ? (cx.materials ? cx.materials : s.materials)[sf.mat] : DevMaterial{MAT_NULL, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
     if (!mat_ok || m.type == MAT_NULL) kill(bounce, zero);                            // integrators.adb:218-220
     else if (m.type == MAT_LIGHT) {                                                   // :102-108 / :155-157 / :222-247
       const f3 n = sf.normal;
       const float sel_pdf = 1.0f / (float)s.n_lights;
       f3 out = zero;
       if (f.render_type != PT_SHADOW && !(dot(neg(d), n) < 0.0f)) {
-        const f3 emit = (m.light >= 0 && m.light < s.n_lights) ? ld3(s.lights[m.light].intensity) : zero;
+        const f3 emit = (m.light >= 0 && m.light < s.n_lights) ? ld3(lights[m.light].intensity) : zero;
         if (f.render_type == PT_STUPID) out = emit;
         else {
           float mis = 1.0f;
           if (!(fl & FLAG_PREV_SPEC)) {
-            const float lp = light_eval_pdf(s.lights[m.light], o, d, t) * sel_pdf;
+            const float lp = light_eval_pdf(lights[m.light], o, d, t) * sel_pdf;
             const float bp = prev_pdf;
             mis = bp * bp / (lp * lp + bp * bp);
           }
@@ -479,7 +480,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
           light = (int)(u01(r1.x) * (float)s.n_lights);
           if (light > s.n_lights - 1) light = s.n_lights - 1;
         }
-        const LightSample ls = light_sample((cx.lights ? cx.lights : s.lights)[light], u01(rnd.x), u01(rnd.y), hpos);
+        const LightSample ls = light_sample(lights[light], u01(rnd.x), u01(rnd.y), hpos);
         const f3 sdir = normalize(ls.pos - hpos);
         const float lp = ls.pdf * sel_pdf;
         f3 bx; float bp;

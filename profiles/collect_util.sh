@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$NAME
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-counters $*"
+B="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu --no-counters $*"
 pass() { n=$1; shift; timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- $B > $OUT/$n.log 2>&1 || { echo "pass $n failed"; tail -3 $OUT/$n.log; return 1; }; }
 pass ta GRBM_GUI_ACTIVE TA_BUSY_avr TA_BUSY_max || exit 1
 pass ta2 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum || exit 1

@@ -1,19 +1,22 @@
+# Round-3 evidence, one gpurun call:  bash profiles/final_collect.sh   (raw output under gpurun_out/, summaries made afterwards by
+# profiles/valu_mix.py + profiles/summarize.py in the build container)
 set -e
 cd $GRAFT_REPO_ROOT
 bash profiles/collect.sh c4
 bash profiles/collect_util.sh c4
-bash profiles/collect.sh c3 --scene c3 --width 1024 --height 1024
-bash profiles/collect_util.sh c3 --scene c3 --width 1024 --height 1024
+bash profiles/collect.sh c3 --scene c3 --width 1024 --height 1024 --vthreads 16
+bash profiles/collect_util.sh c3 --scene c3 --width 1024 --height 1024 --vthreads 16
 mkdir -p gpurun_out/cfg3
 python bench.py --scene c2 --width 512 --height 512 --vthreads 4 --steps 1 --warmup 1 > gpurun_out/cfg3/c2.json 2> gpurun_out/cfg3/c2.err
-python bench.py --scene c3 --width 1024 --height 1024 --steps 1 --warmup 1 > gpurun_out/cfg3/c3.json 2> gpurun_out/cfg3/c3.err
+python bench.py --scene c3 --width 1024 --height 1024 --vthreads 16 --steps 1 --warmup 1 > gpurun_out/cfg3/c3.json 2> gpurun_out/cfg3/c3.err
 python bench.py --scene c5 --width 4096 --height 4096 --vthreads 8 --steps 32 --warmup 1 > gpurun_out/cfg3/c5.json 2> gpurun_out/cfg3/c5.err
 python bench.py > gpurun_out/cfg3/c4.json 2> gpurun_out/cfg3/c4.err
 python bench.py --host-buffers --no-cpu > gpurun_out/cfg3/c4_host.json 2> gpurun_out/cfg3/c4_host.err
+python bench.py --no-cpu --opt bvh_builder=0 > gpurun_out/cfg3/c4_hostsah.json 2> gpurun_out/cfg3/c4_hostsah.err
 python bench.py --no-cpu --opt bvh_builder=1 > gpurun_out/cfg3/c4_lbvh.json 2> gpurun_out/cfg3/c4_lbvh.err
 python bench.py --no-cpu --simulate-shard 0/8 > gpurun_out/cfg3/c4_shard8.json 2> gpurun_out/cfg3/c4_shard8.err
 python bench.py --no-cpu --contexts 8 > gpurun_out/cfg3/c4_ctx8.json 2> gpurun_out/cfg3/c4_ctx8.err
 python bench.py --no-cpu --opt bvh_width=8 > gpurun_out/cfg3/c4_w8.json 2> gpurun_out/cfg3/c4_w8.err
 for f in gpurun_out/cfg3/*.json; do python -c "
 import json,sys
-d=json.load(open('$f')); r=d.get('roofline') or {}; print('$f', d['value'], d['ms_per_step'], r.get('frac'), r.get('trace_Mrays_per_s'), (d.get('cpu_baseline') or {}).get('value'))"; done
+d=json.load(open('$f')); r=d.get('roofline') or {}; print('$f', d['value'], d['ms_per_step'], r.get('frac'), r.get('trace_Mrays_per_s'), d['config'].get('end_to_end_s'), (d.get('cpu_baseline') or {}).get('value'))"; done

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main(tag, name="c4"):
-    """tag: directory under profiles/ (r2_final for the bench.py default workload C4, which bench.py quotes; r2_c3 ...);
+    """tag: directory under profiles/ (r3_final for the bench.py default workload C4, which bench.py quotes; r3_c3 ...);
     name: the collect.sh run to read (gpurun_out/prof_<name>)"""
     global SRC
     SRC = os.path.join(ROOT, "gpurun_out", "prof_" + name)
@@ -69,6 +69,33 @@ def main(tag, name="c4"):
                 if "SQ_INSTS_VMEM_RD" in o:
                     u["vmem_read_insts_per_launch"] = o["SQ_INSTS_VMEM_RD"] / o["dispatches_sq2"]; u["lds_insts_per_launch"] = o["SQ_INSTS_LDS"] / o["dispatches_sq2"]
                 o["utilisation"] = u
+            # issue-boundness (profiles/valu_mix.py): VALU instructions per launch and SIMD x their mean issue time / launch time
+            mix_path = os.path.join(dst, "valu_mix.json")
+            if os.path.exists(mix_path) and "SQ_INSTS_VALU" in o:
+                mix = json.load(open(mix_path))
+                per_simd = o["SQ_INSTS_VALU"] / o["dispatches_sq"] / 1024.0
+                launch_ns = o["total_ns_sq"] / o["dispatches_sq"]
+                o["valu_mean_issue_ns"] = mix["mean_issue_ns_per_valu_instruction"]
+                o["valu_instructions_per_ns_and_simd"] = per_simd / launch_ns
+                o["valu_issue_frac"] = per_simd * mix["mean_issue_ns_per_valu_instruction"] / launch_ns
+                o["valu_issue_formula"] = "SQ_INSTS_VALU / dispatches / 1024 SIMDs x mean issue ns of the kernel's instruction mix (valu_mix.json x valu_rate2.hip) / launch ns"
+    # the other kernels of a step: bytes past L2 and achieved TB/s (the stages are memory-bound; the HBM roofline is theirs)
+    others = {}
+    for k, o in out.items():
+        if "k_trace_coop" in k or "FETCH_SIZE" not in o or "dispatches_write" not in o or not k.startswith("art::"):
+            continue
+        n = o["dispatches_fetch"]
+        fb = 2.0 * o["FETCH_SIZE"] * 1024.0 / n; wb = o["WRITE_SIZE"] * 1024.0 / o["dispatches_write"]; ns = o["total_ns_fetch"] / n
+        e = {"launches": n, "avg_launch_ms": ns / 1e6, "fetch_x2_GB_per_launch": fb / 1e9, "write_GB_per_launch": wb / 1e9, "traffic_TBps": (fb + wb) / ns / 1e3,
+             "frac_of_hbm_peak_8TBps": (fb + wb) / ns / 8000.0}
+        if "SQ_INSTS_VALU" in o:
+            e["valu_instructions_per_ns_and_simd"] = o["SQ_INSTS_VALU"] / o["dispatches_sq"] / 1024.0 / (o["total_ns_sq"] / o["dispatches_sq"])
+        if "TCC_HIT_sum" in o:
+            e["l2_hit_rate"] = o["TCC_HIT_sum"] / max(1.0, o["TCC_HIT_sum"] + o["TCC_MISS_sum"])
+        if "TA_BUSY_avr" in o and "GRBM_GUI_ACTIVE" in o:
+            e["ta_busy_avg"] = o["TA_BUSY_avr"] / (o["GRBM_GUI_ACTIVE"] / 8.0)
+        others[k.replace("art::", "")] = e
+    out["stage_kernels"] = others
     b = os.path.join(SRC, "bench_under_rocprof.json")
     if os.path.exists(b):
         shutil.copyfile(b, os.path.join(dst, "bench_under_rocprof.json"))
@@ -82,4 +109,4 @@ def main(tag, name="c4"):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r2_final", sys.argv[2] if len(sys.argv) > 2 else "c4")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r3_final", sys.argv[2] if len(sys.argv) > 2 else "c4")
