@@ -667,13 +667,15 @@ __global__ __launch_bounds__(256) void k_shade(const DevFrame F, const DevScene 
 // ------------------------------------------------------------------------------------------------
 constexpr int kShadeChunk = 4096, kShadePerThread = kShadeChunk / 256;
 
-__global__ __launch_bounds__(256) void k_shade_compact(const DevFrame F, const DevScene S, const DevPaths Qi, const DevPaths Qo, int bounce,
+// 6 waves per SIMD (80 VGPRs, 48 bytes of scratch per lane): the stage is bound by the latency of its dependent gathers (hit -> triangle
+// shading record -> material), not by issue or bandwidth; left to itself the compiler takes 111 VGPRs = 4 waves (6.6 -> 6.2 ms per launch on C4)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_shade_compact(const DevFrame F, const DevScene S, const DevPaths Qi, const DevPaths Qo, int bounce,
                                                        const int* __restrict__ n_in_ptr, int* __restrict__ n_out_ptr, uint32_t* __restrict__ slot_out,
                                                        unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b) {
   __shared__ int s_cnt[kShadePerThread * 4];      // survivors per (round k, wave)
   __shared__ int s_base, s_rays;
   // record mode: a wave's trace records of one round, [quarter][record] (+1: four consecutive records' quarters fall into four banks)
-  constexpr int kStagePitch = 2 * 64 + 1;
+  constexpr int kStagePitch = 64 + 1;
   __shared__ Rec4 s_stage[4][4 * kStagePitch];
   __shared__ DevSphere s_sph[kAnalyticLdsSpheres];      // the scene's spheres and lights, fetched once per workgroup (emit_ray tests every ray against them)
   __shared__ DevLight s_lgt[kAnalyticLdsLights];
@@ -717,19 +719,15 @@ __global__ __launch_bounds__(256) void k_shade_compact(const DevFrame F, const D
     if (w < n_in) {
       if (keep) slot_out[wo] = (uint32_t)item_slot(Qi, w);
       StageCtx cx = tables;
-      if (staged) { cx.stage = s_stage[wave]; cx.stage_pitch = kStagePitch; cx.stage_item = (int)__popcll(m & ((1ull << lane) - 1ull)); }
+      if (staged) {
+        // the kept items of the wave are consecutive output items: their records are one contiguous piece of the output bank, the
+        // extension rays first, then the shadow rays (REC_BOTH); emit_ray stages one kind at a time and the emitting lanes copy it out
+        const int nk = (int)__popcll(m), per = (Qo.rec_mode == REC_BOTH) ? 2 : 1;
+        const size_t first = (size_t)per * (size_t)(base + s_cnt[k * 4 + wave]);
+        cx.stage = s_stage[wave]; cx.stage_pitch = kStagePitch; cx.stage_item = (int)__popcll(m & ((1ull << lane) - 1ull));
+        cx.stage_count = nk; cx.rec_base[0] = first; cx.rec_base[1] = (per == 2) ? first + (size_t)nk : first;
+      }
       n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cx);
-    }
-    if (staged && m != 0) {
-      // the kept items of the wave are consecutive output items, so their records are one contiguous piece of the output bank: every
-      // store instruction writes 64 x 16 consecutive bytes
-      wave_lds_sync();
-      const int per = (Qo.rec_mode == REC_BOTH) ? 2 : 1;
-      const int n_pieces = 4 * per * (int)__popcll(m);
-      const int wo_first = base + s_cnt[k * 4 + wave];
-      Rec4* out = Qo.rec + 4 * rec_slot(Qo.rec_mode, wo_first, false);
-      for (int pc = lane; pc < n_pieces; pc += 64) out[pc] = s_stage[wave][(pc & 3) * kStagePitch + (pc >> 2)];
-      wave_lds_sync();
     }
   }
   // record mode: the rays just emitted are the closest-hit queries of the next trace launch (k_analytic counts them in the plain layout)

@@ -21,7 +21,16 @@ constexpr float kPhongClamp = 0x1.921eaep+0f;  // static M_PI*0.499995 (material
 struct StageCtx {
   const DevSphere* spheres = nullptr; const DevLight* lights = nullptr; const DevMaterial* materials = nullptr;   // nullptr: the scene's own tables
   Rec4* stage = nullptr; int stage_pitch = 0; int stage_item = 0;
+  // k_shade_compact: stage_count > 0 lanes of the wave emit together (stage_item = this lane's rank among them) and copy the records out
+  // themselves, one kind of ray at a time; rec_base[0 / 1]: first record of the wave's extension / shadow rays in the output bank
+  int stage_count = 0; size_t rec_base[2] = {0, 0};
 };
+
+ART_HD void wave_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
 
 // ---------------------------------------------------------------- sampling helpers
 ART_HD f3 perpendicular(f3 a) {   // GetPerpendicular
@@ -314,7 +323,7 @@ ART_HD size_t rec_slot(int mode, int w, bool shadow_ray) { return (mode == REC_B
 // stage != nullptr: the four quarters go to stage[quarter * stage_pitch + stage_slot] instead (LDS: k_shade_compact then writes a wave's
 // records out as contiguous kilobytes -- 64 lanes storing 16 bytes at a 64- or 128-byte stride cost the vector-memory path four times as much).
 ART_HD void emit_ray(const DevScene& s, const DevPaths& qo, size_t hit_index, size_t rq, bool live, f3 o, f3 d, float tfar, float shm,
-                     const StageCtx& cx = StageCtx(), int stage_slot = 0) {
+                     const StageCtx& cx = StageCtx(), int stage_slot = 0, int kind = 0) {
   Rec4* const stage = cx.stage; const int stage_pitch = cx.stage_pitch;
   Rec4 r0 = {0.0f, 0.0f, 0.0f, -1.0f}, r1 = {0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, KEY_MISS)}, r2 = {0.0f, 0.0f, 0.0f, -1.0f};
   Rec4 r3 = {0.0f, __builtin_bit_cast(float, (uint32_t)hit_index), 0.0f, 0.0f};
@@ -334,7 +343,18 @@ ART_HD void emit_ray(const DevScene& s, const DevPaths& qo, size_t hit_index, si
     }
   }
   if (!qo.has_bvh) return;                              // no trace kernel will run: the hit record above is the whole answer
-  if (stage) { stage[stage_slot] = r0; stage[stage_pitch + stage_slot] = r1; stage[2 * stage_pitch + stage_slot] = r2; stage[3 * stage_pitch + stage_slot] = r3; return; }
+  if (stage) {
+    stage[stage_slot] = r0; stage[stage_pitch + stage_slot] = r1; stage[2 * stage_pitch + stage_slot] = r2; stage[3 * stage_pitch + stage_slot] = r3;
+    if (cx.stage_count > 0) {
+      // the lanes that emit (all of them are here: the call sits behind no data-dependent branch) copy their stage_count records out,
+      // 16 bytes per lane and pass, consecutive lanes to consecutive addresses.  LDS operations of one wave execute in order.
+      wave_fence();
+      Rec4* out = qo.rec + 4 * cx.rec_base[kind];
+      for (int it = 0; it < 4; ++it) { const int g = it * cx.stage_count + stage_slot; out[g] = stage[(g & 3) * stage_pitch + (g >> 2)]; }
+      wave_fence();
+    }
+    return;
+  }
   Rec4* out = qo.rec + 4 * rq;
   out[0] = r0; out[1] = r1; out[2] = r2; out[3] = r3;
 }
@@ -545,8 +565,10 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     // mode has no record for cannot exist (the modes follow the integrator: art_api.cpp); should it ever, the self-check counts it.
     const int mode = qo.rec_mode;
     const int per = (mode == REC_BOTH) ? 2 : 1;
-    if (mode != REC_SHADOW) emit_ray(s, qo, (size_t)wo, rec_slot(mode, wo, false), alive, no, nd, kInfinity, -1.0f, cx, per * cx.stage_item);
-    if (mode != REC_EXT) emit_ray(s, qo, so_i, rec_slot(mode, wo, true), shadow, so, sd, s_tfar, qo.shadow_rule ? sh_min : -1.0f, cx, per * cx.stage_item + (per - 1));
+    // (staged by k_shade_compact: each kind of ray is its own contiguous block of the wave's records, copied out before the next kind is staged)
+    const bool blocks = cx.stage_count > 0;
+    if (mode != REC_SHADOW) emit_ray(s, qo, (size_t)wo, rec_slot(mode, wo, false), alive, no, nd, kInfinity, -1.0f, cx, blocks ? cx.stage_item : per * cx.stage_item, 0);
+    if (mode != REC_EXT) emit_ray(s, qo, so_i, rec_slot(mode, wo, true), shadow, so, sd, s_tfar, qo.shadow_rule ? sh_min : -1.0f, cx, blocks ? cx.stage_item : per * cx.stage_item + (per - 1), 1);
     if (lost != nullptr && ((mode == REC_SHADOW && alive) || (mode == REC_EXT && shadow))) {
 #if defined(__HIP_DEVICE_COMPILE__)
       atomicAdd(lost, 1ull);
