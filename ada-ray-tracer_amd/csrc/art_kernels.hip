@@ -155,6 +155,34 @@ __device__ __forceinline__ void lds_store(uint32_t addr, uint2 v) {       // two
   asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" :: "v"(addr), "v"(v.x), "v"(v.y) : "memory");
 }
 
+// ---- "x = mask ? y : x" as ONE vector instruction under EXEC = mask (round 3).  The kernel's VALU is saturated (issue fraction 1.0,
+// profiles/r3_final) while its scalar unit is 40 % busy: a v_cndmask holds the SIMD for 1.85 ns, the v_mov / v_add that does the same
+// under a lane mask for 0.94 / 1.1 ns, and the two s_mov that set and restore EXEC issue beside the other waves' vector instructions.
+// Only used where all 64 lanes are enabled (the step code of k_trace_coop).  ART_EXECM selects which selects are replaced (bit 0 node
+// load, 1 pop, 2 push + sort key, 3 stack pointer = address of the top entry).  Measured on C4, trace launch average (two boxes, A/B in
+// one call each): 0 -> 57.35 / 57.58 ms, 13 -> 56.73 / 56.85 (-1.2 %), 15 -> 57.15 / 57.18, 5 -> 57.06; alone, bit 1 (the pop) is 0.5 %
+// slower, bits 0 / 2 / 3 are within noise: the step answers to the shape of its dependency chains more than to its instruction count.
+#ifndef ART_EXECM
+#define ART_EXECM 13
+#endif
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pop_masked(mask_t v1, mask_t ok1, uint32_t& sa, uint32_t& pend, uint32_t entry) {     // sa -= 8 in v1, pend = entry in ok1
+  asm("s_mov_b64 exec, %2\n\tv_add_u32 %0, -8, %0\n\ts_mov_b64 exec, %3\n\tv_mov_b32 %1, %4\n\ts_mov_b64 exec, -1" : "+v"(sa), "+v"(pend) : "s"(v1), "s"(ok1), "v"(entry));
+}
+__device__ __forceinline__ u32x4 load_node_masked(mask_t m, const char* base, uint32_t off) {                        // lanes outside m keep garbage: their results are masked
+  u32x4 r;
+  asm volatile("s_mov_b64 exec, %1\n\tglobal_load_dwordx4 %0, %2, %3\n\ts_mov_b64 exec, -1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "s"(m), "v"(off), "s"(base) : "memory");
+  return r;
+}
+__device__ __forceinline__ void lds_store_masked(mask_t m, uint32_t addr, uint2 v) {
+  asm volatile("s_mov_b64 exec, %0\n\tds_write2_b32 %1, %2, %3 offset1:1\n\ts_mov_b64 exec, -1" :: "s"(m), "v"(addr), "v"(v.x), "v"(v.y) : "memory");
+}
+__device__ __forceinline__ uint32_t key_masked(mask_t hit, uint32_t tmn_bits, uint32_t j, uint32_t miss) {           // hit ? (tmn & ~7) | j : miss
+  uint32_t k;
+  asm("v_mov_b32 %0, %4\n\ts_mov_b64 exec, %1\n\tv_and_or_b32 %0, %2, -8, %3\n\ts_mov_b64 exec, -1" : "=&v"(k) : "s"(hit), "v"(tmn_bits), "v"(j), "v"(miss));
+  return k;
+}
+
 // scalar base + 32-bit byte offset: the address costs no vector instruction (a 64-bit pointer per array costs a v_lshl_add_u64 each)
 template <class T> __device__ __forceinline__ T ld_off(const T* base, uint32_t byte_off) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off); }
 template <class T> __device__ __forceinline__ void st_off(T* base, uint32_t byte_off, T v) { *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v; }
@@ -204,7 +232,9 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
   const int n_seg = A.segments, seg_shift = __builtin_ctz((unsigned)n_seg);
   int seg = (int)blockIdx.x & (n_seg - 1), segs_left = n_seg;   // wave-uniform
   mask_t has_ray = 0, pend_valid = 0;                 // group-uniform bits: the group holds a ray / a popped entry waiting for its phase
-  uint32_t sa = sb; int ray = 0;
+  constexpr uint32_t kSaBias = (ART_EXECM & 8) ? 8u : 0u;      // the stack pointer register holds sb + 8 sp + kSaBias (bit 3: the address of the top entry itself)
+  const uint32_t se = sb + kSaBias;                            // its value for an empty stack
+  uint32_t sa = se; int ray = 0;
   int rec_i = 0;                                      // OVF: the ray's record, for k_trace_overflow
   f3 o = mk3(0, 0, 0), d = o, inv = o, noi = o;
   float best_t = 0.0f; uint32_t best_key = KEY_MISS;
@@ -259,7 +289,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         ray = __builtin_bit_cast(int, r3.y); far_found = __builtin_bit_cast(uint32_t, r3.z) != 0u;
         if (OVF) rec_i = chunk_pos + my_rank;
         held_key = KEY_MISS;
-        sa = sb; pend = 0u;                                       // entry word 0 = root node (both encodings)
+        sa = se; pend = 0u;                                       // entry word 0 = root node (both encodings)
       }
       asm volatile("" :: "v"(pf_keep));
       const mask_t got_mask = __builtin_amdgcn_ballot_w64(got);
@@ -282,11 +312,11 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       // next stack entry; an entry culled by the current hit is dropped (its group then sits this step out).  Popping two entries
       // per iteration to skip a culled one costs 12 more instructions in every iteration and saves 0.6 % of the steps: slower.
       {
-        const uint2 e1 = lds_load(sa + 8u);
-        const mask_t v1 = has_ray & ~pend_valid & vcmp(sa > sb);
+        const uint2 e1 = lds_load(sa + (8u - kSaBias));
+        const mask_t v1 = has_ray & ~pend_valid & vcmp(sa > se);
         const mask_t ok1 = v1 & vcmp(!(__builtin_bit_cast(float, e1.y) > best_t));
-        pend = sel(ok1, e1.x, pend);
-        sa = sel(v1, sa - 8u, sa);
+        if (ART_EXECM & 2) pop_masked(v1, ok1, sa, pend, e1.x);
+        else { pend = sel(ok1, e1.x, pend); sa = sel(v1, sa - 8u, sa); }
         pend_valid |= ok1;
       }
       const mask_t active = has_ray & pend_valid;
@@ -295,7 +325,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       const mask_t want_node = active & ~is_leaf;
       // leave when fewer than node_min groups still expand nodes (the others wait on a leaf, are finished, or idle)
       if (__popcll(want_node) < 8 * A.node_min) {
-        if (want_node == 0 || refill_possible || (want_leaf | (has_ray & ~active & vcmp(sa == sb))) != 0) break;
+        if (want_node == 0 || refill_possible || (want_leaf | (has_ray & ~active & vcmp(sa == se))) != 0) break;
       }
       // ---- node phase: lane j tests child j; groups not taking part read the root node and discard the result
       float tmn, tmx; uint32_t entry; mask_t valid;
@@ -303,8 +333,10 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       uint32_t diag_x[ART_DIAG_LOAD] = {};
 #endif
       if (G == 4) {
-        const uint32_t noff = sel(want_node, pend, 0u);
-        const uint4 rec = *reinterpret_cast<const uint4*>(nodes_b + (noff + jrec));       // ONE load: the quad reads the node's 64 contiguous bytes
+        const uint32_t noff = (ART_EXECM & 1) ? pend : sel(want_node, pend, 0u);
+        uint4 rec;
+        if (ART_EXECM & 1) { const u32x4 rr = load_node_masked(want_node, nodes_b, noff + jrec); rec = make_uint4(rr.x, rr.y, rr.z, rr.w); }
+        else rec = *reinterpret_cast<const uint4*>(nodes_b + (noff + jrec));              // ONE load: the quad reads the node's 64 contiguous bytes
         const uint32_t c0 = rec.x, c1 = rec.y; entry = rec.z;
         asm volatile("s_setprio 1" :: "v"(c0));           // a wave whose node has arrived goes ahead of the waves that pop, refill or test leaves (+0.7 % on C4, +3 % on C5)
         const float4 h = make_float4(__builtin_bit_cast(float, dpp_i<0x00>((int)rec.w)), __builtin_bit_cast(float, dpp_i<0x55>((int)rec.w)),
@@ -340,14 +372,16 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         valid = vcmp(cref >= 0);
       }
       const mask_t hit = (G == 4 && !STATS) ? (want_node & vcmp(tmn <= tmx)) : (want_node & valid & vcmp(tmn <= tmx));
-      const int key = (int)sel(hit, (__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j, 0x7fffffffu);
+      const int key = (ART_EXECM & 4) ? (int)key_masked(hit, __builtin_bit_cast(uint32_t, tmn), (uint32_t)j, 0x7fffffffu)
+                                      : (int)sel(hit, (__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j, 0x7fffffffu);
       const int nh = group_sum_g<G>((int)sel(hit, 1u, 0u));
       const int nh_minus_rank = (G == 4) ? quad_sub_rank(key, nh) : nh - group_rank_g<G>(key);
       const uint32_t top = sa + (uint32_t)nh * 8u;
-      const mask_t ovf = OVF ? (want_node & vcmp(top > slimit)) : 0;        // the ray moves to k_trace_overflow
-      const uint32_t dst_hit = (sa + 8u) + (uint32_t)nh_minus_rank * 8u;
-      lds_store(sel(hit & ~ovf, dst_hit, sink), make_uint2(entry, __builtin_bit_cast(uint32_t, tmn)));
-      sa = OVF ? sel(ovf, sb, top) : top;
+      const mask_t ovf = OVF ? (want_node & vcmp(top > slimit + kSaBias)) : 0;        // the ray moves to k_trace_overflow
+      const uint32_t dst_hit = (sa + (8u - kSaBias)) + (uint32_t)nh_minus_rank * 8u;
+      if (ART_EXECM & 4) lds_store_masked(hit & ~ovf, dst_hit, make_uint2(entry, __builtin_bit_cast(uint32_t, tmn)));
+      else lds_store(sel(hit & ~ovf, dst_hit, sink), make_uint2(entry, __builtin_bit_cast(uint32_t, tmn)));
+      sa = OVF ? sel(ovf, se, top) : top;
       if (OVF) {
         if (ovf != 0) {
           if (lane_of(ovf) && j == 0) A.ovf_queue[atomicAdd(A.ovf_count, 1)] = rec_i;
@@ -367,7 +401,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
     }
 
     // ---------------- retire rays whose stack ran dry
-    const mask_t done = has_ray & ~pend_valid & vcmp(sa == sb);
+    const mask_t done = has_ray & ~pend_valid & vcmp(sa == se);
     if (done != 0) {
       if (lane_of(done)) {
         // Only a hit found by THIS kernel needs storing, by the lane that holds it and as one 16-byte record: the starting bound (no hit,
@@ -415,7 +449,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         far_found = far_found || far;
         best_t = far ? next_up_pos(shm) : best_t;
         best_key = far ? KEY_MISS : best_key;
-        sa = near ? sb : sa;                               // near hit: nothing left to learn
+        sa = near ? se : sa;                               // near hit: nothing left to learn
       }
       const bool mine = accept && valid && (key == (uint32_t)win);
       held_key = mine ? key : held_key; held_u = mine ? uu : held_u; held_v = mine ? vv : held_v;
