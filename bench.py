@@ -312,10 +312,10 @@ def main():
                         "traffic": round(prof["traffic_GBps_fetch_x2"], 1) if prof else None,
                         "traffic_source": ("profiles/%s/pmc_summary.json (same source %s, scene, options)" % (PROFILE_TAG, fp["source"])) if prof else None,
                         "kernel": "k_trace_coop" if args.kernel == "coop" else "k_trace_simple",
-                        "bound_evidence": "algorithmic bytes against the HBM peak (the contract's roofline).  What limits the kernel itself is issue, not HBM: "
-                                          "its node-visit rate is the same on C3 / C4 / C5 (L2 hit rate 85 / 51 / ~100 %, 1.8 / 6.2 / <1 TB/s past L2); 16 more VALU "
-                                          "instructions per node step cost 11-13 %, one more L1-hit load per lane and step 15-20 % (profiles/r2_sensitivity.json: "
-                                          "second_look_final_kernel): VALU issue and the vector-memory instruction path are co-limiting",
+                        "bound_evidence": "frac = algorithmic bytes against the HBM peak (the contract's roofline).  What limits the kernel itself is VALU issue: "
+                                          "issue = SQ_INSTS_VALU per launch / 1024 SIMDs x the mean issue time of the kernel's own instruction mix (profiles/valu_mix.py x "
+                                          "profiles/valu_rate2.hip) / launch time; fabric_frac = bytes past L2 / 8.0 TB/s gather ceiling; both from profiles/%s/pmc_summary.json "
+                                          "when its fingerprint equals this run's.  Sensitivity builds: profiles/r2_sensitivity.json" % PROFILE_TAG,
                         "bytes_per_ray": round(bytes_per_ray, 1), "node_bytes": node_bytes, "box_tests_per_ray": round(B, 2), "tri_tests_per_ray": round(T, 2),
                         "node_visits_per_ray": round(NV, 2), "leaf_visits_per_ray": round(LV, 2),
                         "survey_8d_formula_GBps": round(rays_dev0 * (32.0 * B + 48.0 * T + 64.0) / (trace_ms * 1e-3) / 1e9, 1) if trace_ms > 0 else None,
