@@ -322,3 +322,39 @@ def test_two_level_instanced_search_matches_the_flattened_brute_force(art):
     assert (both & ~same).sum() <= n // 500 and (both & same).sum() > n // 3 and not (inst == 7).any()
     ok = both & same
     assert np.abs(t[ok] - w_t[ok]).max() <= 2.0e-5 * np.abs(w_t[ok]).max()
+
+
+def test_cost_optimal_collapse_is_a_sound_tree_with_fewer_expected_node_visits(art):
+    """Host builder option collapse = 1 (round 3): the BVH2 of the SAH build collapsed into wide nodes by the dynamic programme
+    that minimises the summed node areas instead of "open the largest child".  The tree must be as sound as the greedy one (vectorised
+    structural check), find the same hits, and its expected node visits (sum of the inner child-box areas) must not exceed the greedy
+    tree's -- it is the minimum over all collapses of the same binary tree."""
+    import bvh_check
+    from ada_ray_tracer_amd import scenes
+    n = 6000
+    mesh = scenes.random_triangles(n, 9)
+    light = [dict(shape=art.LIGHT_SPHERE, mat=4, center=(0.0, 4.5, 1.0), radius=0.5, intensity=(10.0, 10.0, 10.0), surfaceArea=3.14159)]
+    sd = art.SceneDesc([], light, scenes.cornell_materials(), [mesh], None, scenes.REFERENCE_CAMERA)
+    rng = np.random.default_rng(2)
+    o = (rng.random((3000, 3)) * [4, 4, 4] + [-2, 0.3, 0.3]).astype(np.float32)
+    d = rng.normal(size=(3000, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+
+    def area_of_inner_slots(nodes, W):
+        nd = nodes.reshape(-1, 8 * W)
+        ref = nd[:, 3:4 * W:4].view(np.int32); cnt = nd[:, 4 * W + 3:8 * W:4].view(np.int32)
+        ext = nd[:, 4 * W:].reshape(-1, W, 4)[:, :, :3].astype(np.float64) - nd[:, :4 * W].reshape(-1, W, 4)[:, :, :3].astype(np.float64)
+        area = ext[:, :, 0] * ext[:, :, 1] + ext[:, :, 1] * ext[:, :, 2] + ext[:, :, 2] * ext[:, :, 0]
+        return float(area[(ref >= 0) & (cnt == 0)].sum())
+
+    out = []
+    try:
+        for mode in (0, 1):
+            hostsim.set_bvh_param(art, "collapse", mode)
+            nodes, tris, info = hostsim.bvh(art, sd)
+            bvh_check.check_tree(nodes, tris, info["n_nodes"], info["max_stack"], info["width"], mesh["pos"], mesh["idx"])
+            hits, _ = hostsim.trace(art, sd, o, d)
+            out.append((area_of_inner_slots(nodes, info["width"]), [(h.is_hit, h.prim_index, np.float32(h.t).view(np.uint32)) for h in hits]))
+    finally:
+        hostsim.set_bvh_param(art, "collapse", 0)
+    assert out[0][1] == out[1][1]                                   # the search result cannot depend on the tree
+    assert out[1][0] <= out[0][0] * (1.0 + 1e-6), (out[0][0], out[1][0])
