@@ -699,14 +699,19 @@ __global__ __launch_bounds__(256) void k_shade(const DevFrame F, const DevScene 
 // pass 1 decides who survives (item_survives: flags, hit key, material type), one exclusive scan numbers them in item order, ONE global
 // atomic reserves the chunk's range of the output set; pass 2 shades and stores at the reserved positions.
 // ------------------------------------------------------------------------------------------------
-constexpr int kShadeChunk = 4096, kShadePerThread = kShadeChunk / 256;
+// items per workgroup = 256 x kShadePerThread, one global atomic per workgroup.  Rounds 1-2 used 16 per thread (a single hot word serves
+// ~88 atomics / us); measured in round 3 with the fused stage: 4 per thread is faster at every size -- a thread's items one after the other
+// are its critical path (C2, 4 M paths per step: 3.87 -> 2.03 ms per step; C3 +2.8 %, C5 +2.9 %, C4 +0.6 %), and 130 k atomics per launch of
+// the largest batch still spread over 6 ms.
+constexpr int kShadePerThread = 4;
 
+template <int PER>
 // 6 waves per SIMD (80 VGPRs, 48 bytes of scratch per lane): the stage is bound by the latency of its dependent gathers (hit -> triangle
 // shading record -> material), not by issue or bandwidth; left to itself the compiler takes 111 VGPRs = 4 waves (6.6 -> 6.2 ms per launch on C4)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_shade_compact(const DevFrame F, const DevScene S, const DevPaths Qi, const DevPaths Qo, int bounce,
                                                        const int* __restrict__ n_in_ptr, int* __restrict__ n_out_ptr, uint32_t* __restrict__ slot_out,
                                                        unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b) {
-  __shared__ int s_cnt[kShadePerThread * 4];      // survivors per (round k, wave)
+  __shared__ int s_cnt[PER * 4];      // survivors per (round k, wave)
   __shared__ int s_base, s_rays;
   // record mode: a wave's trace records of one round, [quarter][record] (+1: four consecutive records' quarters fall into four banks)
   constexpr int kStagePitch = 64 + 1;
@@ -714,6 +719,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   __shared__ DevSphere s_sph[kAnalyticLdsSpheres];      // the scene's spheres and lights, fetched once per workgroup (emit_ray tests every ray against them)
   __shared__ DevLight s_lgt[kAnalyticLdsLights];
   const int n_in = n_in_ptr ? *n_in_ptr : Qi.P;
+  constexpr int kShadeChunk = 256 * PER;
   const int c0 = blockIdx.x * kShadeChunk;
   if (c0 >= n_in) return;                                // the grid covers Qi.P items; the work set has shrunk to n_in
   // (the material table stays in global memory: a 40-byte per-lane-indexed record out of LDS measured 7 % slower than the cached global read)
@@ -728,7 +734,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   if (threadIdx.x == 0) s_rays = 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t keep_bits = 0;
-  for (int k = 0; k < kShadePerThread; ++k) {
+  for (int k = 0; k < PER; ++k) {
     const int w = c0 + k * 256 + threadIdx.x;
     const bool keep = (w < n_in) && item_survives(F, S, Qi, w, bounce, tables);
     keep_bits |= keep ? (1u << k) : 0u;
@@ -738,13 +744,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   __syncthreads();
   if (threadIdx.x == 0) {
     int total = 0;
-    for (int i = 0; i < kShadePerThread * 4; ++i) { const int c = s_cnt[i]; s_cnt[i] = total; total += c; }
+    for (int i = 0; i < PER * 4; ++i) { const int c = s_cnt[i]; s_cnt[i] = total; total += c; }
     s_base = total ? atomicAdd(n_out_ptr, total) : 0;
   }
   __syncthreads();
   const int base = s_base;
   int n_rays = 0;
-  for (int k = 0; k < kShadePerThread; ++k) {
+  for (int k = 0; k < PER; ++k) {
     const int w = c0 + k * 256 + threadIdx.x;
     const bool keep = (keep_bits >> k) & 1u;
     const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
@@ -875,7 +881,7 @@ void launch_shade(hipStream_t st, const DevFrame& F, const DevScene& S, const De
 }
 void launch_shade_compact(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Qi, const DevPaths& Qo, int bounce,
                           const int* n_in, int* n_out, uint32_t* slot_out, unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b) {
-  hipLaunchKernelGGL(k_shade_compact, dim3((Qi.P + kShadeChunk - 1) / kShadeChunk), dim3(256), 0, st, F, S, Qi, Qo, bounce, n_in, n_out, slot_out, lost, rays_a, rays_b);
+  hipLaunchKernelGGL(k_shade_compact<kShadePerThread>, dim3((Qi.P + 256 * kShadePerThread - 1) / (256 * kShadePerThread)), dim3(256), 0, st, F, S, Qi, Qo, bounce, n_in, n_out, slot_out, lost, rays_a, rays_b);
 }
 void launch_bump(hipStream_t st, unsigned long long* a, unsigned long long* b, unsigned long long n) { hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, st, a, b, n); }
 void launch_resolve_last(hipStream_t st, const DevPaths& Q, const int* n, int last_level) {
