@@ -703,7 +703,10 @@ __global__ __launch_bounds__(256) void k_shade(const DevFrame F, const DevScene 
 // ~88 atomics / us); measured in round 3 with the fused stage: 4 per thread is faster at every size -- a thread's items one after the other
 // are its critical path (C2, 4 M paths per step: 3.87 -> 2.03 ms per step; C3 +2.8 %, C5 +2.9 %, C4 +0.6 %), and 130 k atomics per launch of
 // the largest batch still spread over 6 ms.
-constexpr int kShadePerThread = 4;
+#ifndef ART_SHADE_PER
+#define ART_SHADE_PER 4
+#endif
+constexpr int kShadePerThread = ART_SHADE_PER;
 
 template <int PER>
 // 6 waves per SIMD (80 VGPRs, 48 bytes of scratch per lane): the stage is bound by the latency of its dependent gathers (hit -> triangle
