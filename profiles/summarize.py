@@ -82,7 +82,7 @@ def main(tag, name="c4"):
     # the other kernels of a step: bytes past L2 and achieved TB/s (the stages are memory-bound; the HBM roofline is theirs)
     others = {}
     for k, o in out.items():
-        if "k_trace_coop" in k or "FETCH_SIZE" not in o or "dispatches_write" not in o or not k.startswith("art::"):
+        if "k_trace_coop" in k or "FETCH_SIZE" not in o or "dispatches_write" not in o or "art::" not in k or "anonymous" in k or "rocprim" in k or k.replace("void ", "").replace("art::", "").strip() == "":
             continue
         n = o["dispatches_fetch"]
         fb = 2.0 * o["FETCH_SIZE"] * 1024.0 / n; wb = o["WRITE_SIZE"] * 1024.0 / o["dispatches_write"]; ns = o["total_ns_fetch"] / n
@@ -94,7 +94,7 @@ def main(tag, name="c4"):
             e["l2_hit_rate"] = o["TCC_HIT_sum"] / max(1.0, o["TCC_HIT_sum"] + o["TCC_MISS_sum"])
         if "TA_BUSY_avr" in o and "GRBM_GUI_ACTIVE" in o:
             e["ta_busy_avg"] = o["TA_BUSY_avr"] / (o["GRBM_GUI_ACTIVE"] / 8.0)
-        others[k.replace("art::", "")] = e
+        others[k.replace("void ", "").replace("art::", "")] = e
     out["stage_kernels"] = others
     b = os.path.join(SRC, "bench_under_rocprof.json")
     if os.path.exists(b):
