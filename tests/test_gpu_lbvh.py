@@ -245,7 +245,7 @@ def _tree_signature(nodes, tris, info):
 
 
 @pytest.mark.parametrize("width", [4, 8])
-@pytest.mark.parametrize("scene", ["soup-9", "soup-3000", "soup-100k", "mixed-20k", "grid-128"])
+@pytest.mark.parametrize("scene", ["soup-9", "soup-2047", "soup-2048", "soup-2049", "soup-3000", "soup-4097", "soup-6145", "soup-100k", "mixed-20k", "grid-128"])
 def test_gpu_sah_builder_builds_the_host_builders_tree(art, backend, scene, width):
     """bvh_builder = 3 restates art_bvh.cpp breadth-first on the GPU.  Every split decision depends only on minima, maxima and counts over
     a node's SET of references, so the binary tree -- hence the wide tree, slot for slot -- must be the host's: same boxes (bits),
@@ -253,7 +253,7 @@ def test_gpu_sah_builder_builds_the_host_builders_tree(art, backend, scene, widt
     triangle records differ."""
     from ada_ray_tracer_amd import scenes
     if scene.startswith("soup"):
-        sd = scenes.synthetic_scene({"soup-9": 9, "soup-3000": 3000, "soup-100k": 100000}[scene], 3)
+        sd = scenes.synthetic_scene(int(scene.split("-")[1].replace("k", "000")), 3)     # 2047 .. 6145: around the builder's 2048-reference chunks
     elif scene == "mixed-20k":
         sd = scenes.mixed_scene(20000, 5)
     else:
