@@ -150,3 +150,23 @@ def test_batch_is_halved_when_hbm_is_short(art, backend):
         hip.hipFree(hog)
     assert spp == 64 and np.array_equal(bits(img), bits(ref))
     assert after.value < (20 << 30)                                     # the render did take a batch's worth of what was left
+
+
+def test_c4_full_frame_render_is_repeatable_and_loses_no_path(art, backend):
+    """The whole C4 frame (1 M triangles, 1920x1080, 64 spp = one 133 M-path batch) twice from a fresh viewport: the accum buffers are the same
+    bits, the ray counts equal, and the compacted work sets' self-check stays 0.  Round 3 moved the trace records into the stages (a wave
+    stages and copies its records cooperatively) and three selects of the trace kernel's node step under explicit EXEC masks: a record
+    copied before it was staged, or a lane mask off by one, would show here as a different image, ray count or a lost path."""
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.synthetic_scene(1000000, 4)
+    backend.upload_scene(sd)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 16, seed=1)
+    out = []
+    for _ in range(2):
+        backend.resize(1920, 1080)
+        accum, _, spp = backend.render_pass(p, 0)
+        st = backend.stats()
+        out.append((bits(accum).copy(), st.rays, st.lost_paths, spp))
+    assert out[0][3] == out[1][3] == 64 and out[0][2] == out[1][2] == 0
+    assert out[0][1] == out[1][1] and np.array_equal(out[0][0], out[1][0])
+    assert 6.5 < out[0][1] / (1920 * 1080 * 64) < 8.0          # 7.22 rays per sample on this scene
