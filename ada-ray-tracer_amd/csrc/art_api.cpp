@@ -207,10 +207,12 @@ static int download_from(const float* acc_dev, float* accum_host, uint32_t* scre
 // and writes the survivors densely into the other (k_shade_compact); cold state (fold stack, terminal value, per-sample radiance, final
 // flags) is indexed by slot.  Hot state per item, record layout (round 3, the cooperative schedule): the trace records of its two rays
 // (2 x 64 B; the next stage reads the extension ray from there), their hit records (2 x 16 B), prev pdf, flags, shadow epsilon, pending
-// explicit colour, item -> slot map, and the extension ray once more as six SoA words for the next stage: 53 words.  Plain layout (one-ray-per-lane schedule, debug pass): rays as SoA arrays, 29 words.
+// explicit colour, item -> slot map, and the extension ray once more as six SoA words for the next stage: 21 words per bank + 32 words of
+// records in one array shared by the banks.  Plain layout (one-ray-per-lane schedule, debug pass): rays as SoA arrays, 29 words.
 constexpr size_t kRecSlack = 4096;       // records past the last one the trace kernel's chunk prefetch may touch
-static size_t hot_floats(size_t P, bool rec) { return (rec ? (32 + 6 + 8 + 7) : (14 + 8 + 7)) * P; }
-static size_t path_floats(size_t P, int depth, bool rec) { return 2 * hot_floats(P, rec) + (6 * (size_t)depth + 3 + 3 + 1) * P + (rec ? 2 * (kRecSlack * 16 + 16) : 0) + 64; }
+static size_t hot_floats(size_t P, bool rec) { return (rec ? (6 + 8 + 7) : (14 + 8 + 7)) * P; }
+// (the trace records are not double-banked: a bank's records are dead once its rays are traced, and the next stage reads none of them)
+static size_t path_floats(size_t P, int depth, bool rec) { return 2 * hot_floats(P, rec) + (rec ? 32 * P + kRecSlack * 16 + 16 : 0) + (6 * (size_t)depth + 3 + 3 + 1) * P + 64; }
 
 static int ensure_paths(size_t P, int depth, bool rec) { return ensure(g_ctx.b_paths, path_floats(P, depth, rec) * 4 + 256); }
 
@@ -221,11 +223,12 @@ static void carve(DevPaths q[2], int P, int depth, bool rec) {
   float* f = f0; const size_t p = (size_t)P;
   auto take = [&](size_t n) { float* r = f; f += n; return r; };
   auto align = [&](size_t floats) { f += (floats - ((size_t)(f - f0) & (floats - 1))) & (floats - 1); };
+  Rec4* records = nullptr;
+  if (rec) { align(16); records = (Rec4*)take(32 * p + kRecSlack * 16); }       // 64-byte records, ONE array for both banks
   for (int k = 0; k < 2; ++k) {
     DevPaths& b = q[k];
     if (rec) {
-      align(16);                                                                // 64-byte records
-      b.rec = (Rec4*)take(32 * p + kRecSlack * 16);
+      b.rec = records;
       b.ray_ox = take(p); b.ray_oy = take(p); b.ray_oz = take(p); b.ray_dx = take(p); b.ray_dy = take(p); b.ray_dz = take(p);   // the extension ray, for the next stage
       b.ray_tfar = nullptr;
     } else {

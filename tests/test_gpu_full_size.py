@@ -112,7 +112,7 @@ def test_c4_full_frame_is_independent_of_shards_batches_and_builder(art, backend
 
 
 def test_batch_is_halved_when_hbm_is_short(art, backend):
-    """A 64-spp 1080p pass wants one batch of 133 M paths: 79 GB of path state (596 B per slot at depth 8, the trace records of both rays of
+    """A 64-spp 1080p pass wants one batch of 133 M paths: 69 GB of path state (516 B per slot at depth 8, the trace records of both rays of
     an item included since round 3).  With most of the HBM taken by someone else the batch is halved until the buffer fits, and the image
     is the same bits (the RNG is keyed by pixel, sample, bounce).  The backend is re-initialised first: its buffers only ever grow, and
     what an earlier test left allocated would decide what fits."""
@@ -136,7 +136,7 @@ def test_batch_is_halved_when_hbm_is_short(art, backend):
         backend.set_option("batch_paths", 128 << 20)
     free, total = C.c_size_t(0), C.c_size_t(0)
     assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
-    keep = 30 << 30                 # 30 GB left (+ the 5 GB of the reference render's buffer): 79 GB cannot fit, 39.6 GB cannot, 19.8 GB can
+    keep = 24 << 30                 # 24 GB left (+ the 4 GB of the reference render's buffer): 68.6 GB cannot fit, 34.3 GB cannot, 17.2 GB can
     if free.value <= keep + (8 << 30):
         pytest.skip("not enough free HBM to take away")
     hog = C.c_void_p(None)
