@@ -80,6 +80,23 @@ def grid_mesh(m, y0=1.0, tilt=0.35):
     return dict(mode=MESH_CLOSEST, pos=pos, nrm=nrm.astype(F), idx=idx, matid=matid)
 
 
+def torus_mesh(nu=256, nv=96, R=1.3, r=0.45, centre=(0.0, 2.2, 2.4)):
+    """A closed, connected surface (2 nu nv triangles of very different sizes: small on the inside of the ring, large outside), tilted in
+    the Cornell box -- the structured counterpart of the random soups: shared vertices, coplanar neighbours, slivers at the seams."""
+    u = np.linspace(0.0, 2.0 * np.pi, nu, endpoint=False); v = np.linspace(0.0, 2.0 * np.pi, nv, endpoint=False)
+    U, V = np.meshgrid(u, v, indexing="ij")
+    x = (R + r * np.cos(V)) * np.cos(U); y = r * np.sin(V); z = (R + r * np.cos(V)) * np.sin(U)
+    c, s_ = np.cos(0.6), np.sin(0.6)
+    pos = np.stack([x, c * y - s_ * z, s_ * y + c * z], -1).reshape(-1, 3) + np.asarray(centre)
+    n = np.stack([np.cos(V) * np.cos(U), np.sin(V), np.cos(V) * np.sin(U)], -1).reshape(-1, 3)
+    nrm = np.stack([n[:, 0], c * n[:, 1] - s_ * n[:, 2], s_ * n[:, 1] + c * n[:, 2]], -1)
+    i, j = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    a_ = (i * nv + j).ravel(); b_ = (((i + 1) % nu) * nv + j).ravel(); c_ = (i * nv + (j + 1) % nv).ravel(); d_ = (((i + 1) % nu) * nv + (j + 1) % nv).ravel()
+    idx = np.stack([np.stack([a_, c_, b_], 1), np.stack([b_, c_, d_], 1)], 1).reshape(-1, 3).astype(np.int32)      # outward-facing
+    matid = (1 + (np.arange(idx.shape[0]) % 3)).astype(np.int32)
+    return dict(mode=MESH_CLOSEST, pos=pos.astype(F), nrm=nrm.astype(F), idx=idx, matid=matid)
+
+
 def rect_light(cx, mat, intensity=(20.0, 20.0, 20.0), y=4.98, half_x=0.25, cz=2.25, half_z=0.33):
     bmin = (F(cx - half_x), F(y), F(cz - half_z)); bmax = (F(cx + half_x), F(y), F(cz + half_z))
     area = F(F(bmax[0] - bmin[0]) * F(bmax[2] - bmin[2]))
