@@ -156,3 +156,30 @@ def test_node_min_and_refill_gate_cannot_stall_a_wave(art, backend):
         backend.set_option("bvh_width", 4)
         backend.set_option("node_min", 4)
         backend.set_option("refill_min", 2)
+
+
+def test_shadow_rays_as_full_closest_hit_searches_give_the_same_image(art, backend):
+    """Option shadow_anyhit = 0: shadow rays carry no 10*eps in their trace records and run as full closest-hit searches
+    (Compute_Shadow's own formulation, ray_tracer.adb:100-132) instead of under the visibility rule.  Same decision, so the same image and
+    ray count -- through the record-writing stages, both widths, and a capped LDS stack (k_trace_overflow restarts from the record)."""
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.mixed_scene(4000, 5)
+    osc = conv.OracleScene(sd)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 1, seed=9)
+    ref, _, cnt = orc.render(osc.scene, orc.make_params(48, 40, orc.PT_MIS, True, 8, 1, seed=9))
+    try:
+        for width in (4, 8):
+            backend.set_option("bvh_width", width)
+            backend.upload_scene(sd)
+            for anyhit, cap in [(1, 0), (0, 0), (0, 5), (1, 5)]:
+                backend.set_option("shadow_anyhit", anyhit)
+                backend.set_option("lds_stack_cap", cap)
+                backend.resize(48, 40)
+                r0 = backend.stats().rays
+                img, _, _ = backend.render_pass(p, 0)
+                assert np.array_equal(bits(img), bits(ref)), (width, anyhit, cap)
+                assert backend.stats().rays - r0 == cnt.rays
+    finally:
+        backend.set_option("bvh_width", 4)
+        backend.set_option("shadow_anyhit", 1)
+        backend.set_option("lds_stack_cap", 0)
