@@ -245,15 +245,17 @@ def _tree_signature(nodes, tris, info):
 
 
 @pytest.mark.parametrize("width", [4, 8])
-@pytest.mark.parametrize("scene", ["soup-9", "soup-2047", "soup-2048", "soup-2049", "soup-3000", "soup-4097", "soup-6145", "soup-100k", "mixed-20k", "grid-128", "torus-49k"])
+@pytest.mark.parametrize("scene", ["soup-9", "soup-2047", "soup-2048", "soup-2049", "soup-3000", "soup-4097", "soup-6145", "soup-100k", "soup-1000k", "mixed-20k", "grid-128", "torus-49k"])
 def test_gpu_sah_builder_builds_the_host_builders_tree(art, backend, scene, width):
     """bvh_builder = 3 restates art_bvh.cpp breadth-first on the GPU.  Every split decision depends only on minima, maxima and counts over
     a node's SET of references, so the binary tree -- hence the wide tree, slot for slot -- must be the host's: same boxes (bits),
     same leaves, same slot order, same node count and stack bound; only the node numbering (breadth-first) and the order of the
     triangle records differ."""
     from ada_ray_tracer_amd import scenes
+    if scene == "soup-1000k" and width == 8:
+        pytest.skip("the C4 mesh is compared at the default width")
     if scene.startswith("soup"):
-        sd = scenes.synthetic_scene(int(scene.split("-")[1].replace("k", "000")), 3)     # 2047 .. 6145: around the builder's 2048-reference chunks
+        sd = scenes.synthetic_scene(int(scene.split("-")[1].replace("k", "000")), 4 if scene == "soup-1000k" else 3)     # 2047 .. 6145: around the builder's 2048-reference chunks
     elif scene == "mixed-20k":
         sd = scenes.mixed_scene(20000, 5)
     else:
