@@ -166,8 +166,12 @@ __device__ __forceinline__ void lds_store(uint32_t addr, uint2 v) {       // two
 #define ART_EXECM 13
 #endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Contract of the four helpers below: they are entered with ALL 64 lanes enabled and leave EXEC = -1.  They are `volatile`
+// (never duplicated, hoisted or sunk across each other; EXEC cannot be named as a clobber -- the compiler rejects reserved registers
+// there).  A caller that wrapped them in a per-lane branch would switch masked-off lanes on: k_trace_coop checks its side of the
+// contract in builds with -DART_CHECK_EXEC (EXEC == -1 at the head of every node step, else the kernel traps).
 __device__ __forceinline__ void pop_masked(mask_t v1, mask_t ok1, uint32_t& sa, uint32_t& pend, uint32_t entry) {     // sa -= 8 in v1, pend = entry in ok1
-  asm("s_mov_b64 exec, %2\n\tv_add_u32 %0, -8, %0\n\ts_mov_b64 exec, %3\n\tv_mov_b32 %1, %4\n\ts_mov_b64 exec, -1" : "+v"(sa), "+v"(pend) : "s"(v1), "s"(ok1), "v"(entry));
+  asm volatile("s_mov_b64 exec, %2\n\tv_add_u32 %0, -8, %0\n\ts_mov_b64 exec, %3\n\tv_mov_b32 %1, %4\n\ts_mov_b64 exec, -1" : "+v"(sa), "+v"(pend) : "s"(v1), "s"(ok1), "v"(entry));
 }
 __device__ __forceinline__ u32x4 load_node_masked(mask_t m, const char* base, uint32_t off) {                        // lanes outside m keep garbage: their results are masked
   u32x4 r;
@@ -179,7 +183,7 @@ __device__ __forceinline__ void lds_store_masked(mask_t m, uint32_t addr, uint2 
 }
 __device__ __forceinline__ uint32_t key_masked(mask_t hit, uint32_t tmn_bits, uint32_t j, uint32_t miss) {           // hit ? (tmn & ~7) | j : miss
   uint32_t k;
-  asm("v_mov_b32 %0, %4\n\ts_mov_b64 exec, %1\n\tv_and_or_b32 %0, %2, -8, %3\n\ts_mov_b64 exec, -1" : "=&v"(k) : "s"(hit), "v"(tmn_bits), "v"(j), "v"(miss));
+  asm volatile("v_mov_b32 %0, %4\n\ts_mov_b64 exec, %1\n\tv_and_or_b32 %0, %2, -8, %3\n\ts_mov_b64 exec, -1" : "=&v"(k) : "s"(hit), "v"(tmn_bits), "v"(j), "v"(miss));
   return k;
 }
 
@@ -328,6 +332,9 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         if (want_node == 0 || refill_possible || (want_leaf | (has_ray & ~active & vcmp(sa == se))) != 0) break;
       }
       // ---- node phase: lane j tests child j; groups not taking part read the root node and discard the result
+#if defined(ART_CHECK_EXEC)
+      if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap();      // the exec-masked helpers restore EXEC to -1: they must be entered with -1
+#endif
       float tmn, tmx; uint32_t entry; mask_t valid;
 #if defined(ART_DIAG_LOAD)
       uint32_t diag_x[ART_DIAG_LOAD] = {};
@@ -350,8 +357,8 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         const f3 pf = mk3(__builtin_fmaf((float)(fb & 255u), h.w, h.x), __builtin_fmaf((float)((fb >> 8) & 255u), h.w, h.y), __builtin_fmaf((float)((fb >> 16) & 255u), h.w, h.z));
         slab_near_far(mk3(__builtin_fmaf(pn.x, inv.x, noi.x), __builtin_fmaf(pn.y, inv.y, noi.y), __builtin_fmaf(pn.z, inv.z, noi.z)),
                       mk3(__builtin_fmaf(pf.x, inv.x, noi.x), __builtin_fmaf(pf.y, inv.y, noi.y), __builtin_fmaf(pf.z, inv.z, noi.z)), best_t, tmn, tmx);
-        valid = ~0ull;
-        if (STATS) valid = vcmp(entry != kQEntryEmpty);
+        // (no validity mask on the walk itself, timed or counted; `valid` only feeds the box-test COUNT of the counting variant below)
+        valid = STATS ? vcmp(entry != kQEntryEmpty) : ~0ull;
 #if defined(ART_DIAG_VALU)          // diagnostic builds only (profiles/diag.sh): n more dependent VALU instructions per node step
         { float x = tmn;
 #pragma unroll
@@ -371,7 +378,9 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         slab_interval(mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), inv, noi, best_t, tmn, tmx);
         valid = vcmp(cref >= 0);
       }
-      const mask_t hit = (G == 4 && !STATS) ? (want_node & vcmp(tmn <= tmx)) : (want_node & valid & vcmp(tmn <= tmx));
+      // the counting variant (STATS) walks with exactly the timed kernel's predicate: at G = 4 an empty slot is never masked out, it
+      // simply cannot pass the interval test (and if a degenerate node ever let it, both variants would pop the same zero-triangle leaf)
+      const mask_t hit = (G == 4) ? (want_node & vcmp(tmn <= tmx)) : (want_node & valid & vcmp(tmn <= tmx));
       const int key = (ART_EXECM & 4) ? (int)key_masked(hit, __builtin_bit_cast(uint32_t, tmn), (uint32_t)j, 0x7fffffffu)
                                       : (int)sel(hit, (__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j, 0x7fffffffu);
       const int nh = group_sum_g<G>((int)sel(hit, 1u, 0u));

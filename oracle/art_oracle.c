@@ -960,8 +960,23 @@ void orc_sample_radiance(const orc_scene* scn, const orc_params* prm, int32_t x,
   out_rgb[0] = c.x; out_rgb[1] = c.y; out_rgb[2] = c.z;
 }
 
-/* Render_Pass = Threads_Num tasks x DoPass (integrators.adb:25-71), accumulated in task order
- * t = 0..vthreads-1 (the reference's order under GNAT.Task_Lock is scheduling dependent).       */
+/* One pixel of Render_Pass: Threads_Num tasks x DoPass (integrators.adb:25-71), accumulated in task order
+ * t = 0..vthreads-1 (the reference's order under GNAT.Task_Lock is scheduling dependent).  `a` = colBuff(x,y). */
+static void pass_pixel(const orc_scene* scn, const orc_params* prm, int x, int y, uint32_t base, float* a, local_counters* lc) {
+  for (int t = 0; t < prm->vthreads; ++t) {
+    f3 color;
+    if (prm->aa_on) {
+      color = ld3(prm->background);                                               /* integrators.adb:42 */
+      for (int i = 0; i < 4; ++i)
+        color = add(color, camera_sample(scn, prm, x, y, base + (uint32_t)(t * 4 + i), lc)); /* :47 */
+    } else {
+      color = camera_sample(scn, prm, x, y, base + (uint32_t)t, lc);              /* :60 */
+    }
+    f3 cb = add(color, ld3(a));                                                   /* :51 / :63 */
+    a[0] = cb.x; a[1] = cb.y; a[2] = cb.z;
+  }
+}
+
 void orc_render_pass(const orc_scene* scn, const orc_params* prm, float* accum, int32_t* spp, orc_counters* cnt) {
   const int W = prm->width, H = prm->height;
   const int per = prm->aa_on ? 4 : 1;
@@ -977,24 +992,30 @@ void orc_render_pass(const orc_scene* scn, const orc_params* prm, float* accum, 
     const int64_t p1 = (blk + 1) * 64 < npx ? (blk + 1) * 64 : npx;
     for (int64_t pi = blk * 64; pi < p1; ++pi) {
       const int x = (int)(pi % W), y = (int)(pi / W);
-      float* a = accum + 3 * ((size_t)y * W + x);
-      for (int t = 0; t < prm->vthreads; ++t) {
-        f3 color;
-        if (prm->aa_on) {
-          color = ld3(prm->background);                                               /* integrators.adb:42 */
-          for (int i = 0; i < 4; ++i)
-            color = add(color, camera_sample(scn, prm, x, y, base + (uint32_t)(t * 4 + i), &lc)); /* :47 */
-        } else {
-          color = camera_sample(scn, prm, x, y, base + (uint32_t)t, &lc);            /* :60 */
-        }
-        f3 cb = add(color, ld3(a));                                                   /* :51 / :63 */
-        a[0] = cb.x; a[1] = cb.y; a[2] = cb.z;
-      }
+      pass_pixel(scn, prm, x, y, base, accum + 3 * ((size_t)y * W + x), &lc);
     }
     rays += lc.rays; tris += lc.tri_tests;
   }
   *spp += prm->vthreads * per;                                                        /* ray_tracer.adb:168-175 */
   if (cnt) { cnt->rays += rays; cnt->tri_tests += tris; cnt->samples += (uint64_t)W * H * prm->vthreads * per; }
+}
+
+/* The same pass for a LIST of pixels of the frame (tests: a BASELINE configuration at its full frame size and sample count is out of
+ * reach as a whole frame, a few hundred of its pixels are not): accum[3k..] = colBuff(xs[k], ys[k]), cumulative like the frame's.    */
+void orc_render_pixels(const orc_scene* scn, const orc_params* prm, const int32_t* xs, const int32_t* ys, int64_t n, float* accum, int32_t spp0,
+                       orc_counters* cnt) {
+  const int per = prm->aa_on ? 4 : 1;
+  uint64_t rays = 0, tris = 0;
+#ifdef _OPENMP
+  if (prm->nthreads > 0) omp_set_num_threads(prm->nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, tris)
+  for (int64_t k = 0; k < n; ++k) {
+    local_counters lc = { 0, 0 };
+    pass_pixel(scn, prm, xs[k], ys[k], (uint32_t)spp0, accum + 3 * k, &lc);
+    rays += lc.rays; tris += lc.tri_tests;
+  }
+  if (cnt) { cnt->rays += rays; cnt->tri_tests += tris; cnt->samples += (uint64_t)n * prm->vthreads * per; }
 }
 
 /* The same pass organised the way the reference runs it (ray_tracer.adb:142-194, 264-277): Threads_Num tasks, each renders the WHOLE

@@ -156,6 +156,9 @@ void orc_build_cornell(orc_cornell_storage* st, const orc_mesh* pyramid, int use
  * ROW-MAJOR (y*width+x), cumulative across passes; *spp is advanced like g_spp.
  * sample index of (vthread t, aa i) = *spp_before + t*(aa?4:1) + i.                              */
 void orc_render_pass(const orc_scene* scn, const orc_params* prm, float* accum, int32_t* spp, orc_counters* cnt);
+/* the same pass for a list of pixels: accum[3k..3k+2] = colBuff(xs[k], ys[k]) (cumulative), samples spp0 .. spp0 + vthreads*per - 1 */
+void orc_render_pixels(const orc_scene* scn, const orc_params* prm, const int32_t* xs, const int32_t* ys, int64_t n, float* accum, int32_t spp0,
+                       orc_counters* cnt);
 
 /* Radiance of one camera sample (for debugging mismatches). */
 /* same result, organised as the reference's task pool: vthreads tasks, each a whole-frame DoPass into a private frame (returns 0 on success) */

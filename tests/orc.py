@@ -115,6 +115,7 @@ def lib():
     L.orc_render_pass.argtypes = [C.POINTER(Scene), C.POINTER(Params), f32p, i32p, C.POINTER(Counters)]
     L.orc_render_pass_tasks.argtypes = [C.POINTER(Scene), C.POINTER(Params), f32p, i32p, C.POINTER(Counters)]
     L.orc_render_pass_tasks.restype = C.c_int
+    L.orc_render_pixels.argtypes = [C.POINTER(Scene), C.POINTER(Params), i32p, i32p, C.c_int64, f32p, C.c_int32, C.POINTER(Counters)]
     L.orc_sample_radiance.argtypes = [C.POINTER(Scene), C.POINTER(Params), C.c_int32, C.c_int32, C.c_uint32, f32p]
     L.orc_debug_pass.argtypes = [C.POINTER(Scene), C.POINTER(Params), f32p, i32p, i32p, i32p]
     L.orc_resolve.argtypes = [f32p, C.c_int32, C.c_int32, C.c_int32, u32p]
@@ -193,6 +194,16 @@ def render(scene, params, passes=1, accum=None, spp0=0):
     for _ in range(passes):
         L.orc_render_pass(C.byref(scene), C.byref(params), fp(accum), C.byref(spp), C.byref(cnt))
     return accum, spp.value, cnt
+
+
+def render_pixels(scene, params, xs, ys, spp0=0, accum=None):
+    """One Render_Pass for the listed pixels only (orc_render_pixels: the per-pixel body of orc_render_pass).  Returns (accum[n,3], Counters)."""
+    xs = np.ascontiguousarray(xs, np.int32); ys = np.ascontiguousarray(ys, np.int32)
+    if accum is None:
+        accum = np.zeros((len(xs), 3), np.float32)
+    cnt = Counters()
+    lib().orc_render_pixels(C.byref(scene), C.byref(params), ip(xs), ip(ys), len(xs), fp(accum), spp0, C.byref(cnt))
+    return accum, cnt
 
 
 def render_tasks(scene, params, accum=None, spp0=0):

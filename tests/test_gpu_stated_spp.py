@@ -1,0 +1,113 @@
+"""Every BASELINE configuration against the oracle AT ITS STATED SAMPLE COUNT (BASELINE.json configs: C2 16 spp, C3 64, C4 256, C5 1024),
+at its full frame size, through the C ABI.
+
+The other full-size tests compare 4 spp (Threads_Num = 1) and the small-frame parity tests stop at 24 spp.  What only these counts
+exercise: sample indices up to 1023 in the RNG key, the sample-chunk offsets of a pass that the backend cuts into several batches
+(a 256-spp 1080p pass is four 64-spp batches: sample_base = spp + 64 / 128 / 192, art_api.cpp render_pass_one), and the accumulation
+order over 16 / 64 / 256 virtual tasks (integrators.adb:42-52: color = (((bg + s0) + s1) + s2) + s3 per task, colBuff = color + colBuff
+in task order).  C2 is small enough for the oracle to render the whole frame; for C3 / C4 / C5 the oracle renders a sample of pixels
+spread over the frame with the per-pixel body of its own Render_Pass (orc_render_pixels), its mesh search walking the exported tree
+(checked on its own against the brute-force scan in tests/test_gpu_parity.py).
+"""
+import numpy as np
+import pytest
+
+import conv
+import orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1.0e-4   # BASELINE.json north_star: per-channel radiance within 1e-4 of the CPU reference at equal spp
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_c2_whole_frame_at_16_spp(art, backend):
+    """configs[1]: the internal Cornell scene with data/pyramid2.vsgf, 512x512, 16 spp = four Render_Pass calls with Threads_Num = 1 and
+    2x2 anti-aliasing, PT_MIS depth 8 -- the whole frame, every pixel, bit for bit; then the same 16 spp as ONE pass of four
+    virtual tasks (the same sum in the same order)."""
+    from ada_ray_tracer_amd import scenes
+    W = H = 512
+    sd = scenes.reference_scene()
+    osc = conv.OracleScene(sd)
+    backend.upload_scene(sd)
+    backend.resize(W, H)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 1, seed=1)
+    spp = 0
+    for _ in range(4):
+        accum, screen, spp = backend.render_pass(p, spp, True, True)
+    assert spp == 16
+    ref, rspp, cnt = orc.render(osc.scene, orc.make_params(W, H, orc.PT_MIS, True, 8, 1, seed=1), passes=4)
+    assert rspp == 16 and np.isfinite(ref).all()
+    assert np.abs(accum - ref).max() / spp <= TOL
+    assert np.array_equal(bits(accum), bits(ref))
+    assert np.array_equal(screen, orc.resolve(ref, 16))                     # ... and the LDR frame Render_Pass hands to SaveBMP
+    backend.resize(W, H)
+    once, _, spp1 = backend.render_pass(art.Backend.pass_params(art.PT_MIS, True, 8, 4, seed=1), 0)
+    assert spp1 == 16 and np.array_equal(bits(once), bits(ref))
+
+
+CONFIGS = {
+    # name: (scene builder, width, height, Threads_Num (spp / 4), sampled pixels)
+    "c3": (lambda sc: sc.synthetic_scene(100000, 3), 1024, 1024, 16, 2000),
+    "c4": (lambda sc: sc.synthetic_scene(1000000, 4), 1920, 1080, 64, 1000),
+    "c5": (lambda sc: sc.mixed_scene(20000, 5), 4096, 4096, 256, 400),
+}
+
+
+@pytest.mark.parametrize("config", ["c3", "c4", "c5"])
+def test_full_frame_at_the_stated_sample_count(art, backend, config):
+    """C3 1024x1024 x 64 spp, C4 1920x1080 x 256 spp, C5 4096x4096 x 1024 spp: ONE Render_Pass with Threads_Num = spp / 4 on the GPU
+    (C4: four batches of 64 spp, C5: 128 batches of 8 spp: every sample-chunk offset occurs), sampled pixels against the oracle."""
+    from ada_ray_tracer_amd import scenes
+    build, W, H, T, n = CONFIGS[config]
+    sd = build(scenes)
+    backend.upload_scene(sd)
+    backend.resize(W, H)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, T, seed=1)
+    s0 = backend.stats()
+    accum, _, spp = backend.render_pass(p, 0)
+    st = backend.stats()
+    assert spp == 4 * T and accum.shape == (H, W, 3)
+    assert st.samples - s0.samples == 4 * T * W * H and st.lost_paths == 0
+    osc = conv.OracleScene(sd)
+    nodes, tris, info = backend.export_bvh()
+    osc.attach_bvh(nodes, tris, info.node_width)
+    rng = np.random.default_rng(4321 + len(config) + T)
+    xs = rng.integers(0, W, n); ys = rng.integers(0, H, n)
+    xs[:4] = [0, W - 1, 0, W - 1]; ys[:4] = [0, 0, H - 1, H - 1]            # the frame's corners
+    ref, cnt = orc.render_pixels(osc.scene, orc.make_params(W, H, orc.PT_MIS, True, 8, T, seed=1), xs, ys)
+    assert cnt.samples == n * 4 * T
+    got = accum[ys, xs]
+    assert np.isfinite(ref).all()
+    assert np.abs(got - ref).max() / spp <= TOL                             # BASELINE's stated tolerance ...
+    assert np.array_equal(bits(got), bits(ref))                             # ... and in fact the same bits
+    assert (ref.sum(1) > 0).mean() > 0.2                                    # not a sample of black pixels
+
+
+def test_c3_two_passes_of_eight_tasks_equal_one_pass_of_sixteen(art, backend):
+    """g_accBuff is cumulative over Render_Pass calls (ray_tracer.adb:281-285): 2 x 32 spp == 1 x 64 spp, bit for bit, against the oracle's
+    two passes on sampled pixels (spp0 = 32 for the second)."""
+    from ada_ray_tracer_amd import scenes
+    W = H = 1024
+    sd = scenes.synthetic_scene(100000, 3)
+    backend.upload_scene(sd)
+    backend.resize(W, H)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 8, seed=1)
+    spp = backend.render_pass_device(p, 0)
+    accum, _, spp = backend.render_pass(p, spp)
+    assert spp == 64
+    backend.resize(W, H)
+    once, _, _ = backend.render_pass(art.Backend.pass_params(art.PT_MIS, True, 8, 16, seed=1), 0)
+    assert np.array_equal(bits(accum), bits(once))
+    osc = conv.OracleScene(sd)
+    nodes, tris, info = backend.export_bvh()
+    osc.attach_bvh(nodes, tris, info.node_width)
+    rng = np.random.default_rng(99)
+    xs = rng.integers(0, W, 500); ys = rng.integers(0, H, 500)
+    prm = orc.make_params(W, H, orc.PT_MIS, True, 8, 8, seed=1)
+    ref, _ = orc.render_pixels(osc.scene, prm, xs, ys, 0)
+    ref, _ = orc.render_pixels(osc.scene, prm, xs, ys, 32, ref)
+    assert np.array_equal(bits(accum[ys, xs]), bits(ref))

@@ -142,3 +142,18 @@ def test_task_pool_organisation_gives_the_same_bits():
         a, spp_a, ca = orc.render(cs.scene, orc.make_params(40, 32, orc.PT_MIS, aa, 8, 5, seed=4))
         b, spp_b, cb = orc.render_tasks(cs.scene, orc.make_params(40, 32, orc.PT_MIS, aa, 8, 5, seed=4, nthreads=nthreads))
         assert spp_a == spp_b and ca.rays == cb.rays and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_pixel_list_pass_is_the_frame_pass():
+    """orc_render_pixels (the pass for a list of pixels, used where a whole BASELINE frame is out of reach: tests/test_gpu_stated_spp.py)
+    == the same pixels of orc_render_pass, also cumulatively over two passes (spp0 = 12 for the second)."""
+    cs = orc.CornellScene()
+    prm = orc.make_params(40, 32, orc.PT_MIS, True, 8, 3, seed=4)
+    frame, spp, cnt = orc.render(cs.scene, prm, passes=2)
+    assert spp == 24
+    ys, xs = np.mgrid[0:32, 0:40]
+    xs = xs.ravel()[::7]; ys = ys.ravel()[::7]
+    part, c1 = orc.render_pixels(cs.scene, prm, xs, ys, 0)
+    part, c2 = orc.render_pixels(cs.scene, prm, xs, ys, 12, part)
+    assert c1.samples == len(xs) * 12
+    assert np.array_equal(part.view(np.uint32), frame[ys, xs].view(np.uint32))
