@@ -212,7 +212,8 @@ static int download_from(const float* acc_dev, float* accum_host, uint32_t* scre
 constexpr size_t kRecSlack = 4096;       // records past the last one the trace kernel's chunk prefetch may touch
 static size_t hot_floats(size_t P, bool rec) { return (rec ? (6 + 8 + 7) : (14 + 8 + 7)) * P; }
 // (the trace records are not double-banked: a bank's records are dead once its rays are traced, and the next stage reads none of them)
-static size_t path_floats(size_t P, int depth, bool rec) { return 2 * hot_floats(P, rec) + (rec ? 32 * P + kRecSlack * 16 + 16 : 0) + (6 * (size_t)depth + 3 + 3 + 1) * P + 64; }
+// cold state: e (depth + 1 levels: dense fold records keep e_k at level k + 1) and w (depth levels) x 3, child (depth levels), term, rad, final flags
+static size_t path_floats(size_t P, int depth, bool rec) { return 2 * hot_floats(P, rec) + (rec ? 32 * P + kRecSlack * 16 + 16 : 0) + (7 * (size_t)depth + 3 + 3 + 3 + 1) * P + 64; }
 
 static int ensure_paths(size_t P, int depth, bool rec) { return ensure(g_ctx.b_paths, path_floats(P, depth, rec) * 4 + 256); }
 
@@ -244,15 +245,17 @@ static void carve(DevPaths q[2], int P, int depth, bool rec) {
     b.shadow_rule = g_ctx.shadow_anyhit ? 1 : 0; b.has_bvh = g_ctx.scene.n_tris > 0 ? 1 : 0;
   }
   DevPaths& a = q[0];
-  a.e_r = take(depth * p); a.e_g = take(depth * p); a.e_b = take(depth * p);
+  a.e_r = take((depth + 1) * p); a.e_g = take((depth + 1) * p); a.e_b = take((depth + 1) * p);
   a.w_r = take(depth * p); a.w_g = take(depth * p); a.w_b = take(depth * p);
+  a.child = (int32_t*)take(depth * p);
+  a.fold_dense = rec ? 1 : 0;                   // the compacted (record) schedule keeps dense fold records; the plain one folds by slot
   a.term_r = take(p); a.term_g = take(p); a.term_b = take(p);
   a.rad_r = take(p); a.rad_g = take(p); a.rad_b = take(p);
   a.final_flags = (uint32_t*)take(p);
   DevPaths& c = q[1];
   c.e_r = a.e_r; c.e_g = a.e_g; c.e_b = a.e_b; c.w_r = a.w_r; c.w_g = a.w_g; c.w_b = a.w_b;
   c.term_r = a.term_r; c.term_g = a.term_g; c.term_b = a.term_b; c.rad_r = a.rad_r; c.rad_g = a.rad_g; c.rad_b = a.rad_b;
-  c.final_flags = a.final_flags;
+  c.final_flags = a.final_flags; c.child = a.child; c.fold_dense = a.fold_dense;
 }
 
 // LDS stack per ray: the tree's worst-case bound if 8 workgroups per CU (8 waves per SIMD) still fit in the CU's 160 KB, else the
@@ -438,7 +441,7 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
           // Compacted work sets: raygen fills bank 0 (one item per slot); stage b shades the items of bank b & 1 and writes the survivors
           // densely into the other bank.  d_live[0] / d_live[32]: the banks' item counts.  Every stage leaves its rays as trace records in
           // its output bank (round 3), at positions given by the item index; the trace kernel reads them from there in item order.
-          if (!c.d_live) HIP_TRY(hipMalloc(&c.d_live, 64 * sizeof(int)));
+          if (!c.d_live) HIP_TRY(hipMalloc(&c.d_live, 32 * 18 * sizeof(int)));          // d_live[32 k]: items of level k (the input set of bounce k), k = 1 .. max_depth <= 16
           unsigned long long* const rays_b = c.count_tests ? c.d_counters + 7 : nullptr;          // the counting pass's ray count (stats[4])
           bank[0].rec_mode = REC_EXT;
           DevPaths q = bank[0];                            // identity layout for raygen
@@ -451,22 +454,24 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
             const DevPaths& qi = (b == 0) ? q : bank[in];
             const bool last = b + 1 >= p->max_depth;
             bank[out].rec_mode = (p->render_type == ART_PT_STUPID) ? REC_EXT : (last ? REC_SHADOW : REC_BOTH);
-            HIP_TRY(hipMemsetAsync(c.d_live + 32 * out, 0, sizeof(int), c.stream));
-            launch_shade_compact(c.stream, F, c.scene, qi, bank[out], b, b == 0 ? nullptr : c.d_live + 32 * in, c.d_live + 32 * out,
+            int* const n_in = c.d_live + 32 * b; int* const n_out = c.d_live + 32 * (b + 1);      // per level: the fold walks them again
+            HIP_TRY(hipMemsetAsync(n_out, 0, sizeof(int), c.stream));
+            launch_shade_compact(c.stream, F, c.scene, qi, bank[out], b, b == 0 ? nullptr : n_in, n_out,
                                  const_cast<uint32_t*>(bank[out].slot_id), c.d_counters + 15, c.d_counters, rays_b);
             if (g_debug_live) {
               int n = -1; unsigned long long r0 = 0;
-              (void)hipStreamSynchronize(c.stream); (void)hipMemcpy(&n, c.d_live + 32 * out, 4, hipMemcpyDeviceToHost); (void)hipMemcpy(&r0, c.d_counters, 8, hipMemcpyDeviceToHost);
+              (void)hipStreamSynchronize(c.stream); (void)hipMemcpy(&n, n_out, 4, hipMemcpyDeviceToHost); (void)hipMemcpy(&r0, c.d_counters, 8, hipMemcpyDeviceToHost);
               std::fprintf(stderr, "stage %d: items out %d of %d, rays so far %llu\n", b, n, q.P, r0);
             }
             if (!last || p->render_type != ART_PT_STUPID) {
-              const RecordQueue rq = {-1, c.d_live + 32 * out, bank[out].rec_mode == REC_BOTH ? 2 : 1};
-              if (trace(bank[out], 2 * q.P, true, c.d_live + 32 * out, &rq)) return 1;
+              const RecordQueue rq = {-1, n_out, bank[out].rec_mode == REC_BOTH ? 2 : 1};
+              if (trace(bank[out], 2 * q.P, true, n_out, &rq)) return 1;
             }
           }
           const int last = p->max_depth & 1;              // the bank the last stage wrote
-          launch_resolve_last(c.stream, bank[last], c.d_live + 32 * last, p->max_depth - 1);
-          launch_fold(c.stream, F, bank[last]);
+          launch_resolve_last(c.stream, bank[last], c.d_live + 32 * p->max_depth, p->max_depth - 1);
+          if (bank[last].fold_dense) launch_fold_levels(c.stream, F, bank[last], p->max_depth, c.d_live);
+          else launch_fold(c.stream, F, bank[last]);
           launch_accumulate(c.stream, F, q, sn, accum_ptr());
         } else {                                          // one-ray-per-lane cross-check kernel: the plain schedule over all slots, in place
           DevPaths q = bank[0];

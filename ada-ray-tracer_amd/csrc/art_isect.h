@@ -7,6 +7,22 @@
 #pragma once
 #include "art_scene.h"
 
+// Diagnostic builds only (-DART_LANE_PROBE, profiles/r4_probe.sh): ART_PROBE(k) adds, for every wave passing the point, its number of
+// enabled lanes to g_lane_probe[2k] and 1 to g_lane_probe[2k + 1] -- where a stage loses its lanes (round 4: k_shade_compact ran at 31 of
+// 64 lanes per VALU instruction).  Expands to nothing in the product build.
+#if defined(ART_LANE_PROBE) && defined(__HIPCC__)
+static __device__ unsigned long long g_lane_probe[2 * 64];
+static __device__ int g_lane_probe_on;        // set around the launches of the kernel under study (k_shade_compact)
+#endif
+#if defined(ART_LANE_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+#define ART_PROBE(k) do { const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true); \
+    if (g_lane_probe_on && (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == __builtin_ctzll(m_)) { \
+      atomicAdd(&g_lane_probe[2 * (k)], (unsigned long long)__builtin_popcountll(m_)); atomicAdd(&g_lane_probe[2 * (k) + 1], 1ull); } } while (0)
+#else
+#define ART_PROBE(k) do { } while (0)
+#endif
+
+
 namespace art {
 
 ART_HD f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
@@ -31,7 +47,9 @@ ART_HD void isect_sphere(f3 o, f3 d, const DevSphere& s, uint32_t index, Cand& b
   const float b = dot(k, d);
   const float c = dot(k, k) - s.r * s.r;
   const float disc = b * b - c;
+  ART_PROBE(50);
   if (disc >= 0.0f) {
+    ART_PROBE(51);
     const float sq = sqrtf(disc);
     const float t1 = -b - sq, t2 = -b + sq;
     if (t1 > 0.0f) { if (t1 < kInfinity) cand_take(best, t1, KEY_SPHERE | index, 0.0f, 0.0f); }
@@ -54,7 +72,9 @@ ART_HD bool slab_reference(f3 o, f3 d, const float* bmin, const float* bmax, flo
 // IntersectCornellBox: exit distance, face by |p - bound| < 1e-5 with later faces overriding, open face 5
 ART_HD void isect_cornell(f3 o, f3 d, const DevScene& s, Cand& best) {
   float tmin, tmax;
+  ART_PROBE(52);
   if (!slab_reference(o, d, s.cb_min, s.cb_max, tmin, tmax)) return;
+  ART_PROBE(53);
   const f3 p = o + tmax * d;
   const float eps = 1.0e-5f;
   uint32_t plane = 0;

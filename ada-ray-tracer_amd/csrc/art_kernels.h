@@ -55,6 +55,7 @@ void launch_shade_compact(hipStream_t st, const DevFrame& F, const DevScene& S, 
                           const int* n_in, int* n_out, uint32_t* slot_out, unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b);
 void launch_resolve_last(hipStream_t st, const DevPaths& Q, const int* n, int last_level);
 void launch_fold(hipStream_t st, const DevFrame& F, const DevPaths& Q);
+void launch_fold_levels(hipStream_t st, const DevFrame& F, const DevPaths& Q, int max_depth, const int* counts);     // dense fold records: counts[32 k] = items of level k
 void launch_accumulate(hipStream_t st, const DevFrame& F, const DevPaths& Q, int samples_in_batch, float* accum);
 void launch_resolve(hipStream_t st, const float* accum, int n_pixels, float norm_c, uint32_t* screen);
 void launch_debug(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q, float* accum, int32_t* prim_index, int32_t* mat_id, int32_t* prim_type);

@@ -703,10 +703,23 @@ __global__ __launch_bounds__(256) void k_shade(const DevFrame F, const DevScene 
 // ------------------------------------------------------------------------------------------------
 // k_shade_compact: one bounce over a compacted work set.  Every stage reads the items of the paths that still need something (input
 // set `Qi`: rays, hits, per-path state, item -> slot map) and writes only the items that will need something at the next stage to the
-// output set `Qo`, densely: the kernels that follow (k_analytic, the trace kernel's ray fetch, the next shade) then stream full
-// 128-byte lines of live data instead of lines in which a quarter of the slots is alive.  A workgroup handles a chunk of 4096 items:
-// pass 1 decides who survives (item_survives: flags, hit key, material type), one exclusive scan numbers them in item order, ONE global
-// atomic reserves the chunk's range of the output set; pass 2 shades and stores at the reserved positions.
+// output set `Qo`, densely: the kernels that follow (the trace kernel's record fetch, the next shade) then stream full 128-byte lines
+// of live data instead of lines in which a quarter of the slots is alive.
+//
+// A workgroup handles a chunk of 256 x PER items in three steps (round 4):
+//   1. classify: every item's class (item_class: its surface material, or CLS_CHEAP when the path ends at this hit), from the flags, the
+//      hit key and the material type alone; per class, a wave reserves its items' places in the class with ONE LDS atomic (ballot +
+//      prefix inside the wave);
+//   2. sort: the chunk's items are laid out class by class in LDS (s_perm), surface classes first -- they are the survivors: ONE global
+//      atomic reserves their range of the output set, item r of the sorted chunk goes to output item base + r;
+//   3. shade in sorted order: thread t takes sorted items t, t + 256, ...: a wave's 64 items are consecutive in the sorted chunk, so
+//      they are of ONE class except where two classes meet.  Before the sort a wave ran every material present in it with that material's
+//      lanes only: 31 of 64 lanes enabled per VALU instruction (C3, C4), 27 (C5), e.g. on C4 71 % of the waves walked the Phong code
+//      (four binary64 pow) for three lanes on the back wall (profiles/r4_shade/lane_probe_*.txt).
+// The survivors of a wave's round are consecutive output items: their trace records are one contiguous piece of the output bank, the
+// extension rays first, then the shadow rays (REC_BOTH).  The wave builds the records of one kind (make_record: analytic primitives
+// intersected = the starting bound, slab set-up), stages them in LDS and copies them out 16 bytes per lane to consecutive addresses --
+// at a point every lane of the wave reaches, outside all per-item branches.
 // ------------------------------------------------------------------------------------------------
 // items per workgroup = 256 x kShadePerThread, one global atomic per workgroup.  Rounds 1-2 used 16 per thread (a single hot word serves
 // ~88 atomics / us); measured in round 3 with the fused stage: 4 per thread is faster at every size -- a thread's items one after the other
@@ -716,22 +729,33 @@ __global__ __launch_bounds__(256) void k_shade(const DevFrame F, const DevScene 
 #define ART_SHADE_PER 4
 #endif
 constexpr int kShadePerThread = ART_SHADE_PER;
+#ifndef ART_SHADE_DEFER
+#define ART_SHADE_DEFER 0         // 1: the kernel builds and copies the records after shade_item, at a wave-uniform point (costs 30 more VGPRs: spills at 6 waves per SIMD, +25 % launch time); 0: shade_item's own emit_ray does (round 3)
+#endif
+#ifndef ART_SHADE_SORT
+#define ART_SHADE_SORT 0          // 1: sort the items of a round by material class (see above); 0: input order (one class for all surfaces)
+#endif
 
+#ifndef ART_SHADE_WAVES
+#define ART_SHADE_WAVES 6
+#endif
 template <int PER>
-// 6 waves per SIMD (80 VGPRs, 48 bytes of scratch per lane): the stage is bound by the latency of its dependent gathers (hit -> triangle
-// shading record -> material), not by issue or bandwidth; left to itself the compiler takes 111 VGPRs = 4 waves (6.6 -> 6.2 ms per launch on C4)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_shade_compact(const DevFrame F, const DevScene S, const DevPaths Qi, const DevPaths Qo, int bounce,
+// 6 waves per SIMD (80 VGPRs): left to itself the compiler takes 111 VGPRs = 4 waves (6.6 -> 6.2 ms per launch on C4, round 3)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_WAVES))) void k_shade_compact(const DevFrame F, const DevScene S, const DevPaths Qi, const DevPaths Qo, int bounce,
                                                        const int* __restrict__ n_in_ptr, int* __restrict__ n_out_ptr, uint32_t* __restrict__ slot_out,
                                                        unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b) {
-  __shared__ int s_cnt[PER * 4];      // survivors per (round k, wave)
+  constexpr int kShadeChunk = 256 * PER;
+  static_assert(kShadeChunk <= 65536, "s_perm holds 16-bit positions");
+  __shared__ int s_tot[PER * kItemClasses];                // items of each class in each round (256 items) of the chunk
   __shared__ int s_base, s_rays;
-  // record mode: a wave's trace records of one round, [quarter][record] (+1: four consecutive records' quarters fall into four banks)
+  __shared__ int s_nall[PER], s_nkeep[PER], s_out0[PER];   // per round: items, survivors, first output item (relative to s_base)
+  __shared__ uint16_t s_perm[kShadeChunk];                 // [round][sorted position] -> thread that classified the item
+  // a wave's trace records of one kind, [quarter][record] (+1: four consecutive records' quarters fall into four banks)
   constexpr int kStagePitch = 64 + 1;
   __shared__ Rec4 s_stage[4][4 * kStagePitch];
-  __shared__ DevSphere s_sph[kAnalyticLdsSpheres];      // the scene's spheres and lights, fetched once per workgroup (emit_ray tests every ray against them)
+  __shared__ DevSphere s_sph[kAnalyticLdsSpheres];      // the scene's spheres and lights, fetched once per workgroup (every emitted ray is tested against them)
   __shared__ DevLight s_lgt[kAnalyticLdsLights];
   const int n_in = n_in_ptr ? *n_in_ptr : Qi.P;
-  constexpr int kShadeChunk = 256 * PER;
   const int c0 = blockIdx.x * kShadeChunk;
   if (c0 >= n_in) return;                                // the grid covers Qi.P items; the work set has shrunk to n_in
   // (the material table stays in global memory: a 40-byte per-lane-indexed record out of LDS measured 7 % slower than the cached global read)
@@ -739,48 +763,108 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   if (tables_in_lds) {
     if ((int)threadIdx.x < S.n_spheres) s_sph[threadIdx.x] = S.spheres[threadIdx.x];
     if ((int)threadIdx.x < S.n_lights) s_lgt[threadIdx.x] = S.lights[threadIdx.x];
-    __syncthreads();
   }
+  if (threadIdx.x < PER * kItemClasses) s_tot[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_rays = 0;
+  __syncthreads();
   StageCtx tables;
   if (tables_in_lds) { tables.spheres = s_sph; tables.lights = s_lgt; }
-  if (threadIdx.x == 0) s_rays = 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t keep_bits = 0;
-#pragma unroll      // the PER survival tests are independent chains of loads (flags, hit -> triangle record -> material): issued together (-6 %)
+  const uint64_t lanes_below = (1ull << lane) - 1ull;
+  // ---- 1. classify; a wave's items of one class take consecutive places in the class (of their round)
+  int cls[PER], rank[PER];
+#pragma unroll      // the PER classifications are independent chains of loads (flags, hit -> triangle record -> material): issued together (-6 %)
   for (int k = 0; k < PER; ++k) {
     const int w = c0 + k * 256 + threadIdx.x;
-    const bool keep = (w < n_in) && item_survives(F, S, Qi, w, bounce, tables);
-    keep_bits |= keep ? (1u << k) : 0u;
-    const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
-    if (lane == 0) s_cnt[k * 4 + wave] = (int)__popcll(m);
+    int c = (w < n_in) ? item_class(S, Qi, w, tables) : kItemClasses;
+    if (!ART_SHADE_SORT && c < CLS_CHEAP) c = CLS_LAMBERT;
+    cls[k] = c; rank[k] = 0;
+#pragma unroll
+    for (int q = 0; q < kItemClasses; ++q) {
+      const uint64_t m = __builtin_amdgcn_ballot_w64(c == q);
+      if (m != 0) {                                        // wave-uniform
+        int b = 0;
+        if (lane == 0) b = atomicAdd(&s_tot[k * kItemClasses + q], (int)__popcll(m));
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (c == q) rank[k] = b + (int)__popcll(m & lanes_below);
+      }
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int total = 0;
-    for (int i = 0; i < PER * 4; ++i) { const int c = s_cnt[i]; s_cnt[i] = total; total += c; }
-    s_base = total ? atomicAdd(n_out_ptr, total) : 0;
+  // ---- 2. sort every round: class q starts where the classes before it end; the surface classes (the survivors) come first.
+  // The sort stays inside a round's 256 items: the four waves of the workgroup then read one 1-KB window of every array at the same time
+  // (sorted over the whole chunk, a wave's loads touched lines whose other halves were fetched again three rounds later: +43 % bytes
+  // fetched, +22 % written back, 16-27 % slower although it ran 29 % fewer VALU instructions -- profiles/r4_shade/ab_sort_chunk.txt)
+  const bool keeps = stage_keeps_surfaces(F, bounce);
+  int total_keep = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    int st = 0, mine = 0, nkeep = 0;
+#pragma unroll
+    for (int q = 0; q < kItemClasses; ++q) {
+      mine = (cls[k] == q) ? st : mine;
+      if (q == CLS_CHEAP) nkeep = keeps ? st : 0;
+      st += s_tot[k * kItemClasses + q];
+    }
+    if (threadIdx.x == 0) { s_nall[k] = st; s_nkeep[k] = nkeep; s_out0[k] = total_keep; }
+    total_keep += nkeep;
+    if (cls[k] < kItemClasses) s_perm[k * 256 + mine + rank[k]] = (uint16_t)threadIdx.x;
   }
+  if (threadIdx.x == 0) s_base = total_keep ? atomicAdd(n_out_ptr, total_keep) : 0;
   __syncthreads();
   const int base = s_base;
+  // ---- 3. shade in sorted order
+  const bool staged = (Qo.rec != nullptr) && Qo.has_bvh;
+  const int mode = Qo.rec_mode;
+  StageCtx cx = tables;
   int n_rays = 0;
+#pragma unroll 1
   for (int k = 0; k < PER; ++k) {
-    const int w = c0 + k * 256 + threadIdx.x;
-    const bool keep = (keep_bits >> k) & 1u;
-    const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
-    const int wo = keep ? base + s_cnt[k * 4 + wave] + (int)__popcll(m & ((1ull << lane) - 1ull)) : -1;
-    const bool staged = (Qo.rec != nullptr) && Qo.has_bvh;
-    if (w < n_in) {
+    const int r = (int)threadIdx.x;                       // position in the sorted round
+    const int n_all_k = s_nall[k], n_keep_k = s_nkeep[k], out0_k = s_out0[k];
+    const bool keep = r < n_keep_k;
+    const int wo = keep ? base + out0_k + r : -1;
+    RayOut ro; ro.alive = false; ro.shadow = false; ro.no = ro.nd = ro.so = ro.sd = mk3(0.0f, 0.0f, 0.0f); ro.s_tfar = -1.0f; ro.sh_min = 0.0f;
+    if (r < n_all_k) {
+      const int w = c0 + k * 256 + (int)s_perm[k * 256 + r];
       if (keep) slot_out[wo] = (uint32_t)item_slot(Qi, w);
-      StageCtx cx = tables;
-      if (staged) {
-        // the kept items of the wave are consecutive output items: their records are one contiguous piece of the output bank, the
-        // extension rays first, then the shadow rays (REC_BOTH); emit_ray stages one kind at a time and the emitting lanes copy it out
-        const int nk = (int)__popcll(m), per = (Qo.rec_mode == REC_BOTH) ? 2 : 1;
-        const size_t first = (size_t)per * (size_t)(base + s_cnt[k * 4 + wave]);
-        cx.stage = s_stage[wave]; cx.stage_pitch = kStagePitch; cx.stage_item = (int)__popcll(m & ((1ull << lane) - 1ull));
-        cx.stage_count = nk; cx.rec_base[0] = first; cx.rec_base[1] = (per == 2) ? first + (size_t)nk : first;
+      if (ART_SHADE_DEFER) n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cx, &ro);
+      else {
+        StageCtx cy = tables;
+        if (staged) {
+          const int nk = min(64, max(0, n_keep_k - wave * 64)), per = (Qo.rec_mode == REC_BOTH) ? 2 : 1;
+          const size_t first = (size_t)per * (size_t)(base + out0_k + wave * 64);
+          cy.stage = s_stage[wave]; cy.stage_pitch = kStagePitch; cy.stage_item = lane; cy.stage_count = nk;
+          cy.rec_base[0] = first; cy.rec_base[1] = (per == 2) ? first + (size_t)nk : first;
+        }
+        n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cy);
       }
-      n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cx);
+    }
+    if (ART_SHADE_DEFER && Qo.rec != nullptr) {
+      // every lane of the wave is here.  The wave's survivors of this round are its lanes [0, nk): consecutive output items.
+      const int r0 = wave * 64;
+      const int nk = min(64, max(0, n_keep_k - r0));
+      if (nk > 0) {                                        // wave-uniform
+        const int per = (mode == REC_BOTH) ? 2 : 1;
+        const size_t first = (size_t)per * (size_t)(base + out0_k + r0);
+#pragma unroll
+        for (int kind = 0; kind < 2; ++kind) {             // 0: extension rays, 1: shadow rays
+          if ((kind == 0 && mode == REC_SHADOW) || (kind == 1 && mode == REC_EXT)) continue;
+          TraceRec t;
+          if (keep) {
+            t = (kind == 0) ? make_record(S, Qo, (size_t)wo, ro.alive, ro.no, ro.nd, kInfinity, -1.0f, cx)
+                            : make_record(S, Qo, (size_t)Qo.P + (size_t)wo, ro.shadow, ro.so, ro.sd, ro.s_tfar, Qo.shadow_rule ? ro.sh_min : -1.0f, cx);
+          }
+          if (staged) {
+            Rec4* const stage = s_stage[wave];
+            if (keep) { stage[lane] = t.r0; stage[kStagePitch + lane] = t.r1; stage[2 * kStagePitch + lane] = t.r2; stage[3 * kStagePitch + lane] = t.r3; }
+            wave_lds_sync();
+            Rec4* out = Qo.rec + 4 * (first + ((kind == 1 && per == 2) ? (size_t)nk : 0));
+            for (int g = lane; g < 4 * nk; g += 64) out[g] = stage[(g & 3) * kStagePitch + (g >> 2)];
+            wave_lds_sync();
+          }
+        }
+      }
     }
   }
   // record mode: the rays just emitted are the closest-hit queries of the next trace launch (k_analytic counts them in the plain layout)
@@ -802,6 +886,15 @@ __global__ __launch_bounds__(256) void k_resolve_last(const DevPaths Q, const in
 __global__ __launch_bounds__(256) void k_fold(const DevFrame F, const DevPaths Q) {
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot < Q.P) fold_slot(F, Q, slot);
+}
+
+// dense fold records: one level (art_shade.h fold_level_item).  n_ptr: the level's item count (nullptr: all Q.P slots = level 0)
+__global__ __launch_bounds__(256) void k_fold_level(const DevFrame F, const DevPaths Q, int level, int deepest, const int* __restrict__ n_ptr,
+                                                    const float* __restrict__ nxt_r, const float* __restrict__ nxt_g, const float* __restrict__ nxt_b,
+                                                    float* __restrict__ cur_r, float* __restrict__ cur_g, float* __restrict__ cur_b) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = n_ptr ? *n_ptr : Q.P;
+  if (w < n) fold_level_item(F, Q, level, w, deepest != 0, nxt_r, nxt_g, nxt_b, cur_r, cur_g, cur_b);
 }
 
 __global__ __launch_bounds__(256) void k_finish(const DevFrame F, const DevPaths Q, int last_level) {
@@ -892,8 +985,17 @@ void launch_raygen(hipStream_t st, const DevFrame& F, const DevScene& S, const D
 void launch_shade(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q, int bounce) {
   hipLaunchKernelGGL(k_shade, dim3(blocks_for(Q.P)), dim3(256), 0, st, F, S, Q, bounce);
 }
+#if defined(ART_LANE_PROBE)
+__global__ void k_probe_on(int v) { g_lane_probe_on = v; }
+#endif
 void launch_shade_compact(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Qi, const DevPaths& Qo, int bounce,
                           const int* n_in, int* n_out, uint32_t* slot_out, unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b) {
+#if defined(ART_LANE_PROBE)
+  hipLaunchKernelGGL(k_probe_on, dim3(1), dim3(1), 0, st, 1);
+  hipLaunchKernelGGL(k_shade_compact<kShadePerThread>, dim3((Qi.P + 256 * kShadePerThread - 1) / (256 * kShadePerThread)), dim3(256), 0, st, F, S, Qi, Qo, bounce, n_in, n_out, slot_out, lost, rays_a, rays_b);
+  hipLaunchKernelGGL(k_probe_on, dim3(1), dim3(1), 0, st, 0);
+  return;
+#endif
   hipLaunchKernelGGL(k_shade_compact<kShadePerThread>, dim3((Qi.P + 256 * kShadePerThread - 1) / (256 * kShadePerThread)), dim3(256), 0, st, F, S, Qi, Qo, bounce, n_in, n_out, slot_out, lost, rays_a, rays_b);
 }
 void launch_bump(hipStream_t st, unsigned long long* a, unsigned long long* b, unsigned long long n) { hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, st, a, b, n); }
@@ -902,6 +1004,16 @@ void launch_resolve_last(hipStream_t st, const DevPaths& Q, const int* n, int la
 }
 void launch_fold(hipStream_t st, const DevFrame& F, const DevPaths& Q) {
   hipLaunchKernelGGL(k_fold, dim3(blocks_for(Q.P)), dim3(256), 0, st, F, Q);
+}
+// the whole fold over dense records: levels max_depth - 1 .. 0, ping-pong between the term arrays (odd levels) and rad (even levels: level 0
+// ends in rad, where k_accumulate reads).  counts[32 * k] = item count of level k (k >= 1)
+void launch_fold_levels(hipStream_t st, const DevFrame& F, const DevPaths& Q, int max_depth, const int* counts) {
+  for (int k = max_depth - 1; k >= 0; --k) {
+    float* cur[3] = {(k & 1) ? Q.term_r : Q.rad_r, (k & 1) ? Q.term_g : Q.rad_g, (k & 1) ? Q.term_b : Q.rad_b};
+    const float* nxt[3] = {(k & 1) ? Q.rad_r : Q.term_r, (k & 1) ? Q.rad_g : Q.term_g, (k & 1) ? Q.rad_b : Q.term_b};
+    hipLaunchKernelGGL(k_fold_level, dim3(blocks_for(Q.P)), dim3(256), 0, st, F, Q, k, k == max_depth - 1 ? 1 : 0, k == 0 ? nullptr : counts + 32 * k,
+                       nxt[0], nxt[1], nxt[2], cur[0], cur[1], cur[2]);
+  }
 }
 void launch_finish(hipStream_t st, const DevFrame& F, const DevPaths& Q, int last_level) {
   hipLaunchKernelGGL(k_finish, dim3(blocks_for(Q.P)), dim3(256), 0, st, F, Q, last_level);
@@ -972,6 +1084,17 @@ void launch_trace(hipStream_t st, const DevScene* S, const TraceArgs& A, int ker
 }
 
 }  // namespace art
+
+#if defined(ART_LANE_PROBE)
+// diagnostic build: read (and clear) the lane probes of art_isect.h
+extern "C" int art_debug_lane_probe(unsigned long long* out, int n) {
+  unsigned long long z[2 * 64] = {};
+  if (n > 2 * 64) n = 2 * 64;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lane_probe), (size_t)n * 8) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_lane_probe), z, sizeof z) != hipSuccess;
+}
+#endif
 
 namespace art {
 int trace_coop_blocks_per_cu(int stack_entries, int width) {

@@ -117,6 +117,14 @@ struct DevPaths {
   // flags word a path ended with (levels recorded, bits 8..) for the fold; with the identity layout it is the flags array itself.
   const uint32_t* slot_id;
   uint32_t* final_flags;
+  // Dense fold records (round 4; the compacted schedule).  fold_dense = 0: level k's e_k / w_k live at [k][slot] (the arrays above), a path's
+  // end at term / final_flags[slot]; a stage then scatters 4-byte words over every line of the level -- measured: 9 % of the shade stage's
+  // bytes, 18 % of its time.  fold_dense = 1: a level's records are indexed by the ITEM index of that bounce's input set, so every store
+  // is dense: item w of bounce k leaves { w_* [k][w] = its weight w_k, or the value its path ended with; child[k][w] = its item at bounce
+  // k + 1 (-1: the path ended here with that value; -2: a surface whose successor was not kept and counts as 0) } and, one bounce later,
+  // e_*[k + 1][w'] = its explicit light e_k at the index w' of that next item.  k_fold_level walks the levels from the deepest up.
+  int32_t* child;               // [max_depth][P]
+  int32_t fold_dense;
   // Trace records of this bank's rays (round 3), 4 x Rec4 per record, or nullptr (REC_NONE: the SoA ray arrays above are used).
   // A stage reads the extension ray of its input item from the input bank's records ({origin, .} {direction, .}: the first two
   // quarters) and writes the records of the rays it emits -- analytic primitives already intersected (the starting bound), slab set-up

@@ -20,11 +20,15 @@ constexpr float kPhongClamp = 0x1.921eaep+0f;  // static M_PI*0.499995 (material
 // stage at 3.3 TB/s), and the LDS staging of the records a wave emits (emit_ray).  All optional: the host simulation passes none.
 struct StageCtx {
   const DevSphere* spheres = nullptr; const DevLight* lights = nullptr; const DevMaterial* materials = nullptr;   // nullptr: the scene's own tables
-  Rec4* stage = nullptr; int stage_pitch = 0; int stage_item = 0;
+  Rec4* stage = nullptr; int stage_pitch = 0; int stage_item = 0;     // LDS staging of the wave's records (emit_ray): k_raygen copies them out itself
   // k_shade_compact: stage_count > 0 lanes of the wave emit together (stage_item = this lane's rank among them) and copy the records out
   // themselves, one kind of ray at a time; rec_base[0 / 1]: first record of the wave's extension / shadow rays in the output bank
   int stage_count = 0; size_t rec_base[2] = {0, 0};
 };
+
+// The rays an item leaves a bounce with, for a caller that writes the trace records itself (k_shade_compact: the wave stages one kind of
+// ray at a time and copies it out at a point every lane of the wave reaches).
+struct RayOut { bool alive, shadow; f3 no, nd, so, sd; float s_tfar, sh_min; };
 
 ART_HD void wave_fence() {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -50,7 +54,9 @@ ART_HD f3 lobe_to_world(f3 dev, f3 direction, f3 normal) {
   { const f3 tmp = ny; ny = nz; nz = tmp; }
   f3 res = (nx * dev.x + ny * dev.y) + nz * dev.z;
   const float inv_sign = (dot(direction, normal) >= 0.0f) ? 1.0f : -1.0f;
+  ART_PROBE(24);
   if (inv_sign * dot(res, normal) < 0.0f) {
+    ART_PROBE(25);
     nx = normalize(cross(normal, direction));
     nz = normalize(cross(nx, ny));
     if (dot(nz, res) < 0.0f) nz = neg(nz);
@@ -104,7 +110,9 @@ ART_HD LightSample light_sample(const DevLight& l, float u1, float u2, f3 p) {
   LightSample r;
   r.pos = mk3(0.0f, 0.0f, 0.0f); r.dir = r.pos; r.pdf = 1.0f;
   r.intensity = ld3(l.intensity);
+  ART_PROBE(10);
   if (l.shape == LIGHT_RECT) {                                   // AreaLight.Sample
+    ART_PROBE(11);
     r.pos.x = l.boxMin[0] + u1 * (l.boxMax[0] - l.boxMin[0]);
     r.pos.y = l.boxMin[1];
     r.pos.z = l.boxMin[2] + u2 * (l.boxMax[2] - l.boxMin[2]);
@@ -118,6 +126,7 @@ ART_HD LightSample light_sample(const DevLight& l, float u1, float u2, f3 p) {
   }
   const f3 c = ld3(l.center);                                    // SphereLight.Sample
   if (dist2(p, c) - l.radius * l.radius < 1.0e-4f) {
+    ART_PROBE(12);
     const float z = 1.0f - 2.0f * u1;                            // UniformSampleSphere
     const float rr = sqrtf(amax(0.0f, 1.0f - z * z));
     float sph, cph;
@@ -128,7 +137,9 @@ ART_HD LightSample light_sample(const DevLight& l, float u1, float u2, f3 p) {
   }
   const f3 wc = normalize(c - p);
   f3 wx, wy;                                                     // CoordinateSystem
+  ART_PROBE(13);
   if (fabsf(wc.x) > fabsf(wc.y)) {
+    ART_PROBE(14);
     const float il = 1.0f / sqrtf(wc.x * wc.x + wc.z * wc.z);
     wx = mk3(-wc.z * il, 0.0f, wc.x * il);
   } else {
@@ -136,6 +147,7 @@ ART_HD LightSample light_sample(const DevLight& l, float u1, float u2, f3 p) {
     wx = mk3(0.0f, wc.z * il, -wc.y * il);
   }
   wy = cross(wc, wx);
+  ART_PROBE(15);
   const float s2 = l.radius * l.radius / dist2(p, c);
   const float cmax = sqrtf(amax(0.0f, 1.0f - s2));
   const float ct = alerp(u1, cmax, 1.0f);                        // UniformSampleCone
@@ -151,10 +163,11 @@ ART_HD LightSample light_sample(const DevLight& l, float u1, float u2, f3 p) {
     const float cc = dot(k, k) - l.radius * l.radius;
     const float disc = b * b - cc;
     float hx;
-    if (disc >= 0.0f) { const float sq = sqrtf(disc); hx = amin(-b - sq, -b + sq); }
+    if (disc >= 0.0f) { ART_PROBE(16); const float sq = sqrtf(disc); hx = amin(-b - sq, -b + sq); }
     else hx = -kInfinity;
     thit = (hx < 0.0f) ? dot(c - p, normalize(rdir)) : hx;
   }
+  ART_PROBE(17);
   r.pos = rpos + thit * rdir;
   r.dir = normalize(r.pos - c);
   r.pdf = sphere_light_pdf(l, p);
@@ -181,6 +194,7 @@ ART_HD BsdfSample bsdf_sample(const DevMaterial& m, float xi1, float xi2, f3 ray
   BsdfSample r;
   switch (m.type) {
     case MAT_LAMBERT: {                                         // materials.adb:197-215
+      ART_PROBE(20);
       const f3 nd = sample_cosine(xi1, xi2, n, n, 1.0f);
       const float ct = dot(nd, n);
       r.pdf = fabsf(ct) * kInvPi;
@@ -190,12 +204,14 @@ ART_HD BsdfSample bsdf_sample(const DevMaterial& m, float xi1, float xi2, f3 ray
       return r;
     }
     case MAT_MIRROR: {                                          // :247-254
+      ART_PROBE(21);
       const f3 nd = reflect(ray_dir, n);
       const float cdiv = 1.0f / amax(dot(nd, n), kEpsDiv);
       r.color = ld3(m.p) * cdiv; r.dir = nd; r.pdf = 1.0f; r.specular = true;
       return r;
     }
     case MAT_GLASS: {                                           // :285-331
+      ART_PROBE(22);
       const float ior = m.p[6];
       const float f = fresnel_unpolarised(dot(ray_dir, n), ior, 1.0f);
       const f3 refl = f * ld3(m.p);
@@ -225,6 +241,7 @@ ART_HD BsdfSample bsdf_sample(const DevMaterial& m, float xi1, float xi2, f3 ray
       return r;
     }
     case MAT_PHONG: {                                           // :363-387
+      ART_PROBE(23);
       const float pw = m.p[3];
       const f3 rr = reflect(ray_dir, n);
       const f3 nd = sample_cosine_fixed(xi1, xi2, rr, n, pw);
@@ -317,37 +334,49 @@ ART_HD Cand analytic_bound(const DevScene& s, const StageCtx& cx, f3 o, f3 d, fl
 ART_HD size_t rec_slot(int mode, int w, bool shadow_ray) { return (mode == REC_BOTH) ? 2 * (size_t)w + (shadow_ray ? 1u : 0u) : (size_t)w; }
 
 // One ray of an output item: its hit record (the starting bound: what stands if the BVH finds nothing nearer) and its 64-byte trace
-// record (art_kernels.h) at position `rq` of the output bank -- everything k_analytic does for the plain layout, done where the ray
-// is born.  shm >= 0: a shadow ray under the visibility rule (art_isect.h shadow_rule).  A ray that does not exist (live = false) or
-// is already decided leaves a record whose bound is negative: the trace kernel takes it and retires it at once.
-// stage != nullptr: the four quarters go to stage[quarter * stage_pitch + stage_slot] instead (LDS: k_shade_compact then writes a wave's
-// records out as contiguous kilobytes -- 64 lanes storing 16 bytes at a 64- or 128-byte stride cost the vector-memory path four times as much).
-ART_HD void emit_ray(const DevScene& s, const DevPaths& qo, size_t hit_index, size_t rq, bool live, f3 o, f3 d, float tfar, float shm,
-                     const StageCtx& cx = StageCtx(), int stage_slot = 0, int kind = 0) {
-  Rec4* const stage = cx.stage; const int stage_pitch = cx.stage_pitch;
-  Rec4 r0 = {0.0f, 0.0f, 0.0f, -1.0f}, r1 = {0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, KEY_MISS)}, r2 = {0.0f, 0.0f, 0.0f, -1.0f};
-  Rec4 r3 = {0.0f, __builtin_bit_cast(float, (uint32_t)hit_index), 0.0f, 0.0f};
+// record (art_kernels.h) -- everything k_analytic does for the plain layout, done where the ray is born.  shm >= 0: a shadow ray under
+// the visibility rule (art_isect.h shadow_rule).  A ray that does not exist (live = false) or is already decided leaves a record whose
+// bound is negative: the trace kernel takes it and retires it at once.
+struct TraceRec { Rec4 r0, r1, r2, r3; };
+ART_HD TraceRec make_record(const DevScene& s, const DevPaths& qo, size_t hit_index, bool live, f3 o, f3 d, float tfar, float shm, const StageCtx& cx = StageCtx()) {
+  TraceRec t;
+  t.r0 = Rec4{0.0f, 0.0f, 0.0f, -1.0f}; t.r1 = Rec4{0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, KEY_MISS)}; t.r2 = Rec4{0.0f, 0.0f, 0.0f, -1.0f};
+  t.r3 = Rec4{0.0f, __builtin_bit_cast(float, (uint32_t)hit_index), 0.0f, 0.0f};
+  ART_PROBE(30);
   if (live) {
+    ART_PROBE(31);
     const Cand best = analytic_bound(s, cx, o, d, tfar);
     qo.hit[hit_index] = DevHit{best.t, best.key, best.u, best.v};
     const bool near_done = (shm >= 0.0f) && (best.key != KEY_MISS) && (best.t <= shm);       // shadow_rule: decided
     if (!near_done && qo.has_bvh) {
+      ART_PROBE(32);
       f3 inv, noi; slab_setup(o, d, inv, noi);
       const bool far_found = (shm >= 0.0f) && (best.key != KEY_MISS);
       const float bt = far_found ? next_up_pos(shm) : best.t;
       const uint32_t bk = far_found ? KEY_MISS : best.key;
       const uint32_t sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
       const uint32_t sel_near = (sx ? 3u : 0u) | ((sy ? 4u : 1u) << 8) | ((sz ? 5u : 2u) << 16) | 0x0c000000u;
-      r0 = Rec4{o.x, o.y, o.z, bt}; r1 = Rec4{d.x, d.y, d.z, __builtin_bit_cast(float, bk)}; r2 = Rec4{inv.x, inv.y, inv.z, shm};
-      r3.x = __builtin_bit_cast(float, sel_near); r3.z = __builtin_bit_cast(float, far_found ? 1u : 0u);
+      t.r0 = Rec4{o.x, o.y, o.z, bt}; t.r1 = Rec4{d.x, d.y, d.z, __builtin_bit_cast(float, bk)}; t.r2 = Rec4{inv.x, inv.y, inv.z, shm};
+      t.r3.x = __builtin_bit_cast(float, sel_near); t.r3.z = __builtin_bit_cast(float, far_found ? 1u : 0u);
     }
   }
-  if (!qo.has_bvh) return;                              // no trace kernel will run: the hit record above is the whole answer
-  if (stage) {
-    stage[stage_slot] = r0; stage[stage_pitch + stage_slot] = r1; stage[2 * stage_pitch + stage_slot] = r2; stage[3 * stage_pitch + stage_slot] = r3;
+  return t;
+}
+
+// ... stored at position `rq` of the output bank, or (cx.stage != nullptr: k_raygen) as four quarters in the wave's LDS staging area,
+// stage[quarter * stage_pitch + stage_slot]; the kernel then writes the wave's records out as contiguous kilobytes (64 lanes storing 16
+// bytes at a 64-byte stride cost the vector-memory path four times as much).  k_shade_compact stages and copies by itself (round 4).
+ART_HD void emit_ray(const DevScene& s, const DevPaths& qo, size_t hit_index, size_t rq, bool live, f3 o, f3 d, float tfar, float shm,
+                     const StageCtx& cx = StageCtx(), int stage_slot = 0, int kind = 0) {
+  const TraceRec t = make_record(s, qo, hit_index, live, o, d, tfar, shm, cx);
+  if (!qo.has_bvh) return;                              // no trace kernel will run: the hit record is the whole answer
+  if (cx.stage) {
+    Rec4* const stage = cx.stage; const int stage_pitch = cx.stage_pitch;
+    stage[stage_slot] = t.r0; stage[stage_pitch + stage_slot] = t.r1; stage[2 * stage_pitch + stage_slot] = t.r2; stage[3 * stage_pitch + stage_slot] = t.r3;
     if (cx.stage_count > 0) {
-      // the lanes that emit (all of them are here: the call sits behind no data-dependent branch) copy their stage_count records out,
-      // 16 bytes per lane and pass, consecutive lanes to consecutive addresses.  LDS operations of one wave execute in order.
+      // k_shade_compact: the wave's stage_count emitting lanes are its lanes [0, stage_count) (sorted rounds: the survivors come first) and
+      // all of them are here -- the call sits behind no material branch.  They copy their records out, 16 bytes per lane and pass,
+      // consecutive lanes to consecutive addresses.  LDS operations of one wave execute in order.
       wave_fence();
       Rec4* out = qo.rec + 4 * cx.rec_base[kind];
       for (int it = 0; it < 4; ++it) { const int g = it * cx.stage_count + stage_slot; out[g] = stage[(g & 3) * stage_pitch + (g >> 2)]; }
@@ -356,7 +385,7 @@ ART_HD void emit_ray(const DevScene& s, const DevPaths& qo, size_t hit_index, si
     return;
   }
   Rec4* out = qo.rec + 4 * rq;
-  out[0] = r0; out[1] = r1; out[2] = r2; out[3] = r3;
+  out[0] = t.r0; out[1] = t.r1; out[2] = t.r2; out[3] = t.r3;
 }
 
 // ---------------------------------------------------------------- camera (ray_tracer.adb:61-97, integrators.adb:37-58)
@@ -402,14 +431,19 @@ ART_HD void raygen_slot(const DevFrame& f, const DevScene& s, const DevPaths& q,
 // (identity layout) this is the plain in-place update; all reads of an item happen before its writes.
 ART_HD int item_slot(const DevPaths& q, int w) { return q.slot_id ? (int)q.slot_id[w] : w; }
 
-// Will item w still need an item after shade_item(bounce)?  (It will if the path goes on, or if it emits a shadow ray whose test is
-// resolved at the next stage.)  Used to number the output items before shading; it must never say no where shade_item says yes --
-// shade_item reports that case (lost != nullptr) -- while a needless yes only costs an idle item.
-ART_HD bool item_survives(const DevFrame& f, const DevScene& s, const DevPaths& qi, int w, int bounce, const StageCtx& cx = StageCtx()) {
+// What shade_item(bounce) will do with item w, decided from the hit alone (flags, hit key, material type) before anything is shaded:
+// k_shade_compact sorts a workgroup's items by this class, so that a wave runs ONE material's code with (nearly) all its lanes -- measured
+// in round 4 on the unsorted kernel: 31 of 64 lanes enabled per VALU instruction; on C4 71 % of the waves ran the Phong path (four binary64
+// pow evaluations) for the 3 lanes that had hit the back wall, on C5 the glass and Phong paths ran at 10 of 64 lanes in 78 % of the waves.
+// CLS_CHEAP: the path ends here (not alive, a miss, a light, no material): nothing is sampled, nothing is emitted.  The other classes are the
+// surface materials; they survive the stage (need an output item) unless this is the last bounce of PT_STUPID -- shade_item reports an item
+// that survives against the prediction (lost != nullptr), a needless yes only costs an idle item.
+enum ItemCls : int32_t { CLS_LAMBERT = 0, CLS_PHONG = 1, CLS_GLASS = 2, CLS_MIRROR = 3, CLS_CHEAP = 4, kItemClasses = 5 };
+ART_HD int32_t item_class(const DevScene& s, const DevPaths& qi, int w, const StageCtx& cx = StageCtx()) {
   const uint32_t fl = qi.flags[w];
-  if (!(fl & FLAG_ALIVE)) return false;                       // only owed a shadow test: resolved now
+  if (!(fl & FLAG_ALIVE)) return CLS_CHEAP;                       // only owed a shadow test: resolved now
   const uint32_t key = qi.hit[w].key;
-  if (key == KEY_MISS) return false;
+  if (key == KEY_MISS) return CLS_CHEAP;
   const uint32_t cls = key & ~KEY_INDEX_MASK, idx = key & KEY_INDEX_MASK;
   int32_t mat;
   if (cls == KEY_SPHERE) mat = s.sphere_mat[idx];
@@ -417,15 +451,20 @@ ART_HD bool item_survives(const DevFrame& f, const DevScene& s, const DevPaths& 
   else if (cls == KEY_QUAD) mat = (cx.lights ? cx.lights : s.lights)[idx].mat;
   else if (cls == KEY_BFTRI) mat = 2;
   else mat = __builtin_bit_cast(int32_t, s.m_shade[(size_t)kTriShadeFloats * (size_t)idx + 9]);
-  if (mat < 0 || mat >= s.n_materials) return false;
+  if (mat < 0 || mat >= s.n_materials) return CLS_CHEAP;
   const int32_t type = (cx.materials ? cx.materials : s.materials)[mat].type;
-  if (type == MAT_NULL || type == MAT_LIGHT) return false;
-  return (f.render_type != PT_STUPID) || (bounce + 1 < f.max_depth);
+  return (type == MAT_LAMBERT) ? CLS_LAMBERT : (type == MAT_PHONG) ? CLS_PHONG : (type == MAT_GLASS) ? CLS_GLASS : (type == MAT_MIRROR) ? CLS_MIRROR : CLS_CHEAP;
+}
+ART_HD bool stage_keeps_surfaces(const DevFrame& f, int bounce) { return (f.render_type != PT_STUPID) || (bounce + 1 < f.max_depth); }
+ART_HD bool item_survives(const DevFrame& f, const DevScene& s, const DevPaths& qi, int w, int bounce, const StageCtx& cx = StageCtx()) {
+  return item_class(s, qi, w, cx) != CLS_CHEAP && stage_keeps_surfaces(f, bounce);
 }
 
 // Returns the number of rays the item emits (the closest-hit queries of the next trace: Mrays/s counts them).
+// defer != nullptr (and qo.rec): the trace records are left to the caller, who gets the rays in *defer.
 ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, const DevPaths& qo, int w, int wo, int bounce, unsigned long long* lost = nullptr,
-                      const StageCtx& cx = StageCtx()) {
+                      const StageCtx& cx = StageCtx(), RayOut* defer = nullptr) {
+  ART_PROBE(0);
   const int slot = item_slot(qi, w);
   const size_t P = (size_t)qi.P;
   uint32_t fl = qi.flags[w];
@@ -439,11 +478,13 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   const float t = hw.t, hu = hw.u, hv = hw.v;
   const float prev_pdf = qi.prev_pdf[w];
   if (fl & FLAG_SHADOW_PENDING) {
+    ART_PROBE(1);
     // Compute_Shadow: hit and t < maxDist - eps2 (enforced by the ray's tfar clip) and t > 10*eps
     const size_t si = P + (size_t)w;
     const DevHit hs = qi.hit[si];
     const bool in_shadow = (hs.key != KEY_MISS) && (hs.t > qi.sh_min_t[w]);
-    const size_t li = (size_t)(bounce - 1) * P + (size_t)slot;
+    // e of the previous level: at [bounce - 1][slot], or (dense fold records) at [bounce][w], this item's own index
+    const size_t li = qi.fold_dense ? (size_t)bounce * P + (size_t)w : (size_t)(bounce - 1) * P + (size_t)slot;
     qi.e_r[li] = in_shadow ? 0.0f : qi.cand_r[w];
     qi.e_g[li] = in_shadow ? 0.0f : qi.cand_g[w];
     qi.e_b[li] = in_shadow ? 0.0f : qi.cand_b[w];
@@ -455,19 +496,27 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   float s_tfar = -1.0f, sh_min = 0.0f, new_pdf = prev_pdf;
   f3 cand = mk3(0.0f, 0.0f, 0.0f);
   const f3 zero = mk3(0.0f, 0.0f, 0.0f);
+  // dense fold record of this item at this level (DevPaths::fold_dense): by default "the path ended here with value 0"
+  f3 rec_w = zero; int32_t rec_child = -1;
   auto kill = [&](int levels, f3 terminal) {       // the deepest PathTrace call returned `terminal`; `levels` fold levels were recorded
-    qi.term_r[slot] = terminal.x; qi.term_g[slot] = terminal.y; qi.term_b[slot] = terminal.z;
     fl = (fl & ~(FLAG_ALIVE | 0xffffff00u)) | ((uint32_t)levels << 8);
-    qi.final_flags[slot] = fl;
+    if (qi.fold_dense) { if (levels == bounce) { rec_w = terminal; rec_child = -1; } }     // levels == bounce + 1: a surface at the last bounce, its record stands
+    else {
+      qi.term_r[slot] = terminal.x; qi.term_g[slot] = terminal.y; qi.term_b[slot] = terminal.z;
+      qi.final_flags[slot] = fl;
+    }
     alive = false;
   };
   if (alive) {
+    ART_PROBE(2);
     const Surface sf = (key != KEY_MISS) ? surface_at(s, o, d, t, key, hu, hv, cx) : Surface{zero, -1, -1};
     const DevLight* const lights = cx.lights ? cx.lights : s.lights;
     const bool mat_ok = (key != KEY_MISS) && sf.mat >= 0 && sf.mat < s.n_materials;
     const DevMaterial m = mat_ok ? (cx.materials ? cx.materials : s.materials)[sf.mat] : DevMaterial{MAT_NULL, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
+    ART_PROBE(3);
     if (!mat_ok || m.type == MAT_NULL) kill(bounce, zero);                            // integrators.adb:218-220
     else if (m.type == MAT_LIGHT) {                                                   // :102-108 / :155-157 / :222-247
+      ART_PROBE(4);
       const f3 n = sf.normal;
       const float sel_pdf = 1.0f / (float)s.n_lights;
       f3 out = zero;
@@ -487,12 +536,13 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
       kill(bounce, out);
     } else {
       const f3 n = sf.normal;
+      ART_PROBE(5);
       const float sel_pdf = 1.0f / (float)s.n_lights;
       uint32_t pixel, sample;
       slot_to_sample(qi, slot, pixel, sample);
       const u4 rnd = philox4x32_10(pixel, sample, (uint32_t)bounce, 0u, f.seed_lo, f.seed_hi);
       const f3 hpos = o + d * t;
-      const size_t li = (size_t)bounce * P + (size_t)slot;
+      const size_t li = (size_t)bounce * P + (size_t)slot;      // this level's record by slot (fold_dense = 0)
       if (f.render_type != PT_STUPID) {                                                // explicit light sampling :159-178 / :251-287
         int light = 0;
         if (s.n_lights > 1) {
@@ -500,9 +550,11 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
           light = (int)(u01(r1.x) * (float)s.n_lights);
           if (light > s.n_lights - 1) light = s.n_lights - 1;
         }
+        ART_PROBE(6);
         const LightSample ls = light_sample(lights[light], u01(rnd.x), u01(rnd.y), hpos);
         const f3 sdir = normalize(ls.pos - hpos);
         const float lp = ls.pdf * sel_pdf;
+        ART_PROBE(7);
         f3 bx; float bp;
         bsdf_eval(m, sdir, neg(d), n, bx, bp);
         const float c1 = amax(dot(sdir, n), 0.0f);
@@ -525,20 +577,29 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
         sh_min = 10.0f * eps;
         shadow = true;
         fl |= FLAG_SHADOW_PENDING;
-      } else {
+      } else if (!qi.fold_dense) {
         qi.e_r[li] = 0.0f; qi.e_g[li] = 0.0f; qi.e_b[li] = 0.0f;
       }
+      ART_PROBE(8);
       const BsdfSample bs = bsdf_sample(m, u01(rnd.z), u01(rnd.w), d, n);                // :116-124 / :183-191 / :291-299
+      ART_PROBE(9);
       const f3 bxv = bs.color * (1.0f / amax(bs.pdf, kGEpsilonDiv));
       const float ct = dot(bs.dir, n);
       no = hpos + (asign(ct) * n) * kGEpsilon;
       nd = bs.dir;
       const f3 wv = fabsf(ct) * bxv;
-      qi.w_r[li] = wv.x; qi.w_g[li] = wv.y; qi.w_b[li] = wv.z;
+      if (qi.fold_dense) { rec_w = wv; rec_child = -2; }          // a surface: its successor's index is known below
+      else { qi.w_r[li] = wv.x; qi.w_g[li] = wv.y; qi.w_b[li] = wv.z; }
       new_pdf = bs.pdf;
       fl = bs.specular ? (fl | FLAG_PREV_SPEC) : (fl & ~FLAG_PREV_SPEC);
       if (bounce + 1 >= f.max_depth) kill(bounce + 1, zero);                             // next level returns 0 untraced (:212-214)
     }
+  }
+  ART_PROBE(40);
+  if (qi.fold_dense) {                                               // dense stores: consecutive items, consecutive addresses
+    const size_t lw = (size_t)bounce * P + (size_t)w;
+    qi.w_r[lw] = rec_w.x; qi.w_g[lw] = rec_w.y; qi.w_b[lw] = rec_w.z;
+    qi.child[lw] = (rec_child == -2 && wo >= 0) ? wo : rec_child;
   }
   // ---- the output item
   if (wo < 0) {
@@ -549,6 +610,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     }
     return 0;
   }
+  ART_PROBE(41);
   const size_t so_i = (size_t)qo.P + (size_t)wo;
   qo.flags[wo] = fl;
   qo.prev_pdf[wo] = new_pdf;
@@ -564,11 +626,14 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     // the item's rays go out as trace records, at positions given by the item index (REC_BOTH: 2 wo and 2 wo + 1).  A ray the bank's
     // mode has no record for cannot exist (the modes follow the integrator: art_api.cpp); should it ever, the self-check counts it.
     const int mode = qo.rec_mode;
-    const int per = (mode == REC_BOTH) ? 2 : 1;
-    // (staged by k_shade_compact: each kind of ray is its own contiguous block of the wave's records, copied out before the next kind is staged)
-    const bool blocks = cx.stage_count > 0;
-    if (mode != REC_SHADOW) emit_ray(s, qo, (size_t)wo, rec_slot(mode, wo, false), alive, no, nd, kInfinity, -1.0f, cx, blocks ? cx.stage_item : per * cx.stage_item, 0);
-    if (mode != REC_EXT) emit_ray(s, qo, so_i, rec_slot(mode, wo, true), shadow, so, sd, s_tfar, qo.shadow_rule ? sh_min : -1.0f, cx, blocks ? cx.stage_item : per * cx.stage_item + (per - 1), 1);
+    if (defer) {
+      defer->alive = alive; defer->shadow = shadow; defer->no = no; defer->nd = nd; defer->so = so; defer->sd = sd; defer->s_tfar = s_tfar; defer->sh_min = sh_min;
+    } else {
+      const int per = (mode == REC_BOTH) ? 2 : 1;
+      const bool blocks = cx.stage_count > 0;      // k_shade_compact: each kind of ray is its own contiguous block of the wave's records
+      if (mode != REC_SHADOW) emit_ray(s, qo, (size_t)wo, rec_slot(mode, wo, false), alive, no, nd, kInfinity, -1.0f, cx, blocks ? cx.stage_item : per * cx.stage_item, 0);
+      if (mode != REC_EXT) emit_ray(s, qo, so_i, rec_slot(mode, wo, true), shadow, so, sd, s_tfar, qo.shadow_rule ? sh_min : -1.0f, cx, blocks ? cx.stage_item : per * cx.stage_item + (per - 1), 1);
+    }
     if (lost != nullptr && ((mode == REC_SHADOW && alive) || (mode == REC_EXT && shadow))) {
 #if defined(__HIP_DEVICE_COMPILE__)
       atomicAdd(lost, 1ull);
@@ -596,7 +661,7 @@ ART_HD void resolve_last_shadow(const DevPaths& q, int w, int last_level) {
   const size_t si = (size_t)q.P + (size_t)w;
   const DevHit hs = q.hit[si];
   const bool in_shadow = (hs.key != KEY_MISS) && (hs.t > q.sh_min_t[w]);
-  const size_t li = (size_t)last_level * (size_t)q.P + (size_t)slot;
+  const size_t li = q.fold_dense ? (size_t)(last_level + 1) * (size_t)q.P + (size_t)w : (size_t)last_level * (size_t)q.P + (size_t)slot;
   q.e_r[li] = in_shadow ? 0.0f : q.cand_r[w];
   q.e_g[li] = in_shadow ? 0.0f : q.cand_g[w];
   q.e_b[li] = in_shadow ? 0.0f : q.cand_b[w];
@@ -614,6 +679,29 @@ ART_HD void fold_slot(const DevFrame& f, const DevPaths& q, int slot) {
     else L = mk3(q.e_r[li], q.e_g[li], q.e_b[li]) + w * L;
   }
   q.rad_r[slot] = L.x; q.rad_g[slot] = L.y; q.rad_b[slot] = L.z;
+}
+
+// The same fold over dense records (DevPaths::fold_dense), one level per call from the deepest up: item w of bounce `level` gets
+//   L = its path's terminal value (child -1),  or  e_level + w_level * L(child)   -- L(child) = 0 at the deepest level and for child -2 --
+// read from `nxt` (the level below, indexed by that level's items) and written to `cur`.  Level 0's items are the slots: its `cur` is rad.
+// The operations on a path's values are those of fold_slot in the same order, so the bits are the same.
+ART_HD void fold_level_item(const DevFrame& f, const DevPaths& q, int level, int w, bool deepest,
+                            const float* nxt_r, const float* nxt_g, const float* nxt_b, float* cur_r, float* cur_g, float* cur_b) {
+  const size_t lw = (size_t)level * (size_t)q.P + (size_t)w;
+  const int32_t c = q.child[lw];
+  f3 L = mk3(q.w_r[lw], q.w_g[lw], q.w_b[lw]);
+  if (c != -1) {
+    const f3 wv = L;
+    const bool has = (c >= 0);
+    const f3 Ln = (has && !deepest) ? mk3(nxt_r[c], nxt_g[c], nxt_b[c]) : mk3(0.0f, 0.0f, 0.0f);
+    if (f.render_type == PT_STUPID) L = wv * Ln;
+    else {
+      const size_t le = (size_t)(level + 1) * (size_t)q.P + (size_t)(has ? c : 0);
+      const f3 ev = has ? mk3(q.e_r[le], q.e_g[le], q.e_b[le]) : mk3(0.0f, 0.0f, 0.0f);
+      L = ev + wv * Ln;
+    }
+  }
+  cur_r[w] = L.x; cur_g[w] = L.y; cur_b[w] = L.z;
 }
 
 ART_HD void finish_slot(const DevFrame& f, const DevPaths& q, int slot, int last_level) {     // plain layout: both steps per slot

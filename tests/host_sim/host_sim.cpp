@@ -58,6 +58,10 @@ extern "C" int hs_trace(const ArtSceneDesc* sd, const float* o, const float* d, 
 
 static int g_rank = 0, g_nranks = 1, g_tile = 32;
 extern "C" void hs_set_shard(int rank, int nranks, int tile) { g_rank = rank; g_nranks = nranks; g_tile = tile; }
+// 1: fold over dense per-level records (DevPaths::fold_dense, what the GPU's compacted schedule does; here with the identity layout, where an
+// item's index is its slot at every level) instead of the slot-indexed fold stack
+static int g_fold_dense = 0;
+extern "C" void hs_set_fold_dense(int on) { g_fold_dense = on; }
 
 extern "C" int hs_render(const ArtSceneDesc* sd, const ArtPassParams* p, int w, int h, int spp0, float* accum /*row-major*/,
                          unsigned long long* rays_out) {
@@ -80,6 +84,12 @@ extern "C" int hs_render(const ArtSceneDesc* sd, const ArtPassParams* p, int w, 
   q.e_r = take(D * pp); q.e_g = take(D * pp); q.e_b = take(D * pp); q.w_r = take(D * pp); q.w_g = take(D * pp); q.w_b = take(D * pp);
   q.term_r = take(pp); q.term_g = take(pp); q.term_b = take(pp); q.rad_r = take(pp); q.rad_g = take(pp); q.rad_b = take(pp);
   q.slot_id = nullptr; q.final_flags = q.flags;            // identity layout: one item per slot, updated in place
+  std::vector<float> ebuf; std::vector<int32_t> childbuf;
+  if (g_fold_dense) {                                      // e needs one level more (e_k sits at level k + 1), plus the child links
+    ebuf.assign((size_t)3 * (D + 1) * pp, 0.0f); childbuf.assign((size_t)D * pp, -7);
+    q.e_r = ebuf.data(); q.e_g = q.e_r + (D + 1) * pp; q.e_b = q.e_g + (D + 1) * pp;
+    q.child = childbuf.data(); q.fold_dense = 1;
+  }
   unsigned long long rays = 0;
   auto trace = [&](int nr) {
 #pragma omp parallel for schedule(dynamic, 1024) reduction(+ : rays)
@@ -99,8 +109,19 @@ extern "C" int hs_render(const ArtSceneDesc* sd, const ArtPassParams* p, int w, 
     for (int s = 0; s < P; ++s) shade_slot(F, hs.hdr, q, s, b);
   }
   if (p->render_type != ART_PT_STUPID) trace(2 * P);
+  if (g_fold_dense) {
 #pragma omp parallel for
-  for (int s = 0; s < P; ++s) finish_slot(F, q, s, D - 1);
+    for (int s = 0; s < P; ++s) resolve_last_shadow(q, s, D - 1);
+    for (int k = D - 1; k >= 0; --k) {                     // art_kernels.hip launch_fold_levels: odd levels -> term, even levels -> rad
+      float* cur[3] = {(k & 1) ? q.term_r : q.rad_r, (k & 1) ? q.term_g : q.rad_g, (k & 1) ? q.term_b : q.rad_b};
+      const float* nxt[3] = {(k & 1) ? q.rad_r : q.term_r, (k & 1) ? q.rad_g : q.term_g, (k & 1) ? q.rad_b : q.term_b};
+#pragma omp parallel for
+      for (int s = 0; s < P; ++s) fold_level_item(F, q, k, s, k == D - 1, nxt[0], nxt[1], nxt[2], cur[0], cur[1], cur[2]);
+    }
+  } else {
+#pragma omp parallel for
+    for (int s = 0; s < P; ++s) finish_slot(F, q, s, D - 1);
+  }
 #pragma omp parallel for
   for (int pl = 0; pl < npix; ++pl) accumulate_pixel(F, q, pl, S, accum);
   if (rays_out) *rays_out = rays;

@@ -22,6 +22,11 @@ def lib(art):
     return _lib
 
 
+def set_fold_dense(art, on):
+    """1: the fold over dense per-level records (the GPU's compacted schedule), 0: the slot-indexed fold stack"""
+    lib(art).hs_set_fold_dense(int(on))
+
+
 def set_shard(art, rank, nranks, tile=32):
     lib(art).hs_set_shard(rank, nranks, tile)
 

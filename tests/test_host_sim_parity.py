@@ -28,6 +28,26 @@ def test_wavefront_pipeline_equals_recursive_oracle(art, cornell, rt, aa):
     assert np.array_equal(bits(acc), bits(ref)) and rays == cnt.rays
 
 
+@pytest.mark.parametrize("rt", ["PT_MIS", "PT_SHADOW", "PT_STUPID"])
+@pytest.mark.parametrize("depth", [1, 2, 8])
+def test_dense_fold_records_give_the_recursion_s_bits(art, cornell, rt, depth):
+    """Round 4: the GPU's compacted schedule keeps the fold stack as dense per-level records (weight or terminal value + link to the item of
+    the next bounce, e_k one level down; art_shade.h fold_level_item) and folds level by level from the deepest up.  Same operations on a
+    path's values in the same order as the recursion: the same bits as the oracle, for every integrator and at depths 1, 2 and 8
+    (glass, Phong, Lambert, light hits, misses, paths cut at the depth limit) -- and as the slot-indexed fold stack."""
+    cs, sd = cornell
+    p = art.Backend.pass_params(getattr(art, rt), True, depth, 2, seed=5, background=(0.02, 0.03, 0.05))
+    plain, rays0 = hostsim.render(art, sd, p, 40, 36)
+    hostsim.set_fold_dense(art, 1)
+    try:
+        acc, rays = hostsim.render(art, sd, p, 40, 36)
+    finally:
+        hostsim.set_fold_dense(art, 0)
+    ref, _, cnt = orc.render(cs.scene, orc.make_params(40, 36, getattr(orc, rt), True, depth, 2, seed=5, background=(0.02, 0.03, 0.05)))
+    assert rays == cnt.rays == rays0
+    assert np.array_equal(bits(acc), bits(ref)) and np.array_equal(bits(plain), bits(ref))
+
+
 @pytest.mark.parametrize("depth", [1, 2, 5])
 def test_max_trace_depth(art, cornell, depth):
     cs, sd = cornell
