@@ -732,6 +732,9 @@ constexpr int kShadePerThread = ART_SHADE_PER;
 #ifndef ART_SHADE_DEFER
 #define ART_SHADE_DEFER 0         // 1: the kernel builds and copies the records after shade_item, at a wave-uniform point (costs 30 more VGPRs: spills at 6 waves per SIMD, +25 % launch time); 0: shade_item's own emit_ray does (round 3)
 #endif
+#ifndef ART_SHADE_HINT
+#define ART_SHADE_HINT 1          // 1: the classification's key and material index go along to shade_item (all of an item's loads start at once)
+#endif
 #ifndef ART_SHADE_SORT
 #define ART_SHADE_SORT 0          // 1: sort the items of a round by material class (see above); 0: input order (one class for all surfaces)
 #endif
@@ -745,21 +748,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
                                                        const int* __restrict__ n_in_ptr, int* __restrict__ n_out_ptr, uint32_t* __restrict__ slot_out,
                                                        unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b) {
   constexpr int kShadeChunk = 256 * PER;
-  static_assert(kShadeChunk <= 65536, "s_perm holds 16-bit positions");
   __shared__ int s_tot[PER * kItemClasses];                // items of each class in each round (256 items) of the chunk
   __shared__ int s_base, s_rays;
   __shared__ int s_nall[PER], s_nkeep[PER], s_out0[PER];   // per round: items, survivors, first output item (relative to s_base)
-  __shared__ uint16_t s_perm[kShadeChunk];                 // [round][sorted position] -> thread that classified the item
+  // [round][sorted position] -> { hit key, thread that classified the item | surface flag << 8 | material index << 9 }: what the
+  // classification fetched goes along (ItemHint), so that shade_item asks for the triangle's normals and the material record at once
+  __shared__ uint2 s_hint[kShadeChunk];
   // a wave's trace records of one kind, [quarter][record] (+1: four consecutive records' quarters fall into four banks)
   constexpr int kStagePitch = 64 + 1;
   __shared__ Rec4 s_stage[4][4 * kStagePitch];
+  constexpr int kShadeLdsLights = 8;                    // (8, not k_analytic's 16: with the hints the workgroup's LDS must stay below 160 KB / 6)
   __shared__ DevSphere s_sph[kAnalyticLdsSpheres];      // the scene's spheres and lights, fetched once per workgroup (every emitted ray is tested against them)
-  __shared__ DevLight s_lgt[kAnalyticLdsLights];
+  __shared__ DevLight s_lgt[kShadeLdsLights];
   const int n_in = n_in_ptr ? *n_in_ptr : Qi.P;
   const int c0 = blockIdx.x * kShadeChunk;
   if (c0 >= n_in) return;                                // the grid covers Qi.P items; the work set has shrunk to n_in
   // (the material table stays in global memory: a 40-byte per-lane-indexed record out of LDS measured 7 % slower than the cached global read)
-  const bool tables_in_lds = (S.n_spheres <= kAnalyticLdsSpheres) && (S.n_lights <= kAnalyticLdsLights);
+  const bool tables_in_lds = (S.n_spheres <= kAnalyticLdsSpheres) && (S.n_lights <= kShadeLdsLights);
   if (tables_in_lds) {
     if ((int)threadIdx.x < S.n_spheres) s_sph[threadIdx.x] = S.spheres[threadIdx.x];
     if ((int)threadIdx.x < S.n_lights) s_lgt[threadIdx.x] = S.lights[threadIdx.x];
@@ -772,11 +777,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t lanes_below = (1ull << lane) - 1ull;
   // ---- 1. classify; a wave's items of one class take consecutive places in the class (of their round)
-  int cls[PER], rank[PER];
+  int cls[PER], rank[PER]; ItemHint hint[PER];
 #pragma unroll      // the PER classifications are independent chains of loads (flags, hit -> triangle record -> material): issued together (-6 %)
   for (int k = 0; k < PER; ++k) {
     const int w = c0 + k * 256 + threadIdx.x;
-    int c = (w < n_in) ? item_class(S, Qi, w, tables) : kItemClasses;
+    hint[k].key = KEY_MISS; hint[k].mat = 0;
+    int c = (w < n_in) ? item_class(S, Qi, w, tables, &hint[k]) : kItemClasses;
+    const bool surface = c < CLS_CHEAP;
+    hint[k].mat = (int32_t)(threadIdx.x | (surface ? 256u : 0u) | ((uint32_t)hint[k].mat << 9));
     if (!ART_SHADE_SORT && c < CLS_CHEAP) c = CLS_LAMBERT;
     cls[k] = c; rank[k] = 0;
 #pragma unroll
@@ -808,7 +816,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
     }
     if (threadIdx.x == 0) { s_nall[k] = st; s_nkeep[k] = nkeep; s_out0[k] = total_keep; }
     total_keep += nkeep;
-    if (cls[k] < kItemClasses) s_perm[k * 256 + mine + rank[k]] = (uint16_t)threadIdx.x;
+    if (cls[k] < kItemClasses) s_hint[k * 256 + mine + rank[k]] = make_uint2(hint[k].key, (uint32_t)hint[k].mat);
   }
   if (threadIdx.x == 0) s_base = total_keep ? atomicAdd(n_out_ptr, total_keep) : 0;
   __syncthreads();
@@ -826,9 +834,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
     const int wo = keep ? base + out0_k + r : -1;
     RayOut ro; ro.alive = false; ro.shadow = false; ro.no = ro.nd = ro.so = ro.sd = mk3(0.0f, 0.0f, 0.0f); ro.s_tfar = -1.0f; ro.sh_min = 0.0f;
     if (r < n_all_k) {
-      const int w = c0 + k * 256 + (int)s_perm[k * 256 + r];
+      const uint2 hk = s_hint[k * 256 + r];
+      const int w = c0 + k * 256 + (int)(hk.y & 255u);
+      ItemHint ih; ih.key = hk.x; ih.mat = (int32_t)(hk.y >> 9);
+      const ItemHint* const hp = (ART_SHADE_HINT && (hk.y & 256u)) ? &ih : nullptr;
       if (keep) slot_out[wo] = (uint32_t)item_slot(Qi, w);
-      if (ART_SHADE_DEFER) n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cx, &ro);
+      if (ART_SHADE_DEFER) n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cx, &ro, hp);
       else {
         StageCtx cy = tables;
         if (staged) {
@@ -837,7 +848,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
           cy.stage = s_stage[wave]; cy.stage_pitch = kStagePitch; cy.stage_item = lane; cy.stage_count = nk;
           cy.rec_base[0] = first; cy.rec_base[1] = (per == 2) ? first + (size_t)nk : first;
         }
-        n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cy);
+        n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cy, nullptr, hp);
       }
     }
     if (ART_SHADE_DEFER && Qo.rec != nullptr) {

@@ -30,6 +30,11 @@ struct StageCtx {
 // ray at a time and copies it out at a point every lane of the wave reaches).
 struct RayOut { bool alive, shadow; f3 no, nd, so, sd; float s_tfar, sh_min; };
 
+// Diagnostic builds only (wrong pictures; profiles/r4_shade/sensitivity.txt): -DART_DIAG_SKIP=<bits> leaves out one kind of the stage's traffic --
+// 1 trace-record copy-out, 2 the triangle-normal gather, 4 the next ray as SoA words, 8 the hit-record (starting bound) stores, 16 the fold records
+#ifndef ART_DIAG_SKIP
+#define ART_DIAG_SKIP 0
+#endif
 ART_HD void wave_fence() {
 #if defined(__HIP_DEVICE_COMPILE__)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -286,7 +291,10 @@ ART_HD void bsdf_eval(const DevMaterial& m, f3 l, f3 v, f3 n, f3& bxdf, float& p
 // ---------------------------------------------------------------- hit record -> shading frame
 struct Surface { f3 normal; int32_t mat; int32_t mat_id; };
 
-ART_HD Surface surface_at(const DevScene& s, f3 o, f3 d, float t, uint32_t key, float u, float v, const StageCtx& cx = StageCtx()) {
+// pre.on: the three vertex normals of a BVH-mesh triangle's shading record, already fetched (shade_item's hinted path)
+struct PreNormals { f3 a, b, c; bool on; };
+ART_HD Surface surface_at(const DevScene& s, f3 o, f3 d, float t, uint32_t key, float u, float v, const StageCtx& cx = StageCtx(),
+                          const PreNormals pre = PreNormals{{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, false}) {
   Surface sf;
   const uint32_t cls = key & ~KEY_INDEX_MASK, idx = key & KEY_INDEX_MASK;
   if (cls == KEY_SPHERE) {                                      // geometry.adb:88,95-96
@@ -306,6 +314,9 @@ ART_HD Surface surface_at(const DevScene& s, f3 o, f3 d, float t, uint32_t key, 
       const float* nr = s.bf_nrm;
       sf.normal = (w * ld3(nr + 3 * (size_t)ix[0]) + v * ld3(nr + 3 * (size_t)ix[1])) + u * ld3(nr + 3 * (size_t)ix[2]);
       sf.mat_id = 2;                                            // geometry.adb:311 hard-codes 2
+    } else if (pre.on) {
+      sf.normal = (w * pre.a + v * pre.b) + u * pre.c;
+      sf.mat_id = -1;                                                          // the caller has the material index from its hint
     } else {
       const float* r = s.m_shade + (size_t)kTriShadeFloats * (size_t)idx;      // the triangle's own record: normals of A, B, C and the material id
       sf.normal = (w * ld3(r) + v * ld3(r + 3)) + u * ld3(r + 6);
@@ -346,7 +357,7 @@ ART_HD TraceRec make_record(const DevScene& s, const DevPaths& qo, size_t hit_in
   if (live) {
     ART_PROBE(31);
     const Cand best = analytic_bound(s, cx, o, d, tfar);
-    qo.hit[hit_index] = DevHit{best.t, best.key, best.u, best.v};
+    if (!(ART_DIAG_SKIP & 8)) qo.hit[hit_index] = DevHit{best.t, best.key, best.u, best.v};
     const bool near_done = (shm >= 0.0f) && (best.key != KEY_MISS) && (best.t <= shm);       // shadow_rule: decided
     if (!near_done && qo.has_bvh) {
       ART_PROBE(32);
@@ -379,7 +390,7 @@ ART_HD void emit_ray(const DevScene& s, const DevPaths& qo, size_t hit_index, si
       // consecutive lanes to consecutive addresses.  LDS operations of one wave execute in order.
       wave_fence();
       Rec4* out = qo.rec + 4 * cx.rec_base[kind];
-      for (int it = 0; it < 4; ++it) { const int g = it * cx.stage_count + stage_slot; out[g] = stage[(g & 3) * stage_pitch + (g >> 2)]; }
+      if (!(ART_DIAG_SKIP & 1)) for (int it = 0; it < 4; ++it) { const int g = it * cx.stage_count + stage_slot; out[g] = stage[(g & 3) * stage_pitch + (g >> 2)]; }
       wave_fence();
     }
     return;
@@ -439,7 +450,10 @@ ART_HD int item_slot(const DevPaths& q, int w) { return q.slot_id ? (int)q.slot_
 // surface materials; they survive the stage (need an output item) unless this is the last bounce of PT_STUPID -- shade_item reports an item
 // that survives against the prediction (lost != nullptr), a needless yes only costs an idle item.
 enum ItemCls : int32_t { CLS_LAMBERT = 0, CLS_PHONG = 1, CLS_GLASS = 2, CLS_MIRROR = 3, CLS_CHEAP = 4, kItemClasses = 5 };
-ART_HD int32_t item_class(const DevScene& s, const DevPaths& qi, int w, const StageCtx& cx = StageCtx()) {
+// What the classification has already fetched for a SURFACE item (class < CLS_CHEAP): its hit key and its material index (in range, a
+// surface material).  shade_item starts every load of the item from it at once instead of walking hit -> triangle record -> material.
+struct ItemHint { uint32_t key; int32_t mat; };
+ART_HD int32_t item_class(const DevScene& s, const DevPaths& qi, int w, const StageCtx& cx = StageCtx(), ItemHint* hint = nullptr) {
   const uint32_t fl = qi.flags[w];
   if (!(fl & FLAG_ALIVE)) return CLS_CHEAP;                       // only owed a shadow test: resolved now
   const uint32_t key = qi.hit[w].key;
@@ -453,6 +467,7 @@ ART_HD int32_t item_class(const DevScene& s, const DevPaths& qi, int w, const St
   else mat = __builtin_bit_cast(int32_t, s.m_shade[(size_t)kTriShadeFloats * (size_t)idx + 9]);
   if (mat < 0 || mat >= s.n_materials) return CLS_CHEAP;
   const int32_t type = (cx.materials ? cx.materials : s.materials)[mat].type;
+  if (hint) { hint->key = key; hint->mat = mat; }
   return (type == MAT_LAMBERT) ? CLS_LAMBERT : (type == MAT_PHONG) ? CLS_PHONG : (type == MAT_GLASS) ? CLS_GLASS : (type == MAT_MIRROR) ? CLS_MIRROR : CLS_CHEAP;
 }
 ART_HD bool stage_keeps_surfaces(const DevFrame& f, int bounce) { return (f.render_type != PT_STUPID) || (bounce + 1 < f.max_depth); }
@@ -462,15 +477,31 @@ ART_HD bool item_survives(const DevFrame& f, const DevScene& s, const DevPaths& 
 
 // Returns the number of rays the item emits (the closest-hit queries of the next trace: Mrays/s counts them).
 // defer != nullptr (and qo.rec): the trace records are left to the caller, who gets the rays in *defer.
+// hint != nullptr: the item is a surface item and *hint holds its hit key and material index (k_shade_compact's classification): the
+// triangle's normals and the material record are then requested together with the item's own words, one round trip instead of three
+// dependent ones (hit -> triangle shading record -> material).
 ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, const DevPaths& qo, int w, int wo, int bounce, unsigned long long* lost = nullptr,
-                      const StageCtx& cx = StageCtx(), RayOut* defer = nullptr) {
+                      const StageCtx& cx = StageCtx(), RayOut* defer = nullptr, const ItemHint* hint = nullptr) {
   ART_PROBE(0);
   const int slot = item_slot(qi, w);
   const size_t P = (size_t)qi.P;
   uint32_t fl = qi.flags[w];
   // ---- everything the item holds is read first
   const DevHit hw = qi.hit[w];
-  const uint32_t key = hw.key;
+  const uint32_t key = hint ? hint->key : hw.key;
+  PreNormals pre_n = PreNormals{{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, false};
+  DevMaterial pre_m = DevMaterial{MAT_NULL, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
+  if (hint) {
+    pre_m = (cx.materials ? cx.materials : s.materials)[hint->mat];
+    if (!(ART_DIAG_SKIP & 2) && (hint->key & ~KEY_INDEX_MASK) == KEY_TRI) {
+      const float* r = s.m_shade + (size_t)kTriShadeFloats * (size_t)(hint->key & KEY_INDEX_MASK);
+      pre_n.a = ld3(r); pre_n.b = ld3(r + 3); pre_n.c = ld3(r + 6); pre_n.on = true;
+    }
+  }
+  // the shadow test the item may owe (its words exist for every item; asked for now, used below if the flag says so)
+  const bool may_owe = (bounce > 0) && (f.render_type != PT_STUPID);
+  DevHit hs = DevHit{0.0f, KEY_MISS, 0.0f, 0.0f}; float owed_min = 0.0f; f3 owed = mk3(0.0f, 0.0f, 0.0f);
+  if (may_owe) { hs = qi.hit[P + (size_t)w]; owed_min = qi.sh_min_t[w]; owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
   // (the extension ray is kept as six SoA words next to its trace record: reading it back out of the record would pull the whole
   // 128-byte line of the item's two records for 24 useful bytes)
   const f3 o = mk3(qi.ray_ox[w], qi.ray_oy[w], qi.ray_oz[w]);
@@ -480,14 +511,13 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   if (fl & FLAG_SHADOW_PENDING) {
     ART_PROBE(1);
     // Compute_Shadow: hit and t < maxDist - eps2 (enforced by the ray's tfar clip) and t > 10*eps
-    const size_t si = P + (size_t)w;
-    const DevHit hs = qi.hit[si];
-    const bool in_shadow = (hs.key != KEY_MISS) && (hs.t > qi.sh_min_t[w]);
+    if (!may_owe) { hs = qi.hit[P + (size_t)w]; owed_min = qi.sh_min_t[w]; owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
+    const bool in_shadow = (hs.key != KEY_MISS) && (hs.t > owed_min);
     // e of the previous level: at [bounce - 1][slot], or (dense fold records) at [bounce][w], this item's own index
     const size_t li = qi.fold_dense ? (size_t)bounce * P + (size_t)w : (size_t)(bounce - 1) * P + (size_t)slot;
-    qi.e_r[li] = in_shadow ? 0.0f : qi.cand_r[w];
-    qi.e_g[li] = in_shadow ? 0.0f : qi.cand_g[w];
-    qi.e_b[li] = in_shadow ? 0.0f : qi.cand_b[w];
+    qi.e_r[li] = in_shadow ? 0.0f : owed.x;
+    qi.e_g[li] = in_shadow ? 0.0f : owed.y;
+    qi.e_b[li] = in_shadow ? 0.0f : owed.z;
     fl &= ~FLAG_SHADOW_PENDING;
   }
   // ---- what the output item will hold
@@ -509,10 +539,10 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   };
   if (alive) {
     ART_PROBE(2);
-    const Surface sf = (key != KEY_MISS) ? surface_at(s, o, d, t, key, hu, hv, cx) : Surface{zero, -1, -1};
+    const Surface sf = (key != KEY_MISS) ? surface_at(s, o, d, t, key, hu, hv, cx, pre_n) : Surface{zero, -1, -1};
     const DevLight* const lights = cx.lights ? cx.lights : s.lights;
-    const bool mat_ok = (key != KEY_MISS) && sf.mat >= 0 && sf.mat < s.n_materials;
-    const DevMaterial m = mat_ok ? (cx.materials ? cx.materials : s.materials)[sf.mat] : DevMaterial{MAT_NULL, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
+    const bool mat_ok = hint ? true : ((key != KEY_MISS) && sf.mat >= 0 && sf.mat < s.n_materials);
+    const DevMaterial m = hint ? pre_m : (mat_ok ? (cx.materials ? cx.materials : s.materials)[sf.mat] : DevMaterial{MAT_NULL, 0, {0, 0, 0, 0, 0, 0, 0, 0}});
     ART_PROBE(3);
     if (!mat_ok || m.type == MAT_NULL) kill(bounce, zero);                            // integrators.adb:218-220
     else if (m.type == MAT_LIGHT) {                                                   // :102-108 / :155-157 / :222-247
@@ -596,7 +626,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     }
   }
   ART_PROBE(40);
-  if (qi.fold_dense) {                                               // dense stores: consecutive items, consecutive addresses
+  if (qi.fold_dense && !(ART_DIAG_SKIP & 16)) {                      // dense stores: consecutive items, consecutive addresses
     const size_t lw = (size_t)bounce * P + (size_t)w;
     qi.w_r[lw] = rec_w.x; qi.w_g[lw] = rec_w.y; qi.w_b[lw] = rec_w.z;
     qi.child[lw] = (rec_child == -2 && wo >= 0) ? wo : rec_child;
@@ -618,7 +648,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     qo.sh_min_t[wo] = sh_min;
     qo.cand_r[wo] = cand.x; qo.cand_g[wo] = cand.y; qo.cand_b[wo] = cand.z;
   }
-  if (alive) {
+  if (alive && !(ART_DIAG_SKIP & 4)) {
     qo.ray_ox[wo] = no.x; qo.ray_oy[wo] = no.y; qo.ray_oz[wo] = no.z;
     qo.ray_dx[wo] = nd.x; qo.ray_dy[wo] = nd.y; qo.ray_dz[wo] = nd.z;
   }
