@@ -103,7 +103,7 @@ EXPORTED_SYMBOLS = [
     "art_debug_hit_pass", "art_bind_accum", "art_accum_device", "art_download", "art_synchronize", "art_trace_rays",
     "art_export_bvh", "art_get_stats", "art_set_option", "art_last_error", "art_shutdown",
     "gcore_init_and_clear", "gcore_destroy", "gcore_add_mesh_3f", "gcore_instance_meshes", "gcore_commit_scene",
-    "gcore_closest_hit", "gcore_closest_hit_n", "gcore_set_two_level",
+    "gcore_closest_hit", "gcore_closest_hit_n", "gcore_set_two_level", "gcore_set_single_ray_on_gpu",
 ]
 
 

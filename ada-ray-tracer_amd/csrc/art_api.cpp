@@ -741,7 +741,7 @@ int art_init(int device_ordinal) {
 
 // One process, n GPUs (SURVEY 8e / 8b "Threading": the Ada host calls Render_Pass from its environment task, test.adb:50, so the
 // fan-out over the node's GPUs has to happen below the C ABI).  ordinals == NULL: devices 0..n-1.  Every device gets its own
-// context, stream, replicated scene and path buffers; device k owns the 32x32 pixel tiles with tile_id mod n == k; art_render_pass /
+// context, stream, replicated scene and path buffers; device k owns the 32x32 pixel tiles (bx, by) with (bx + 3 by) mod n == k (diagonals: build_pixmap); art_render_pass /
 // art_download add the float3 framebuffers into device 0 with ONE RCCL reduce over xGMI.  Listing the same ordinal several times puts
 // several contexts on one GPU (a rehearsal of the whole path on a 1-GPU box; the reduce is then a local sum).
 int art_init_devices(int32_t n, const int32_t* ordinals) {
@@ -856,6 +856,25 @@ int art_export_bvh(float* nodes, int64_t node_cap, float* tris, int64_t tri_cap,
   if (tris) { if (tri_cap < (int64_t)b.tris.size()) return fail("art_export_bvh: triangle buffer too small"); std::memcpy(tris, b.tris.data(), b.tris.size() * 4); }
   return 0;
 }
+
+}  // extern "C"
+namespace art {
+// the uploaded tree of device 0 as host arrays (the packets art_export_bvh returns); the caller holds g_mu
+int fetch_host_bvh(std::vector<float>& nodes, std::vector<float>& tris, int& width, int& n_tris) {
+  Ctx& c = g_devs[0];
+  if (!c.scene_ready) return fail("no scene uploaded");
+  Bvh8& b = c.host_scene.bvh;
+  width = b.width; n_tris = b.n_tris;
+  if (c.host_scene.gpu_built && b.nodes.empty()) {
+    nodes.resize((size_t)b.n_nodes * node_floats(b.width)); tris.resize((size_t)b.n_tris * kTriFloats);
+    if (use_dev(0)) return 1;
+    HIP_TRY(hipMemcpy(nodes.data(), c.b_nodes.p, nodes.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tris.data(), c.b_tris.p, tris.size() * 4, hipMemcpyDeviceToHost));
+  } else { nodes = b.nodes; tris = b.tris; }
+  return 0;
+}
+}  // namespace art
+extern "C" {
 
 int art_get_stats(ArtStats* out) {
   std::lock_guard<std::mutex> lk(g_mu);

@@ -71,5 +71,6 @@ int upload_scene(const ArtSceneDesc* d);
 int resize(int w, int h);
 int trace_rays(const float* origins, const float* dirs, const float* tfar, int64_t n, ArtHit* out, int kernel, ArtStats* st);
 void shutdown();
+int fetch_host_bvh(std::vector<float>& nodes, std::vector<float>& tris, int& width, int& n_tris);   // device 0's tree as host arrays (caller holds g_mu)
 
 }  // namespace art

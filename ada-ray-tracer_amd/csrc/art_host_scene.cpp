@@ -101,9 +101,15 @@ std::vector<uint32_t> build_pixmap(int W, int H, int rank, int nranks, int T) {
   std::vector<uint32_t> pm;
   pm.reserve((size_t)W * H / (size_t)(nranks > 0 ? nranks : 1) + 1024);
   const int tx = (W + T - 1) / T, ty = (H + T - 1) / T;
+  // The deal: tile (bx, by) belongs to rank (bx + s by) mod n, s odd and coprime to n -- diagonals, whatever the frame width.  Rounds 1-3
+  // dealt tile_id mod n: with a frame of 128 tiles per row (4096 pixels) and n = 8 that is bx mod 8, i.e. every rank owns full-height
+  // COLUMNS of tiles, and a bright object a column or two wide lands on one rank: 2.7 % (max over mean) on C5 in the per-rank rehearsal
+  // of round 4 (profiles/r4_scaling.json), 1.6 % on C4 whose 60 tiles per row shift the columns by 4 from row to row.
+  const int n = nranks > 0 ? nranks : 1;
+  const int skew = (n % 3 != 0) ? 3 : (n % 5 != 0) ? 5 : 7;
   for (int by = 0; by < ty; ++by)
     for (int bx = 0; bx < tx; ++bx) {
-      if ((by * tx + bx) % nranks != rank) continue;
+      if ((bx + skew * by) % n != rank) continue;
       for (int y = by * T; y < (H < (by + 1) * T ? H : (by + 1) * T); ++y)
         for (int x = bx * T; x < (W < (bx + 1) * T ? W : (bx + 1) * T); ++x) pm.push_back((uint32_t)(y * W + x));
     }

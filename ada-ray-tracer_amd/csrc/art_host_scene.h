@@ -28,7 +28,7 @@ struct HostScene {
 
 bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& out, std::string& err);
 
-// pixel ownership for multi-GPU sharding: tile x tile pixel tiles dealt round-robin, tile_id % nranks == rank.
+// pixel ownership for multi-GPU sharding: tile x tile pixel tiles dealt along diagonals, (bx + s by) % nranks == rank (s = 3, or 5 / 7 when 3 divides nranks).
 // Returns the global pixel indices (y*W + x) owned by `rank`, in tile order.
 std::vector<uint32_t> build_pixmap(int W, int H, int rank, int nranks, int tile);
 

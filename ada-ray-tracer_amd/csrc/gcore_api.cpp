@@ -10,8 +10,11 @@
 // with hit = (1-u-v) v0 + u v1 + v v2.  Two-sidedness is obtained by uploading each triangle in both
 // windings (the kernel's Moeller-Trumbore test is the reference's one-sided one, geometry.adb:243).
 //
-// gcore_closest_hit is the per-ray compatibility path (SURVEY 8b "per-ray fallback for debugging"); the frame-level
-// art_render_pass is the fast path.  Concurrent callers are combined into one launch; gcore_closest_hit_n takes a batch.
+// gcore_closest_hit is the per-ray compatibility path (SURVEY 8b "per-ray fallback for debugging": "host BVH walk or batched queue");
+// the frame-level art_render_pass is the fast path.  Round 4: a single-ray call walks the committed tree ON THE CALLING THREAD (the
+// reference calls it from up to 28 Ada tasks, one ray each, and Embree answers on the caller's core: embree_connect.cpp:196-238) --
+// the same tree, the same published walk and the same triangle arithmetic as the GPU kernels, so the same hits, bit for bit; no launch,
+// no lock beyond a shared one against a concurrent commit.  gcore_closest_hit_n (the batch form) stays on the GPU.
 // The scene committed here REPLACES the art_* scene of the process (one backend singleton, like g_data in embree_connect.cpp:12-22):
 // a process uses either seam at a time.
 #include <algorithm>
@@ -20,6 +23,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -61,7 +65,12 @@ struct GState {
   std::vector<float> wverts;   // world-space vertices of every instance, 3 per vertex
   std::vector<int32_t> widx;
   TwoLevel two;
+  // the committed flattened tree on the host (binary32 node packets + triangle records, as art_export_bvh returns them): what a
+  // single-ray gcore_closest_hit walks.  (Two-level scenes walk two.host, which the build left on the host anyway.)
+  std::vector<float> h_nodes, h_tris; int h_width = 4, h_ntris = 0;
 } g;
+// single-ray queries hold it shared, commit / destroy exclusively (the reference has no such guard: it commits before it renders)
+std::shared_mutex g_scene_rw;
 
 template <typename T> bool to_device(void** p, const std::vector<T>& v) {
   if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -91,6 +100,7 @@ bool build_two_level(std::string& err) {
 extern "C" {
 
 void gcore_destroy(void) {
+  std::unique_lock<std::shared_mutex> wr(g_scene_rw);
   std::lock_guard<std::mutex> lk(art::g_mu);
   g.two.release();
   g = GState();
@@ -107,6 +117,7 @@ void gcore_init_and_clear(void) {
 }
 
 int gcore_add_mesh_3f(const float* a_vertices3f, int a_vertexNum, const int* a_indices, int a_indicesNum) {
+  std::unique_lock<std::shared_mutex> wr(g_scene_rw);
   std::lock_guard<std::mutex> lk(art::g_mu);
   if (!a_vertices3f || !a_indices || a_vertexNum <= 0 || a_indicesNum < 3) {
     std::printf("[c_gcore]: gcore_add_mesh_3f, bad arguments\n");
@@ -127,6 +138,7 @@ int gcore_add_mesh_3f(const float* a_vertices3f, int a_vertexNum, const int* a_i
 }
 
 void gcore_instance_meshes(int a_geomId, const float* a_matrices16f, int a_matrixNum) {
+  std::unique_lock<std::shared_mutex> wr(g_scene_rw);
   std::lock_guard<std::mutex> lk(art::g_mu);
   if (a_geomId < 0 || a_geomId >= (int)g.meshes.size() || !a_matrices16f) {
     std::printf("gcore_instance_meshes, bad meshId = %d\n", a_geomId);
@@ -141,8 +153,10 @@ void gcore_instance_meshes(int a_geomId, const float* a_matrices16f, int a_matri
 }
 
 void gcore_commit_scene(void) {
+  std::unique_lock<std::shared_mutex> wr(g_scene_rw);
   std::lock_guard<std::mutex> lk(art::g_mu);
-  g.tri_inst.clear(); g.tri_prim.clear(); g.wverts.clear(); g.widx.clear();
+  g.committed = false;
+  g.tri_inst.clear(); g.tri_prim.clear(); g.wverts.clear(); g.widx.clear(); g.h_nodes.clear(); g.h_tris.clear(); g.h_ntris = 0;
   g.two.release(); g.two.on = false;
   const bool two_level = (g_force_two_level == 1) || (g_force_two_level < 0 && (int)g.insts.size() >= kTwoLevelMinInstances);
   if (two_level) {                       // embree_connect.cpp:147-184: one tree per mesh, instances on top
@@ -181,6 +195,7 @@ void gcore_commit_scene(void) {
   sd.n_lights = 1; sd.lights = &light; sd.n_materials = 1; sd.materials = &mat; sd.n_meshes = 1; sd.meshes = &mesh;
   sd.cam_matrix[0] = sd.cam_matrix[5] = sd.cam_matrix[10] = sd.cam_matrix[15] = 1.0f;
   if (art::upload_scene(&sd)) { std::printf("[c_gcore]: %s\n", art_last_error()); return; }
+  if (art::fetch_host_bvh(g.h_nodes, g.h_tris, g.h_width, g.h_ntris)) { std::printf("[c_gcore]: %s\n", art_last_error()); return; }
   g.committed = true;
 }
 
@@ -196,15 +211,13 @@ std::condition_variable q_cv;
 std::vector<Req*> q_pending;
 bool q_leader = false;
 
-void fill_hit(const ArtHit& h, float tn, Req& r) {
-  r.found = false;
-  if (!h.is_hit || h.prim_type != 2) return;
-  const int32_t k = h.prim_index >> 1; const bool flipped = (h.prim_index & 1) != 0;
-  HitCpp* pHit = r.out;
+// a hit of the flattened upload -> HitCpp.  prim_index: the uploaded triangle (2k front winding, 2k + 1 back winding of input triangle k)
+void fill_flat(int32_t prim_index, float t, float hu, float hv, float tn, HitCpp* pHit) {
+  const int32_t k = prim_index >> 1; const bool flipped = (prim_index & 1) != 0;
   pHit->primIndex = g.tri_prim[k];
   pHit->geomIndex = 0;                 // each mesh scene holds a single geometry (embree_connect.cpp:139)
   pHit->instIndex = g.tri_inst[k];
-  pHit->t = h.t + tn;
+  pHit->t = t + tn;
   const int32_t* ix = &g.widx[6 * (size_t)k];
   const float* A = &g.wverts[3 * (size_t)ix[0]]; const float* B = &g.wverts[3 * (size_t)ix[1]]; const float* C = &g.wverts[3 * (size_t)ix[2]];
   const float e1[3] = { B[0] - A[0], B[1] - A[1], B[2] - A[2] }, e2[3] = { C[0] - A[0], C[1] - A[1], C[2] - A[2] };
@@ -212,10 +225,65 @@ void fill_hit(const ArtHit& h, float tn, Req& r) {
   pHit->normal[1] = e1[2] * e2[0] - e1[0] * e2[2];
   pHit->normal[2] = e1[0] * e2[1] - e1[1] * e2[0];
   // kernel barycentrics: v = weight of its 2nd vertex, u = weight of its 3rd (geometry.adb:245-246)
-  pHit->texCoord[0] = flipped ? h.u : h.v;   // weight of v1
-  pHit->texCoord[1] = flipped ? h.v : h.u;   // weight of v2
+  pHit->texCoord[0] = flipped ? hu : hv;   // weight of v1
+  pHit->texCoord[1] = flipped ? hv : hu;   // weight of v2
+}
+void fill_hit(const ArtHit& h, float tn, Req& r) {
+  r.found = false;
+  if (!h.is_hit || h.prim_type != 2) return;
+  fill_flat(h.prim_index, h.t, h.u, h.v, tn, r.out);
   r.found = true;
 }
+// a hit of the two-level search -> HitCpp
+void fill_two_level(const art::InstHit& h, float tn, HitCpp* pHit) {
+  const TwoLevel& T = g.two;
+  const art::InstRec& R = T.host.inst[(size_t)h.inst];
+  const GMesh& gm = g.meshes[(size_t)R.mesh];
+  const int32_t tri = h.prim >> 1; const bool flipped = (h.prim & 1) != 0;
+  const GInst& gi = g.insts[(size_t)g.tri_inst[(size_t)h.inst]];
+  pHit->primIndex = tri; pHit->geomIndex = 0; pHit->instIndex = g.tri_inst[(size_t)h.inst];
+  pHit->t = h.t + tn;
+  // Ng of the instanced triangle in WORLD space: cross of the transformed edges (what the flattened upload reports)
+  float w[3][3];
+  for (int c = 0; c < 3; ++c) {
+    const float* v = &gm.verts[3 * (size_t)gm.idx[3 * (size_t)tri + c]];
+    for (int rr = 0; rr < 3; ++rr) w[c][rr] = gi.m[4 * rr] * v[0] + gi.m[4 * rr + 1] * v[1] + gi.m[4 * rr + 2] * v[2] + gi.m[4 * rr + 3];
+  }
+  const float e1[3] = {w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2]}, e2[3] = {w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2]};
+  pHit->normal[0] = e1[1] * e2[2] - e1[2] * e2[1]; pHit->normal[1] = e1[2] * e2[0] - e1[0] * e2[2]; pHit->normal[2] = e1[0] * e2[1] - e1[1] * e2[0];
+  pHit->texCoord[0] = flipped ? h.u : h.v; pHit->texCoord[1] = flipped ? h.v : h.u;
+}
+
+// ---- one ray on the calling thread: the published walk of art_isect.h (bvh_closest / instanced_closest compile for the host) over the
+// committed tree.  Same boxes (the binary32 packets ARE the dequantised nodes the GPU kernel tests), same Moeller-Trumbore arithmetic
+// (-ffp-contract=off, the slab's fma is a real fma on both sides), the hit is a lexicographic minimum: the GPU's answer, bit for bit.
+// Two bodies of the same source: one built for CPUs with FMA3 (every x86-64 host of an MI355X has it), one generic (fmaf through libm).
+static inline __attribute__((always_inline)) bool host_walk_body(const float* pos, const float* dir, float t_near, float t_far, HitCpp* pHit) {
+  if (!g.committed || !pos || !dir || !pHit) return false;
+  const float t0 = (t_near > 0.0f) ? t_near : 0.0f;
+  const float f = t_far - t0;
+  if (!(f > 0.0f)) return false;
+  const art::f3 d = art::mk3(dir[0], dir[1], dir[2]);
+  const art::f3 o = art::mk3(pos[0] + t0 * dir[0], pos[1] + t0 * dir[1], pos[2] + t0 * dir[2]);
+  if (g.two.on) {
+    const art::InstHit h = art::instanced_closest(g.two.host.view(), o, d, f);
+    if (h.inst < 0) return false;
+    fill_two_level(h, t0, pHit);
+    return true;
+  }
+  art::DevScene view;                                            // only these four members are read by bvh_closest
+  view.node_width = g.h_width; view.n_tris = g.h_ntris; view.nodes = g.h_nodes.data(); view.tris = g.h_tris.data();
+  art::Cand c = art::cand_init(f);
+  art::ShadowState sh; sh.shm = -1.0f; sh.far = false; sh.rep = c;
+  art::bvh_closest<false>(view, o, d, c, nullptr, sh);
+  if (c.key == art::KEY_MISS || (c.key & ~art::KEY_INDEX_MASK) != art::KEY_TRI) return false;
+  fill_flat((int32_t)(c.key & art::KEY_INDEX_MASK), c.t, c.u, c.v, t0, pHit);
+  return true;
+}
+__attribute__((target("fma"))) bool host_walk_fma(const float* pos, const float* dir, float t_near, float t_far, HitCpp* pHit) { return host_walk_body(pos, dir, t_near, t_far, pHit); }
+bool host_walk_generic(const float* pos, const float* dir, float t_near, float t_far, HitCpp* pHit) { return host_walk_body(pos, dir, t_near, t_far, pHit); }
+const bool g_cpu_has_fma = __builtin_cpu_supports("fma") != 0;
+int g_force_gpu_single = 0;          // gcore_set_single_ray_on_gpu (tests): 1 = the flat-combined GPU launches of rounds 2-3
 
 // answers reqs[0..n) with ONE launch (art_trace_rays without statistics: no events, no counter read-back)
 void run_batch(Req* const* reqs, size_t n) {
@@ -261,22 +329,7 @@ void run_batch(Req* const* reqs, size_t n) {
       Req& r = *reqs[who[k]];
       const art::InstHit& h = ih[k];
       if (h.inst < 0) continue;
-      const art::InstRec& R = T.host.inst[(size_t)h.inst];
-      const GMesh& gm = g.meshes[(size_t)R.mesh];
-      const int32_t tri = h.prim >> 1; const bool flipped = (h.prim & 1) != 0;
-      const GInst& gi = g.insts[(size_t)g.tri_inst[(size_t)h.inst]];
-      HitCpp* pHit = r.out;
-      pHit->primIndex = tri; pHit->geomIndex = 0; pHit->instIndex = g.tri_inst[(size_t)h.inst];
-      pHit->t = h.t + tn[k];
-      // Ng of the instanced triangle in WORLD space: cross of the transformed edges (what the flattened upload reports)
-      float w[3][3];
-      for (int c = 0; c < 3; ++c) {
-        const float* v = &gm.verts[3 * (size_t)gm.idx[3 * (size_t)tri + c]];
-        for (int rr = 0; rr < 3; ++rr) w[c][rr] = gi.m[4 * rr] * v[0] + gi.m[4 * rr + 1] * v[1] + gi.m[4 * rr + 2] * v[2] + gi.m[4 * rr + 3];
-      }
-      const float e1[3] = {w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2]}, e2[3] = {w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2]};
-      pHit->normal[0] = e1[1] * e2[2] - e1[2] * e2[1]; pHit->normal[1] = e1[2] * e2[0] - e1[0] * e2[2]; pHit->normal[2] = e1[0] * e2[1] - e1[1] * e2[0];
-      pHit->texCoord[0] = flipped ? h.u : h.v; pHit->texCoord[1] = flipped ? h.v : h.u;
+      fill_two_level(h, tn[k], r.out);
       r.found = true;
     }
     return;
@@ -287,7 +340,14 @@ void run_batch(Req* const* reqs, size_t n) {
 
 }  // namespace
 
+// 1: single-ray calls ride flat-combined GPU launches as in rounds 2-3 (kept for A/B and for the parity test host == GPU); 0: host walk
+void gcore_set_single_ray_on_gpu(int on) { std::unique_lock<std::shared_mutex> wr(g_scene_rw); g_force_gpu_single = on; }
+
 bool gcore_closest_hit(const float a_rayPos[3], const float a_rayDir[3], float t_near, float t_far, HitCpp* pHit) {
+  {
+    std::shared_lock<std::shared_mutex> rd(g_scene_rw);
+    if (!g_force_gpu_single) return g_cpu_has_fma ? host_walk_fma(a_rayPos, a_rayDir, t_near, t_far, pHit) : host_walk_generic(a_rayPos, a_rayDir, t_near, t_far, pHit);
+  }
   Req me; me.pos = a_rayPos; me.dir = a_rayDir; me.t_near = t_near; me.t_far = t_far; me.out = pHit; me.found = false; me.done = false;
   std::unique_lock<std::mutex> lk(q_mu);
   q_pending.push_back(&me);

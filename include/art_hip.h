@@ -130,7 +130,7 @@ typedef struct ArtBvhInfo { int32_t n_nodes, n_tris, max_stack, node_width; doub
 
 int  art_init(int device_ordinal);                       /* -1: keep the current HIP device */
 /* One process, n GPUs of the node (the Ada host calls Render_Pass from one task: ray_tracer.adb:240-293, test.adb:50).  ordinals ==
- * NULL: devices 0..n-1.  Scene and BVH are replicated, device k owns the 32x32 pixel tiles with tile_id mod n == k, and the float3
+ * NULL: devices 0..n-1.  Scene and BVH are replicated, device k owns the 32x32 pixel tiles (bx, by) with (bx + 3 by) mod n == k, and the float3
  * framebuffers are added into device 0 by ONE RCCL reduce over xGMI whenever the image is asked for (art_render_pass with host
  * pointers, art_download, art_reduce).  The image is bit-identical for any n.  Call INSTEAD of art_init; art_set_stream /
  * art_set_shard / art_bind_accum are single-device calls and fail afterwards.  Repeating one ordinal n times rehearses the whole
@@ -141,7 +141,7 @@ int  art_reduce(void);                                   /* enqueue the framebuf
 int  art_set_stream(void* hip_stream);                   /* hipStream_t; NULL = default stream */
 int  art_upload_scene(const ArtSceneDesc* scene);        /* Scene.Init: flatten + BVH build + copy to HBM */
 int  art_resize(int32_t width, int32_t height);          /* Resize_Viewport (ray_tracer.adb:297-320): zero accum, spp := 0 */
-int  art_set_shard(int32_t rank, int32_t nranks, int32_t tile);   /* pixel tiles (tile x tile) dealt round-robin over ranks */
+int  art_set_shard(int32_t rank, int32_t nranks, int32_t tile);   /* pixel tiles (tile x tile) dealt along diagonals over the ranks */
 
 /* One Render_Pass.  accum_host (float3 per pixel) and screen_host (u32 per pixel) may be NULL; when given
  * they receive the cumulative accum buffer and the resolved LDR image in p->layout.  *spp_inout is g_spp. */
@@ -200,6 +200,11 @@ _Bool gcore_closest_hit(const float a_rayPos[3], const float a_rayDir[3], float 
  * like Embree's instance geometries, embree_connect.cpp:147-184; below that every instance is flattened into one world-space mesh),
  * 0 always flatten, 1 always two-level. */
 void gcore_set_two_level(int mode);
+/* Where a single-ray gcore_closest_hit is answered: 0 (default, round 4) on the calling thread -- a host walk of the committed tree, the
+ * same tree, walk and triangle arithmetic as the GPU kernels, so the same hit bit for bit: what the reference's call pattern needs (28
+ * tasks, one ray each: scene_hydra_embree.adb:426-446; Embree's rtcIntersect1 also runs on the caller's core, embree_connect.cpp:218);
+ * 1: concurrent callers are combined into shared GPU launches (rounds 2-3; kept for A/B and for the host == GPU parity test). */
+void gcore_set_single_ray_on_gpu(int on);
 /* Batch form (extension; no counterpart in embree_connect.cpp): t_near / t_far may be NULL for 0 / 1e5; returns the number of hits. */
 int  gcore_closest_hit_n(int a_rayNum, const float* a_rayPos3f, const float* a_rayDir3f, const float* t_near, const float* t_far,
                          HitCpp* pHits, unsigned char* pFound);

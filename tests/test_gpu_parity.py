@@ -466,10 +466,48 @@ def test_gcore_queries_combine_and_batch(art, backend):
     nh = L.gcore_closest_hit_n(n, o.ctypes.data_as(art.f32p), d.ctypes.data_as(art.f32p), None, None, hits, found)
     t_batch = (time.perf_counter() - t0) / n
     batch = [(True, hits[i].primIndex, hits[i].instIndex, hits[i].t, tuple(hits[i].normal), tuple(hits[i].texCoord)) if found[i] else (False,) for i in range(n)]
-    assert batch == out and nh == sum(1 for s in out if s[0])
-    print("gcore queries/s: serial %.0f, 28 threads %.0f, batch of %d %.0f" % (1 / t_serial, 1 / t_threads, n, 1 / t_batch))
-    assert t_batch * 50 < t_serial, "a batch must cost far less per ray than one launch per ray"
+    assert batch == out and nh == sum(1 for s in out if s[0])            # the host walk of a single ray == the GPU batch, every field, bit for bit
+    print("gcore queries/s through ctypes: serial %.0f, 28 threads %.0f, batch of %d %.0f" % (1 / t_serial, 1 / t_threads, n, 1 / t_batch))
+    # the flat-combined GPU launches of rounds 2-3 (gcore_set_single_ray_on_gpu): the same answers again, and far slower per ray than a batch
+    L.gcore_set_single_ray_on_gpu(1)
+    try:
+        t0 = time.perf_counter(); on_gpu = [query(i) for i in range(100)]; t_gpu1 = (time.perf_counter() - t0) / 100
+        out2 = [None] * n
+
+        def worker2(k):
+            for i in range(k, n, 28):
+                out2[i] = query(i)
+        ts = [threading.Thread(target=worker2, args=(k,)) for k in range(28)]
+        [t.start() for t in ts]; [t.join() for t in ts]
+    finally:
+        L.gcore_set_single_ray_on_gpu(0)
+    assert on_gpu == serial[:100] and out2 == out
+    assert t_batch * 50 < t_gpu1, "a batch must cost far less per ray than one launch per ray"
+    assert t_serial * 5 < t_gpu1, "the host walk must beat a launch per ray"
     L.gcore_destroy()
+
+
+@pytest.mark.parametrize("instances", [1, 64])
+def test_gcore_single_ray_calls_serve_the_reference_s_call_pattern(art, backend, instances):
+    """scene_hydra_embree.adb:426-446 calls gcore_closest_hit once per ray from up to 28 tasks; Embree answers on the caller's core
+    (embree_connect.cpp:218).  host/gcore_bench.cpp does the same natively (ctypes would measure the GIL): 28 threads x one ray per call
+    on a 200k-triangle soup (flattened upload) and on 64 instances of a 20k-triangle mesh (two-level scene), against ONE GPU batch of the
+    same rays: every HitCpp the same bytes, and at least a million queries per second (round 3: 18 k/s)."""
+    import json
+    import os
+    import subprocess
+    backend.shutdown()                                   # the harness is its own process with its own backend
+    exe = os.path.join(art.PKG_DIR, "gcore_bench")
+    args = [exe, "200000", "400000", "28", "1"] if instances == 1 else [exe, "20000", "400000", "28", "64"]
+    try:
+        res = subprocess.run(args, capture_output=True, text=True, timeout=280)
+    finally:
+        backend.__init__(0)
+    assert res.returncode == 0, res.stdout + res.stderr
+    d = json.loads(res.stdout.strip().splitlines()[-1])
+    print(d)
+    assert d["different_from_gpu_batch"] == 0 and d["hits"] == d["batch_hits"] and d["hits"] > d["rays"] // 10
+    assert d["threads_queries_per_s"] >= 1.0e6
 
 
 def test_gcore_two_level_instancing_matches_the_flattened_scene(art, backend):
