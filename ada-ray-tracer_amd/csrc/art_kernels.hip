@@ -845,7 +845,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
         if (staged) {
           const int nk = min(64, max(0, n_keep_k - wave * 64)), per = (Qo.rec_mode == REC_BOTH) ? 2 : 1;
           const size_t first = (size_t)per * (size_t)(base + out0_k + wave * 64);
-          cy.stage = s_stage[wave]; cy.stage_pitch = kStagePitch; cy.stage_item = lane; cy.stage_count = nk;
+          cy.stage = s_stage[wave]; cy.stage_pitch = kStagePitch; cy.stage_item = lane; cy.stage_count = nk; cy.lost = lost;
           cy.rec_base[0] = first; cy.rec_base[1] = (per == 2) ? first + (size_t)nk : first;
         }
         n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cy, nullptr, hp);

@@ -81,6 +81,7 @@ struct Args {
   const int2* chunk; int2* chunk_next;                           // chunk -> (active index, chunk number inside the node)
   Dec* dec; S4* flags; const S4* offs;
   int* gbins;                                                    // [big slot][3][NB][kBinWords]
+  int* err;                                                      // device error word: set when a partition does not match its bins (read by the host every level)
   int* chunk_cnt; const int* chunk_off;                          // lefts per chunk, exclusive sums
   S4* totals;
   SahCost P;
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void k_eval(const Args A, int m) {
 #pragma unroll
     for (int k = 0; k < 24; ++k) acc[k] = ((k % 6) < 3) ? wave_min_i(acc[k]) : wave_max_i(acc[k]);
     for (int k = 0; k < 6; ++k) { d.lbox[k] = acc[k]; d.lcb[k] = acc[6 + k]; d.rbox[k] = acc[12 + k]; d.rcb[k] = acc[18 + k]; }
-    if (run_l != nl) d.kind = -1;                                                  // cannot happen: the bins and the partition apply the same expression
+    if (run_l != nl && lane == 0) atomicExch(A.err, 1);                            // cannot happen (the bins and the partition apply the same expression); if it ever does the host fails the build
   }
   if (lane == 0) {
     A.dec[i] = d;
@@ -385,6 +386,8 @@ __global__ __launch_bounds__(256) void k_part_write(const Args A) {
     }
     run_l += tl; run_r += tr;
   }
+  // the node's last chunk: its lefts must add up to what the bins said (k_eval's d.nl), else children would overlap or lose references
+  if (threadIdx.x == 0 && (cd.y + 1) * kChunk >= count && run_l != d.nl) atomicExch(A.err, 1);
 #pragma unroll
   for (int k = 0; k < 24; ++k) {
     const int v = ((k % 6) < 3) ? wave_min_i(acc[k]) : wave_max_i(acc[k]);
@@ -516,19 +519,20 @@ bool build_bvh_sah_gpu(const float* d_tri9, int n, const BvhBuildParams& prm, hi
   P.node_cost = prm.node_cost; P.leaf_base = prm.leaf_base; P.tri_cost = prm.tri_cost >= 0.0f ? prm.tri_cost : (prm.width == 4 ? 0.2f : 0.05f);
   const size_t N2 = 2 * (size_t)n;                                                 // BVH2 nodes: at most 2n - 1
   const int max_big = n / kChunk + 2, max_chunks = n / kChunk + 2 * max_big + 2;
+  const size_t max_active = (size_t)n / 2 + 1;                                     // an active node holds at least two references (Dec alone is 128 B per entry: ADVICE r3)
   const int bin_words = 3 * P.nb * kBinWords;
   Scratch S;
   float4 *rlo[2], *rhi[2]; Nodes N; Act* act[2]; int2* chunk[2]; Dec* dec; S4 *flags, *offs, *totals; int *gbins, *chunk_cnt, *chunk_off, *misc;
   Item* items[2]; Kids* kids; int *n_inner, *inner_off;
   if (!S.get(&rlo[0], n, err) || !S.get(&rlo[1], n, err) || !S.get(&rhi[0], n, err) || !S.get(&rhi[1], n, err) ||
       !S.get(&N.blo, N2, err) || !S.get(&N.bhi, N2, err) || !S.get(&N.clo, N2, err) || !S.get(&N.chi, N2, err) || !S.get(&N.child, N2, err) ||
-      !S.get(&act[0], n, err) || !S.get(&act[1], n, err) || !S.get(&chunk[0], max_chunks, err) || !S.get(&chunk[1], max_chunks, err) ||
-      !S.get(&dec, n, err) || !S.get(&flags, n, err) || !S.get(&offs, n, err) || !S.get(&totals, 1, err) ||
+      !S.get(&act[0], max_active, err) || !S.get(&act[1], max_active, err) || !S.get(&chunk[0], max_chunks, err) || !S.get(&chunk[1], max_chunks, err) ||
+      !S.get(&dec, max_active, err) || !S.get(&flags, max_active, err) || !S.get(&offs, max_active, err) || !S.get(&totals, 1, err) ||
       !S.get(&gbins, (size_t)max_big * bin_words, err) || !S.get(&chunk_cnt, max_chunks, err) || !S.get(&chunk_off, max_chunks, err) || !S.get(&misc, 8, err) ||
       !S.get(&items[0], n, err) || !S.get(&items[1], n, err) || !S.get(&kids, n, err) || !S.get(&n_inner, n, err) || !S.get(&inner_off, n, err))
     return false;
   size_t tmp_a = 0, tmp_b = 0;
-  SB_TRY(hipcub::DeviceScan::ExclusiveScan(nullptr, tmp_a, flags, offs, S4Sum(), S4{0, 0, 0, 0}, n, st));
+  SB_TRY(hipcub::DeviceScan::ExclusiveScan(nullptr, tmp_a, flags, offs, S4Sum(), S4{0, 0, 0, 0}, (int)max_active, st));
   SB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_b, n_inner, inner_off, n, st));
   void* tmp = nullptr;
   const size_t tmp_bytes = std::max(tmp_a, tmp_b);
@@ -562,7 +566,7 @@ bool build_bvh_sah_gpu(const float* d_tri9, int n, const BvhBuildParams& prm, hi
     A.N = N; A.rlo_in = rlo[cur]; A.rhi_in = rhi[cur]; A.rlo_out = rlo[nxt]; A.rhi_out = rhi[nxt];
     A.act = act[cur]; A.act_next = act[nxt]; A.chunk = chunk[cur]; A.chunk_next = chunk[nxt];
     A.dec = dec; A.flags = flags; A.offs = offs; A.gbins = gbins; A.chunk_cnt = chunk_cnt; A.chunk_off = chunk_off; A.totals = totals;
-    A.P = P; A.node_base = n_nodes2;
+    A.P = P; A.node_base = n_nodes2; A.err = misc + 2;
     if (n_big > max_big || n_chunks > max_chunks) { err = "internal: GPU SAH chunk plan out of bounds"; return false; }
     if (n_chunks > 0) {
       const int gw = n_big * bin_words;
@@ -579,18 +583,15 @@ bool build_bvh_sah_gpu(const float* d_tri9, int n, const BvhBuildParams& prm, hi
       SB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, chunk_cnt, chunk_off, n_chunks, st));
       hipLaunchKernelGGL(k_part_write, dim3(n_chunks), dim3(256), 0, st, A);
     }
-    S4 t;
+    S4 t; int h_misc[8];
     SB_TRY(hipMemcpyAsync(&t, totals, sizeof t, hipMemcpyDeviceToHost, st));
-    SB_TRY(hipStreamSynchronize(st));
-    n_nodes2 += 2 * t.s; m = t.a; n_chunks = t.c; n_big = t.b;
-    if ((size_t)n_nodes2 > N2 || m > n) { err = "internal: GPU SAH node count out of bounds"; return false; }
-    if (++level > 4096) { err = "internal: GPU SAH build did not terminate"; return false; }
-  }
-  {
-    int h_misc[8];
-    SB_TRY(hipMemcpyAsync(h_misc, misc, sizeof h_misc, hipMemcpyDeviceToHost, st));
+    SB_TRY(hipMemcpyAsync(h_misc, misc, sizeof h_misc, hipMemcpyDeviceToHost, st));      // the error words travel with every level's round trip
     SB_TRY(hipStreamSynchronize(st));
     if (h_misc[0]) { err = "non-finite triangle vertex, or a coordinate beyond 1e18 (box extents and the node quantisation need headroom in binary32)"; return false; }
+    if (h_misc[2]) { err = "internal: GPU SAH partition does not match its bins"; return false; }
+    n_nodes2 += 2 * t.s; m = t.a; n_chunks = t.c; n_big = t.b;
+    if ((size_t)n_nodes2 > N2 || (size_t)m > max_active) { err = "internal: GPU SAH node count out of bounds"; return false; }
+    if (++level > 4096) { err = "internal: GPU SAH build did not terminate"; return false; }
   }
   // triangle records: position p of the final reference order
   SB_TRY(hipMalloc(&out.tris, (size_t)n * kTriFloats * sizeof(float)));

@@ -33,7 +33,9 @@ struct alignas(16) Rec4 { float x, y, z, w; };
 // given by the item index -- no queue, no atomics, no separate pass over the rays):
 //   REC_NONE    the plain layout: rays as SoA arrays, k_analytic prepares the queue (one-ray-per-lane schedule, host simulation, debug pass)
 //   REC_EXT     one extension ray per item, record w            (after raygen; PT_STUPID)
-//   REC_BOTH    extension ray at record 2w, shadow ray at 2w+1  (the two rays of a surface point next to each other in the queue)
+//   REC_BOTH    k_shade_compact: per wave and round, the extension rays of its nk kept items as one block of nk records, then their nk
+//               shadow rays (the two rays of a surface point within 64 records of each other in the queue); the unstaged path of
+//               the host simulation: extension ray at record 2w, shadow ray at 2w + 1 (rec_slot)
 //   REC_SHADOW  one shadow ray per item, record w               (after the last bounce: the path itself has ended)
 enum RecMode : int32_t { REC_NONE = 0, REC_EXT = 1, REC_BOTH = 2, REC_SHADOW = 3 };
 
@@ -126,9 +128,11 @@ struct DevPaths {
   int32_t* child;               // [max_depth][P]
   int32_t fold_dense;
   // Trace records of this bank's rays (round 3), 4 x Rec4 per record, or nullptr (REC_NONE: the SoA ray arrays above are used).
-  // A stage reads the extension ray of its input item from the input bank's records ({origin, .} {direction, .}: the first two
-  // quarters) and writes the records of the rays it emits -- analytic primitives already intersected (the starting bound), slab set-up
-  // done -- straight into the output bank's, where the trace kernel picks them up in item order.
+  // WRITE-ONLY for the stages: both banks point at ONE record array (a bank's records are dead once its rays are traced), so a stage
+  // that read its input item's record would race with the records other workgroups are writing for the output bank -- a stage reads
+  // the extension ray from the six SoA words of its input bank instead.  A stage writes the records of the rays it emits -- analytic
+  // primitives already intersected (the starting bound), slab set-up done -- where the trace kernel picks them up in item order; a
+  // record names its hit slot itself (r3.y), so its position in the array carries no meaning beyond the order.
   Rec4* rec;
   int32_t rec_mode;             // RecMode of `rec`
   int32_t shadow_rule;          // shadow rays carry Compute_Shadow's 10*eps so that the search may use the visibility rule (option shadow_anyhit)

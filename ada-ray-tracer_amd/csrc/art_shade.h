@@ -24,6 +24,7 @@ struct StageCtx {
   // k_shade_compact: stage_count > 0 lanes of the wave emit together (stage_item = this lane's rank among them) and copy the records out
   // themselves, one kind of ray at a time; rec_base[0 / 1]: first record of the wave's extension / shadow rays in the output bank
   int stage_count = 0; size_t rec_base[2] = {0, 0};
+  unsigned long long* lost = nullptr;          // the self-check counter (ArtStats::lost_paths): a staged record read before its lane wrote it is counted there
 };
 
 // The rays an item leaves a bounce with, for a caller that writes the trace records itself (k_shade_compact: the wave stages one kind of
@@ -390,7 +391,18 @@ ART_HD void emit_ray(const DevScene& s, const DevPaths& qo, size_t hit_index, si
       // consecutive lanes to consecutive addresses.  LDS operations of one wave execute in order.
       wave_fence();
       Rec4* out = qo.rec + 4 * cx.rec_base[kind];
-      if (!(ART_DIAG_SKIP & 1)) for (int it = 0; it < 4; ++it) { const int g = it * cx.stage_count + stage_slot; out[g] = stage[(g & 3) * stage_pitch + (g >> 2)]; }
+      // the copy-out relies on every emitting lane having staged its record before any lane reads it, i.e. on the compiler
+      // keeping this call at ONE place that all of them reach together.  Checked at run time: the last quarter of record q of the wave
+      // must name hit slot (first item + q) of this kind, else the stage counts a lost path (tests assert the counter stays 0).
+      const uint32_t hit0 = (uint32_t)hit_index - (uint32_t)stage_slot; (void)hit0;
+      if (!(ART_DIAG_SKIP & 1)) for (int it = 0; it < 4; ++it) {
+        const int g = it * cx.stage_count + stage_slot;
+        const Rec4 v = stage[(g & 3) * stage_pitch + (g >> 2)];
+        out[g] = v;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if ((g & 3) == 3 && cx.lost != nullptr && __builtin_bit_cast(uint32_t, v.y) != hit0 + (uint32_t)(g >> 2)) atomicAdd(cx.lost, 1ull);
+#endif
+      }
       wave_fence();
     }
     return;
