@@ -249,13 +249,14 @@ static void carve(DevPaths q[2], int P, int depth, bool rec) {
   a.w_r = take(depth * p); a.w_g = take(depth * p); a.w_b = take(depth * p);
   a.child = (int32_t*)take(depth * p);
   a.fold_dense = rec ? 1 : 0;                   // the compacted (record) schedule keeps dense fold records; the plain one folds by slot
+  a.synth0 = rec ? 1 : 0;                       // ... and lets bounce 0 recompute the camera ray instead of reading it back (nothing else reads raygen's bank)
   a.term_r = take(p); a.term_g = take(p); a.term_b = take(p);
   a.rad_r = take(p); a.rad_g = take(p); a.rad_b = take(p);
   a.final_flags = (uint32_t*)take(p);
   DevPaths& c = q[1];
   c.e_r = a.e_r; c.e_g = a.e_g; c.e_b = a.e_b; c.w_r = a.w_r; c.w_g = a.w_g; c.w_b = a.w_b;
   c.term_r = a.term_r; c.term_g = a.term_g; c.term_b = a.term_b; c.rad_r = a.rad_r; c.rad_g = a.rad_g; c.rad_b = a.rad_b;
-  c.final_flags = a.final_flags; c.child = a.child; c.fold_dense = a.fold_dense;
+  c.final_flags = a.final_flags; c.child = a.child; c.fold_dense = a.fold_dense; c.synth0 = a.synth0;
 }
 
 // LDS stack per ray: the tree's worst-case bound if 8 workgroups per CU (8 waves per SIMD) still fit in the CU's 160 KB, else the

@@ -736,17 +736,20 @@ constexpr int kShadePerThread = ART_SHADE_PER;
 #define ART_SHADE_HINT 1          // 1: the classification's key and material index go along to shade_item (all of an item's loads start at once)
 #endif
 #ifndef ART_SHADE_SORT
-#define ART_SHADE_SORT 0          // 1: sort the items of a round by material class (see above); 0: input order (one class for all surfaces)
+#define ART_SHADE_SORT 1          // 1: sort the items of a round by material class (see above); 0: input order (one class for all surfaces).  A/B in one call on the final stage (profiles/r4_shade/ab_sort_final.txt): C4 5.28 vs 5.70 ms per launch, C3 1.70-1.83 vs 1.88-1.90, C5 33.4 vs 33.7 ms per batch
 #endif
 
 #ifndef ART_SHADE_WAVES
 #define ART_SHADE_WAVES 6
 #endif
-template <int PER>
+// CAMERA: bounce 0 over raygen's bank (DevPaths::synth0: flags, previous pdf and the camera ray are recomputed, not read) -- its own
+// instantiation, so that the other bounces' code is exactly what it was (as one kernel the extra branch cost 17 more spilled VGPRs: +7 %)
+template <int PER, bool CAMERA>
 // 6 waves per SIMD (80 VGPRs): left to itself the compiler takes 111 VGPRs = 4 waves (6.6 -> 6.2 ms per launch on C4, round 3)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_WAVES))) void k_shade_compact(const DevFrame F, const DevScene S, const DevPaths Qi, const DevPaths Qo, int bounce,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_WAVES))) void k_shade_compact(const DevFrame F, const DevScene S, const DevPaths Qi, const DevPaths Qo, int bounce_arg,
                                                        const int* __restrict__ n_in_ptr, int* __restrict__ n_out_ptr, uint32_t* __restrict__ slot_out,
                                                        unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b) {
+  const int bounce = CAMERA ? 0 : bounce_arg;            // (a literal for the camera instantiation: no shadow test can be owed, nothing is pending)
   constexpr int kShadeChunk = 256 * PER;
   __shared__ int s_tot[PER * kItemClasses];                // items of each class in each round (256 items) of the chunk
   __shared__ int s_base, s_rays;
@@ -782,7 +785,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
   for (int k = 0; k < PER; ++k) {
     const int w = c0 + k * 256 + threadIdx.x;
     hint[k].key = KEY_MISS; hint[k].mat = 0;
-    int c = (w < n_in) ? item_class(S, Qi, w, tables, &hint[k]) : kItemClasses;
+    int c = (w < n_in) ? item_class(S, Qi, w, tables, &hint[k], CAMERA ? 1 : 0) : kItemClasses;
     const bool surface = c < CLS_CHEAP;
     hint[k].mat = (int32_t)(threadIdx.x | (surface ? 256u : 0u) | ((uint32_t)hint[k].mat << 9));
     if (!ART_SHADE_SORT && c < CLS_CHEAP) c = CLS_LAMBERT;
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
       ItemHint ih; ih.key = hk.x; ih.mat = (int32_t)(hk.y >> 9);
       const ItemHint* const hp = (ART_SHADE_HINT && (hk.y & 256u)) ? &ih : nullptr;
       if (keep) slot_out[wo] = (uint32_t)item_slot(Qi, w);
-      if (ART_SHADE_DEFER) n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cx, &ro, hp);
+      if (ART_SHADE_DEFER) n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cx, &ro, hp, CAMERA ? 1 : 0);
       else {
         StageCtx cy = tables;
         if (staged) {
@@ -848,7 +851,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
           cy.stage = s_stage[wave]; cy.stage_pitch = kStagePitch; cy.stage_item = lane; cy.stage_count = nk; cy.lost = lost;
           cy.rec_base[0] = first; cy.rec_base[1] = (per == 2) ? first + (size_t)nk : first;
         }
-        n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cy, nullptr, hp);
+        n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cy, nullptr, hp, CAMERA ? 1 : 0);
       }
     }
     if (ART_SHADE_DEFER && Qo.rec != nullptr) {
@@ -1001,13 +1004,16 @@ __global__ void k_probe_on(int v) { g_lane_probe_on = v; }
 #endif
 void launch_shade_compact(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Qi, const DevPaths& Qo, int bounce,
                           const int* n_in, int* n_out, uint32_t* slot_out, unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b) {
+  const bool camera = Qi.synth0 && Qi.slot_id == nullptr;
+  const dim3 grid((Qi.P + 256 * kShadePerThread - 1) / (256 * kShadePerThread));
 #if defined(ART_LANE_PROBE)
   hipLaunchKernelGGL(k_probe_on, dim3(1), dim3(1), 0, st, 1);
-  hipLaunchKernelGGL(k_shade_compact<kShadePerThread>, dim3((Qi.P + 256 * kShadePerThread - 1) / (256 * kShadePerThread)), dim3(256), 0, st, F, S, Qi, Qo, bounce, n_in, n_out, slot_out, lost, rays_a, rays_b);
-  hipLaunchKernelGGL(k_probe_on, dim3(1), dim3(1), 0, st, 0);
-  return;
 #endif
-  hipLaunchKernelGGL(k_shade_compact<kShadePerThread>, dim3((Qi.P + 256 * kShadePerThread - 1) / (256 * kShadePerThread)), dim3(256), 0, st, F, S, Qi, Qo, bounce, n_in, n_out, slot_out, lost, rays_a, rays_b);
+  if (camera) hipLaunchKernelGGL((k_shade_compact<kShadePerThread, true>), grid, dim3(256), 0, st, F, S, Qi, Qo, bounce, n_in, n_out, slot_out, lost, rays_a, rays_b);
+  else hipLaunchKernelGGL((k_shade_compact<kShadePerThread, false>), grid, dim3(256), 0, st, F, S, Qi, Qo, bounce, n_in, n_out, slot_out, lost, rays_a, rays_b);
+#if defined(ART_LANE_PROBE)
+  hipLaunchKernelGGL(k_probe_on, dim3(1), dim3(1), 0, st, 0);
+#endif
 }
 void launch_bump(hipStream_t st, unsigned long long* a, unsigned long long* b, unsigned long long n) { hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, st, a, b, n); }
 void launch_resolve_last(hipStream_t st, const DevPaths& Q, const int* n, int last_level) {

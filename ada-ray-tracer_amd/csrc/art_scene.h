@@ -127,6 +127,11 @@ struct DevPaths {
   // e_*[k + 1][w'] = its explicit light e_k at the index w' of that next item.  k_fold_level walks the levels from the deepest up.
   int32_t* child;               // [max_depth][P]
   int32_t fold_dense;
+  // 1 (the compacted schedule): what raygen would write for every camera ray alike, or what bounce 0 can recompute from the slot, is not
+  // stored at all -- flags = alive | previous-specular, previous pdf 1 (StartSample, materials.ads:25), origin = the camera position,
+  // direction = camera_dir(pixel, sample) again (60 instructions against 24 B written and 24 B read per path).  The identity-layout
+  // bank (slot_id == nullptr) is then raygen's and is read by bounce 0 only.
+  int32_t synth0;
   // Trace records of this bank's rays (round 3), 4 x Rec4 per record, or nullptr (REC_NONE: the SoA ray arrays above are used).
   // WRITE-ONLY for the stages: both banks point at ONE record array (a bank's records are dead once its rays are traced), so a stage
   // that read its input item's record would race with the records other workgroups are writing for the output bank -- a stage reads

@@ -36,6 +36,9 @@ struct RayOut { bool alive, shadow; f3 no, nd, so, sd; float s_tfar, sh_min; };
 #ifndef ART_DIAG_SKIP
 #define ART_DIAG_SKIP 0
 #endif
+#ifndef ART_SYNTH_DIR
+#define ART_SYNTH_DIR 1           // DevPaths::synth0: 1 = bounce 0 recomputes the camera direction as well (raygen then stores a hit and a record, nothing else), 0 = raygen stores the direction (measured equal within noise on C3 / C4, 2 % slower on C5)
+#endif
 ART_HD void wave_fence() {
 #if defined(__HIP_DEVICE_COMPILE__)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -436,16 +439,18 @@ ART_HD void raygen_slot(const DevFrame& f, const DevScene& s, const DevPaths& q,
   uint32_t pixel, sample;
   slot_to_sample(q, slot, pixel, sample);
   const f3 d = camera_dir(f, s, pixel, sample);
-  q.ray_ox[slot] = s.cam_pos[0]; q.ray_oy[slot] = s.cam_pos[1]; q.ray_oz[slot] = s.cam_pos[2];
-  q.ray_dx[slot] = d.x; q.ray_dy[slot] = d.y; q.ray_dz[slot] = d.z;
+  if (!q.synth0) { q.ray_ox[slot] = s.cam_pos[0]; q.ray_oy[slot] = s.cam_pos[1]; q.ray_oz[slot] = s.cam_pos[2]; }
+  if (!q.synth0 || !ART_SYNTH_DIR) { q.ray_dx[slot] = d.x; q.ray_dy[slot] = d.y; q.ray_dz[slot] = d.z; }
   if (q.rec) emit_ray(s, q, (size_t)slot, (size_t)slot, true, ld3(s.cam_pos), d, kInfinity, -1.0f, cx, cx.stage_item);     // REC_EXT: record `slot`
   else {
     q.ray_tfar[slot] = kInfinity;
     q.ray_tfar[q.P + slot] = -1.0f;
   }
-  q.prev_pdf[slot] = 1.0f;                         // StartSample (materials.ads:25)
-  q.flags[slot] = FLAG_ALIVE | FLAG_PREV_SPEC;
-  q.term_r[slot] = 0.0f; q.term_g[slot] = 0.0f; q.term_b[slot] = 0.0f;
+  if (!q.synth0) {                                   // (synth0: bounce 0 knows all of this without being told, DevPaths::synth0)
+    q.prev_pdf[slot] = 1.0f;                         // StartSample (materials.ads:25)
+    q.flags[slot] = FLAG_ALIVE | FLAG_PREV_SPEC;
+  }
+  if (!q.fold_dense) { q.term_r[slot] = 0.0f; q.term_g[slot] = 0.0f; q.term_b[slot] = 0.0f; }      // (dense fold records: a path's end is a record of its level)
 }
 
 // ---------------------------------------------------------------- one bounce
@@ -465,8 +470,11 @@ enum ItemCls : int32_t { CLS_LAMBERT = 0, CLS_PHONG = 1, CLS_GLASS = 2, CLS_MIRR
 // What the classification has already fetched for a SURFACE item (class < CLS_CHEAP): its hit key and its material index (in range, a
 // surface material).  shade_item starts every load of the item from it at once instead of walking hit -> triangle record -> material.
 struct ItemHint { uint32_t key; int32_t mat; };
-ART_HD int32_t item_class(const DevScene& s, const DevPaths& qi, int w, const StageCtx& cx = StageCtx(), ItemHint* hint = nullptr) {
-  const uint32_t fl = qi.flags[w];
+// camera: 1 / 0 = the caller knows (k_shade_compact is compiled once for bounce 0 and once for the others, so that neither carries the
+// other's loads and registers), -1 = look at the bank
+ART_HD int32_t item_class(const DevScene& s, const DevPaths& qi, int w, const StageCtx& cx = StageCtx(), ItemHint* hint = nullptr, int camera_mode = -1) {
+  const bool camera = (camera_mode >= 0) ? (camera_mode != 0) : (qi.synth0 && qi.slot_id == nullptr);         // raygen's bank: every item is a live camera ray (DevPaths::synth0)
+  const uint32_t fl = camera ? (FLAG_ALIVE | FLAG_PREV_SPEC) : qi.flags[w];
   if (!(fl & FLAG_ALIVE)) return CLS_CHEAP;                       // only owed a shadow test: resolved now
   const uint32_t key = qi.hit[w].key;
   if (key == KEY_MISS) return CLS_CHEAP;
@@ -493,11 +501,12 @@ ART_HD bool item_survives(const DevFrame& f, const DevScene& s, const DevPaths& 
 // triangle's normals and the material record are then requested together with the item's own words, one round trip instead of three
 // dependent ones (hit -> triangle shading record -> material).
 ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, const DevPaths& qo, int w, int wo, int bounce, unsigned long long* lost = nullptr,
-                      const StageCtx& cx = StageCtx(), RayOut* defer = nullptr, const ItemHint* hint = nullptr) {
+                      const StageCtx& cx = StageCtx(), RayOut* defer = nullptr, const ItemHint* hint = nullptr, int camera_mode = -1) {
   ART_PROBE(0);
   const int slot = item_slot(qi, w);
   const size_t P = (size_t)qi.P;
-  uint32_t fl = qi.flags[w];
+  const bool camera = (camera_mode >= 0) ? (camera_mode != 0) : (qi.synth0 && qi.slot_id == nullptr);         // bounce 0 of the compacted schedule: raygen stored the hit and nothing else (DevPaths::synth0)
+  uint32_t fl = camera ? (FLAG_ALIVE | FLAG_PREV_SPEC) : qi.flags[w];
   // ---- everything the item holds is read first
   const DevHit hw = qi.hit[w];
   const uint32_t key = hint ? hint->key : hw.key;
@@ -516,10 +525,20 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   if (may_owe) { hs = qi.hit[P + (size_t)w]; owed_min = qi.sh_min_t[w]; owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
   // (the extension ray is kept as six SoA words next to its trace record: reading it back out of the record would pull the whole
   // 128-byte line of the item's two records for 24 useful bytes)
-  const f3 o = mk3(qi.ray_ox[w], qi.ray_oy[w], qi.ray_oz[w]);
-  const f3 d = mk3(qi.ray_dx[w], qi.ray_dy[w], qi.ray_dz[w]);
+  f3 o, d; float prev_pdf;
+  if (camera) {
+    o = ld3(s.cam_pos); prev_pdf = 1.0f;
+    if (ART_SYNTH_DIR) {
+      uint32_t cpix, csam;
+      slot_to_sample(qi, slot, cpix, csam);
+      d = camera_dir(f, s, cpix, csam);                                         // raygen_slot's own expression: the same bits
+    } else d = mk3(qi.ray_dx[w], qi.ray_dy[w], qi.ray_dz[w]);
+  } else {
+    o = mk3(qi.ray_ox[w], qi.ray_oy[w], qi.ray_oz[w]);
+    d = mk3(qi.ray_dx[w], qi.ray_dy[w], qi.ray_dz[w]);
+    prev_pdf = qi.prev_pdf[w];
+  }
   const float t = hw.t, hu = hw.u, hv = hw.v;
-  const float prev_pdf = qi.prev_pdf[w];
   if (fl & FLAG_SHADOW_PENDING) {
     ART_PROBE(1);
     // Compute_Shadow: hit and t < maxDist - eps2 (enforced by the ray's tfar clip) and t > 10*eps

@@ -134,6 +134,26 @@ def synthetic_scene(n_tris, config_id=3, rect_lights=False):
     return SceneDesc(spheres=spheres, lights=lights, materials=mats, meshes=[mesh], cornell=CORNELL_BOX, cam_pos=REFERENCE_CAMERA)
 
 
+def structured_scene(n_tris=1000000):
+    """The structured counterpart of C4 (perf evidence beyond random soups, bench.py --scene s4): Cornell walls + the three sphere lights of
+    synthetic_scene + two closed, connected surfaces of about n_tris triangles in total -- a finely tessellated torus (triangles of very
+    different sizes, slivers at the seams, coplanar neighbours) over a tilted regular grid (equal triangles: the radix tree's balanced
+    worst case).  Not a BASELINE configuration."""
+    mats = cornell_materials()
+    mats[4] = dict(type=MAT_LIGHT, light=0)
+    mats.append(dict(type=MAT_LIGHT, light=1)); mats.append(dict(type=MAT_LIGHT, light=2))
+    lights = [sphere_light(-1.5, 4), sphere_light(0.0, 11), sphere_light(1.5, 12)]
+    spheres = [(l["center"], l["radius"], l["mat"]) for l in lights]
+    nv = max(8, int(round((0.75 * n_tris / 5.0) ** 0.5))); nu = int(round(2.5 * nv))             # 2 nu nv = 5 nv^2 = 3/4 of the triangles ...
+    m = max(4, int(round((n_tris / 4 / 2) ** 0.5)))                                              # ... 2 m^2 = the rest
+    tor = torus_mesh(nu, nv); grd = grid_mesh(m, y0=0.4, tilt=0.15)
+    pos = np.concatenate([tor["pos"], grd["pos"]]); nrm = np.concatenate([tor["nrm"], grd["nrm"]])
+    idx = np.concatenate([tor["idx"], grd["idx"] + tor["pos"].shape[0]]).astype(np.int32)
+    matid = (1 + (np.arange(idx.shape[0]) % 3)).astype(np.int32)
+    mesh = dict(mode=MESH_CLOSEST, pos=pos, nrm=nrm, idx=idx, matid=matid)
+    return SceneDesc(spheres=spheres, lights=lights, materials=mats, meshes=[mesh], cornell=CORNELL_BOX, cam_pos=REFERENCE_CAMERA)
+
+
 def mixed_scene(n_tris=20000, config_id=5, extra_spheres=8):
     """C5: spheres (Phong, glass, extra glass/diffuse) + emissive sphere light + a triangle mesh inside the Cornell box."""
     mats = cornell_materials()

@@ -54,6 +54,9 @@ def build_scene(art, args):
         return scenes.synthetic_scene(100000, 3), "C3: synthetic 100000 triangles + 3 sphere lights in the Cornell box"
     if args.scene == "c5":
         return scenes.mixed_scene(20000, 5), "C5: spheres + 20000-triangle mesh, glass/diffuse/emissive"
+    if args.scene == "s4":
+        sd = scenes.structured_scene(args.tris)
+        return sd, "S4 (not a BASELINE config): structured meshes, %d triangles (tessellated torus + regular grid) + 3 sphere lights in the Cornell box" % sd.desc.meshes[0].ntris
     if args.scene == "c1":
         return scenes.eight_sphere_scene(), "C1: Cornell-box-style 8-sphere scene"
     return scenes.reference_scene(), "C2: internal Cornell scene with data/pyramid2.vsgf (Scene.Init by the product's host layer)"
@@ -159,7 +162,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="c4", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--scene", default="c4", choices=["c1", "c2", "c3", "c4", "c5", "s4"])
     ap.add_argument("--tris", type=int, default=1000000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)

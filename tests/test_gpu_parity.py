@@ -584,3 +584,18 @@ def test_gcore_two_level_instancing_matches_the_flattened_scene(art, backend):
     assert np.abs(two[5][ok] - flat[5][ok]).max() < 1.0e-3                                   # barycentrics
     nn = lambda v: v / np.linalg.norm(v, axis=1, keepdims=True)
     assert np.abs(nn(two[4][ok]) - nn(flat[4][ok])).max() < 1.0e-4                            # world-space Ng
+
+
+def test_structured_mesh_scene_bit_exact(art, backend):
+    """scenes.structured_scene (bench.py --scene s4: a tessellated torus over a regular grid -- shared vertices, coplanar neighbours, slivers,
+    interpolated vertex normals that differ per vertex) at a size the oracle's brute-force scan can follow: the accum buffer bit for bit."""
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.structured_scene(6000)
+    osc = conv.OracleScene(sd)
+    backend.upload_scene(sd)
+    backend.resize(80, 64)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=9)
+    accum, _, spp = backend.render_pass(p, 0)
+    ref, _, cnt = orc.render(osc.scene, orc.make_params(80, 64, orc.PT_MIS, True, 8, 2, seed=9))
+    assert_radiance_equal(accum, ref, spp)
+    assert backend.stats().rays == cnt.rays
