@@ -169,7 +169,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // Contract of the four helpers below: they are entered with ALL 64 lanes enabled and leave EXEC = -1.  They are `volatile`
 // (never duplicated, hoisted or sunk across each other; EXEC cannot be named as a clobber -- the compiler rejects reserved registers
 // there).  A caller that wrapped them in a per-lane branch would switch masked-off lanes on: k_trace_coop checks its side of the
-// contract in builds with -DART_CHECK_EXEC (EXEC == -1 at the head of every node step, else the kernel traps).
+// contract in builds with -DART_CHECK_EXEC (EXEC == -1 at the head of every node step, else the kernel traps): libart_hip_check.so,
+// run by tests/test_gpu_widths.py::test_trace_kernel_keeps_its_exec_contract.
 __device__ __forceinline__ void pop_masked(mask_t v1, mask_t ok1, uint32_t& sa, uint32_t& pend, uint32_t entry) {     // sa -= 8 in v1, pend = entry in ok1
   asm volatile("s_mov_b64 exec, %2\n\tv_add_u32 %0, -8, %0\n\ts_mov_b64 exec, %3\n\tv_mov_b32 %1, %4\n\ts_mov_b64 exec, -1" : "+v"(sa), "+v"(pend) : "s"(v1), "s"(ok1), "v"(entry));
 }

@@ -43,7 +43,7 @@ import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 GATHER_CEILING_GBPS = 8000.0   # MI355X_MICROARCH.md "Indexed rows": random rows out of the Infinity Cache, 8.6 TB/s (38 MB table) .. 7.4-7.9 (151 MB)
-PROFILE_TAG = "r3_final"
+PROFILE_TAG = "r4_final"
 
 
 def build_scene(art, args):

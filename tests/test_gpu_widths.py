@@ -183,3 +183,49 @@ def test_shadow_rays_as_full_closest_hit_searches_give_the_same_image(art, backe
         backend.set_option("bvh_width", 4)
         backend.set_option("shadow_anyhit", 1)
         backend.set_option("lds_stack_cap", 0)
+
+
+def test_trace_kernel_keeps_its_exec_contract(art, backend, tmp_path):
+    """the exec-masked inline asm of k_trace_coop's node step (pop, node load, LDS push, sort key: `s_mov exec, mask ... s_mov
+    exec, -1`) is only right when it is entered with all 64 lanes enabled.  libart_hip_check.so is the same library with -DART_CHECK_EXEC:
+    the kernel traps if EXEC != -1 at the head of a node step.  A render of the mixed scene (both widths, a capped LDS stack with the
+    overflow kernel, shadow rays with and without the visibility rule) in a process of its own must finish and give the product's bits."""
+    import os
+    import subprocess
+    import sys
+    lib = os.path.join(art.PKG_DIR, "libart_hip_check.so")
+    assert os.path.exists(lib), "make -C ada-ray-tracer_amd builds it (__graft_entry__.build)"
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.mixed_scene(4000, 5)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=9)
+    want = {}
+    try:
+        for width, cap in ((4, 0), (4, 5), (8, 0)):
+            backend.set_option("bvh_width", width); backend.set_option("lds_stack_cap", cap)
+            backend.upload_scene(sd); backend.resize(96, 64)
+            want[(width, cap)], _, _ = backend.render_pass(p, 0)
+    finally:
+        backend.set_option("bvh_width", 4); backend.set_option("lds_stack_cap", 0)
+    out = str(tmp_path / "check.npz")
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "art = ge.load_package()\n"
+        "from ada_ray_tracer_amd import scenes\n"
+        "be = art.Backend(0)\n"
+        "sd = scenes.mixed_scene(4000, 5)\n"
+        "p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=9)\n"
+        "res = {}\n"
+        "for width, cap in ((4, 0), (4, 5), (8, 0)):\n"
+        "    be.set_option('bvh_width', width); be.set_option('lds_stack_cap', cap)\n"
+        "    be.upload_scene(sd); be.resize(96, 64)\n"
+        "    res['w%%d_c%%d' %% (width, cap)], _, _ = be.render_pass(p, 0)\n"
+        "np.savez(%r, **res)\n"
+        "be.shutdown()\n" % (art.ROOT, out))
+    env = dict(os.environ, ART_LIB=lib)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.load(out)
+    for (width, cap), img in want.items():
+        assert np.array_equal(bits(got["w%d_c%d" % (width, cap)]), bits(img)), (width, cap)
