@@ -324,6 +324,8 @@ def main():
                         "survey_8d_formula_GBps": round(rays_dev0 * (32.0 * B + 48.0 * T + 64.0) / (trace_ms * 1e-3) / 1e9, 1) if trace_ms > 0 else None,
                         "l2_hit_rate": round(prof["l2_hit_rate"], 4) if prof and "l2_hit_rate" in prof else None,
                         "wave_occupancy": occ,
+                        # the stages around the trace kernel: whole job over trace-only = trace-kernel time / wall time of the timed steps
+                        "whole_over_trace_only": round((trace_ms * 1e-3) / elapsed, 4) if (elapsed > 0 and not in_library) else None,
                         "avg_launch_ms": round(trace_ms / max(1, launches), 4), "launches": int(launches),
                         "trace_Mrays_per_s": round(rays_dev0 / (trace_ms * 1e-3) / 1e6, 2) if trace_ms > 0 else None}
         cpu = None

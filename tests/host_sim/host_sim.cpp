@@ -58,6 +58,12 @@ extern "C" int hs_trace(const ArtSceneDesc* sd, const float* o, const float* d, 
 
 static int g_rank = 0, g_nranks = 1, g_tile = 32;
 extern "C" void hs_set_shard(int rank, int nranks, int tile) { g_rank = rank; g_nranks = nranks; g_tile = tile; }
+// the product's pixel ownership map (art_host_scene.cpp build_pixmap) for one rank: returns the number of pixels, fills out[0 .. cap)
+extern "C" long long hs_pixmap(int w, int h, int rank, int nranks, int tile, unsigned* out, long long cap) {
+  const std::vector<uint32_t> pm = build_pixmap(w, h, rank, nranks, tile);
+  for (size_t i = 0; i < pm.size() && (long long)i < cap; ++i) out[i] = pm[i];
+  return (long long)pm.size();
+}
 // 1: fold over dense per-level records (DevPaths::fold_dense, what the GPU's compacted schedule does; here with the identity layout, where an
 // item's index is its slot at every level) instead of the slot-indexed fold stack
 static int g_fold_dense = 0;

@@ -22,6 +22,16 @@ def lib(art):
     return _lib
 
 
+def pixmap(art, w, h, rank, nranks, tile=32):
+    """the pixels (y * w + x) rank owns in an nranks-way job: the product's build_pixmap"""
+    L = lib(art)
+    L.hs_pixmap.restype = C.c_longlong
+    L.hs_pixmap.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_longlong]
+    out = np.zeros(w * h, np.uint32)
+    n = L.hs_pixmap(w, h, rank, nranks, tile, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size)
+    return out[:n].copy()
+
+
 def set_fold_dense(art, on):
     """1: the fold over dense per-level records (the GPU's compacted schedule), 0: the slot-indexed fold stack"""
     lib(art).hs_set_fold_dense(int(on))

@@ -44,10 +44,11 @@ CONFIGS = {
     "c3": (lambda sc: sc.synthetic_scene(100000, 3), 1024, 1024, 3000),
     "c4": (lambda sc: sc.synthetic_scene(1000000, 4), 1920, 1080, 3000),
     "c5": (lambda sc: sc.mixed_scene(20000, 5), 4096, 4096, 3000),
+    "s4": (lambda sc: sc.structured_scene(1000000), 1920, 1080, 2000),       # not a BASELINE config: the structured 1 M-triangle scene of bench.py --scene s4
 }
 
 
-@pytest.mark.parametrize("config", ["c3", "c4", "c5"])
+@pytest.mark.parametrize("config", ["c3", "c4", "c5", "s4"])
 def test_full_frame_sampled_pixels_equal_the_oracle(art, backend, config):
     from ada_ray_tracer_amd import scenes
     build, W, H, n = CONFIGS[config]

@@ -111,3 +111,30 @@ def test_c3_two_passes_of_eight_tasks_equal_one_pass_of_sixteen(art, backend):
     ref, _ = orc.render_pixels(osc.scene, prm, xs, ys, 0)
     ref, _ = orc.render_pixels(osc.scene, prm, xs, ys, 32, ref)
     assert np.array_equal(bits(accum[ys, xs]), bits(ref))
+
+
+@pytest.mark.parametrize("rt,aa,T,depth,bg", [("PT_SHADOW", True, 16, 8, (0.0, 0.0, 0.0)), ("PT_STUPID", True, 16, 8, (0.1, 0.2, 0.3)),
+                                             ("PT_MIS", False, 64, 8, (0.0, 0.0, 0.0)), ("PT_MIS", True, 16, 16, (0.05, 0.05, 0.05)),
+                                             ("PT_MIS", True, 16, 1, (0.0, 0.0, 0.0))])
+def test_c3_other_integrators_depths_and_aa_off_at_64_spp(art, backend, rt, aa, T, depth, bg):
+    """C3 at its frame and sample count through the rest of the pass parameters: the two other integrators (PT_SHADOW's light hits return 0,
+    PT_STUPID has no shadow rays: other record modes, other fold formula), anti-aliasing off (64 tasks of one sample: sample index = task),
+    Max_Trace_Depth 16 (the limit of the ABI: 17 levels of dense fold records) and 1, a background colour in the per-task sum."""
+    from ada_ray_tracer_amd import scenes
+    W = H = 1024
+    sd = scenes.synthetic_scene(100000, 3)
+    backend.upload_scene(sd)
+    backend.resize(W, H)
+    p = art.Backend.pass_params(getattr(art, rt), aa, depth, T, seed=7, background=bg)
+    accum, _, spp = backend.render_pass(p, 0)
+    assert spp == (4 * T if aa else T) and backend.stats().lost_paths == 0
+    osc = conv.OracleScene(sd)
+    nodes, tris, info = backend.export_bvh()
+    osc.attach_bvh(nodes, tris, info.node_width)
+    rng = np.random.default_rng(17 + depth + T)
+    n = 600
+    xs = rng.integers(0, W, n); ys = rng.integers(0, H, n)
+    ref, _ = orc.render_pixels(osc.scene, orc.make_params(W, H, getattr(orc, rt), aa, depth, T, seed=7, background=bg), xs, ys)
+    got = accum[ys, xs]
+    assert np.isfinite(ref).all() and np.abs(got - ref).max() / spp <= TOL
+    assert np.array_equal(bits(got), bits(ref))

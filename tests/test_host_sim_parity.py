@@ -378,3 +378,23 @@ def test_cost_optimal_collapse_is_a_sound_tree_with_fewer_expected_node_visits(a
         hostsim.set_bvh_param(art, "collapse", 0)
     assert out[0][1] == out[1][1]                                   # the search result cannot depend on the tree
     assert out[1][0] <= out[0][0] * (1.0 + 1e-6), (out[0][0], out[1][0])
+
+
+@pytest.mark.parametrize("w,h", [(1920, 1080), (4096, 4096), (1024, 1024), (96, 54), (33, 70)])
+def test_tile_deal_is_a_partition_and_balanced(art, w, h):
+    """every pixel has exactly one owner for any number of ranks, and the deal (32 x 32 tiles along diagonals, round 4) gives
+    every rank the same share within a few tiles -- also on the 4096-wide frame whose 128 tiles per row made `tile_id mod 8` a deal of
+    whole COLUMNS, and no rank's tiles line up in full-height columns any more."""
+    for n in (1, 2, 3, 4, 6, 8):
+        seen = np.zeros(w * h, np.int32)
+        counts = []
+        for r in range(n):
+            pm = hostsim.pixmap(art, w, h, r, n)
+            seen[pm] += 1
+            counts.append(pm.size)
+            if n == 8 and w >= 1024:
+                cols = np.unique((pm % w) // 32)                      # tile columns this rank touches
+                assert cols.size == (w + 31) // 32                    # all of them: no rank is confined to every 8th column
+        assert (seen == 1).all()
+        tiles = ((w + 31) // 32) * ((h + 31) // 32)
+        assert max(counts) - min(counts) <= 32 * 32 * (2 if tiles >= 4 * n else tiles)
