@@ -113,8 +113,8 @@ def test_c4_full_frame_is_independent_of_shards_batches_and_builder(art, backend
 
 
 def test_batch_is_halved_when_hbm_is_short(art, backend):
-    """A 64-spp 1080p pass wants one batch of 133 M paths: 69 GB of path state (516 B per slot at depth 8, the trace records of both rays of
-    an item included since round 3).  With most of the HBM taken by someone else the batch is halved until the buffer fits, and the image
+    """A 64-spp 1080p pass wants one batch of 133 M paths: 74.6 GB of path state (560 B per slot at depth 8: the trace records of both rays of
+    an item since round 3, dense per-level fold records with their child links since round 4).  With most of the HBM taken by someone else the batch is halved until the buffer fits, and the image
     is the same bits (the RNG is keyed by pixel, sample, bounce).  The backend is re-initialised first: its buffers only ever grow, and
     what an earlier test left allocated would decide what fits."""
     import ctypes as C
@@ -137,7 +137,7 @@ def test_batch_is_halved_when_hbm_is_short(art, backend):
         backend.set_option("batch_paths", 128 << 20)
     free, total = C.c_size_t(0), C.c_size_t(0)
     assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
-    keep = 24 << 30                 # 24 GB left (+ the 4 GB of the reference render's buffer): 68.6 GB cannot fit, 34.3 GB cannot, 17.2 GB can
+    keep = 24 << 30                 # 24 GB left (+ the 4 GB of the reference render's buffer): 74.6 GB cannot fit, 37.3 GB cannot, 18.6 GB can
     if free.value <= keep + (8 << 30):
         pytest.skip("not enough free HBM to take away")
     hog = C.c_void_p(None)
