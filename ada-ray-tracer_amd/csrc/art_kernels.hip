@@ -745,11 +745,37 @@ constexpr int kShadePerThread = ART_SHADE_PER;
 #endif
 // CAMERA: bounce 0 over raygen's bank (DevPaths::synth0: flags, previous pdf and the camera ray are recomputed, not read) -- its own
 // instantiation, so that the other bounces' code is exactly what it was (as one kernel the extra branch cost 17 more spilled VGPRs: +7 %)
+// The stage's arguments as ONE struct: about 240 dwords of scene header and array pointers.  Taken by value the compiler loads all of them
+// into SGPRs at the kernel's entry and keeps them live to its end: 320 of them spilled to VGPR lanes (v_writelane / v_readlane: 15 % of the
+// kernel's VALU instructions, and the VGPRs that hold them).  ART_SHADE_KERNARG = 1: the code reads the fields through a pointer to the
+// kernarg segment instead, laundered at the head of every round so that a field is a scalar load (scalar cache) where it is used:
+// 80 spilled SGPRs instead of 320, 0-2 spilled VGPRs instead of 5-7, 6 % fewer VALU instructions; A/B in one call
+// (profiles/r4_shade/ab_kernarg.txt): C4 5.01 vs 5.26 ms per launch (bounce 0: 7.4 vs 8.0), C3 1.58 vs 1.82 (2.98 vs 3.61), C5 3.61 vs 3.67.
+// (0: the struct by value -- which as ONE parameter allocates worse than the eleven parameters of before: 29 spilled VGPRs, 6.0 ms.)
+struct ShadeKernArgs {
+  DevFrame F; DevScene S; DevPaths Qi; DevPaths Qo; int bounce;
+  const int* n_in_ptr; int* n_out_ptr; uint32_t* slot_out; unsigned long long* lost; unsigned long long* rays_a; unsigned long long* rays_b;
+};
+#ifndef ART_SHADE_KERNARG
+#define ART_SHADE_KERNARG 1
+#endif
+typedef const __attribute__((address_space(4))) ShadeKernArgs* ShadeKArgs;
+__device__ __forceinline__ ShadeKArgs launder_kargs(ShadeKArgs k) { unsigned long long r = (unsigned long long)k; asm volatile("" : "+s"(r)); return (ShadeKArgs)r; }
+
 template <int PER, bool CAMERA>
 // 6 waves per SIMD (80 VGPRs): left to itself the compiler takes 111 VGPRs = 4 waves (6.6 -> 6.2 ms per launch on C4, round 3)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_WAVES))) void k_shade_compact(const DevFrame F, const DevScene S, const DevPaths Qi, const DevPaths Qo, int bounce_arg,
-                                                       const int* __restrict__ n_in_ptr, int* __restrict__ n_out_ptr, uint32_t* __restrict__ slot_out,
-                                                       unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_WAVES))) void k_shade_compact(const ShadeKernArgs A_by_value) {
+#if ART_SHADE_KERNARG
+  ShadeKArgs K = launder_kargs((ShadeKArgs)__builtin_amdgcn_kernarg_segment_ptr());
+#define ART_KREF(T, field) (*(const T*)&K->field)
+#else
+  const ShadeKernArgs* const K = &A_by_value;
+#define ART_KREF(T, field) (K->field)
+#endif
+  const DevFrame& F = ART_KREF(DevFrame, F); const DevScene& S = ART_KREF(DevScene, S); const DevPaths& Qi = ART_KREF(DevPaths, Qi); const DevPaths& Qo = ART_KREF(DevPaths, Qo);
+  const int bounce_arg = K->bounce;
+  const int* const n_in_ptr = K->n_in_ptr; int* const n_out_ptr = K->n_out_ptr; uint32_t* const slot_out = K->slot_out;
+  unsigned long long* const lost = K->lost; unsigned long long* const rays_a = K->rays_a; unsigned long long* const rays_b = K->rays_b;
   const int bounce = CAMERA ? 0 : bounce_arg;            // (a literal for the camera instantiation: no shadow test can be owed, nothing is pending)
   constexpr int kShadeChunk = 256 * PER;
   __shared__ int s_tot[PER * kItemClasses];                // items of each class in each round (256 items) of the chunk
@@ -832,6 +858,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
   int n_rays = 0;
 #pragma unroll 1
   for (int k = 0; k < PER; ++k) {
+#if ART_SHADE_KERNARG
+    const ShadeKArgs K2 = launder_kargs(K);               // the round's own view of the arguments: nothing loaded before survives in a register
+    const DevFrame& F = *(const DevFrame*)&K2->F; const DevScene& S = *(const DevScene*)&K2->S; const DevPaths& Qi = *(const DevPaths*)&K2->Qi; const DevPaths& Qo = *(const DevPaths*)&K2->Qo;
+    uint32_t* const slot_out = K2->slot_out; unsigned long long* const lost = K2->lost;
+#endif
     const int r = (int)threadIdx.x;                       // position in the sorted round
     const int n_all_k = s_nall[k], n_keep_k = s_nkeep[k], out0_k = s_out0[k];
     const bool keep = r < n_keep_k;
@@ -1010,8 +1041,9 @@ void launch_shade_compact(hipStream_t st, const DevFrame& F, const DevScene& S, 
 #if defined(ART_LANE_PROBE)
   hipLaunchKernelGGL(k_probe_on, dim3(1), dim3(1), 0, st, 1);
 #endif
-  if (camera) hipLaunchKernelGGL((k_shade_compact<kShadePerThread, true>), grid, dim3(256), 0, st, F, S, Qi, Qo, bounce, n_in, n_out, slot_out, lost, rays_a, rays_b);
-  else hipLaunchKernelGGL((k_shade_compact<kShadePerThread, false>), grid, dim3(256), 0, st, F, S, Qi, Qo, bounce, n_in, n_out, slot_out, lost, rays_a, rays_b);
+  ShadeKernArgs A; A.F = F; A.S = S; A.Qi = Qi; A.Qo = Qo; A.bounce = bounce; A.n_in_ptr = n_in; A.n_out_ptr = n_out; A.slot_out = slot_out; A.lost = lost; A.rays_a = rays_a; A.rays_b = rays_b;
+  if (camera) hipLaunchKernelGGL((k_shade_compact<kShadePerThread, true>), grid, dim3(256), 0, st, A);
+  else hipLaunchKernelGGL((k_shade_compact<kShadePerThread, false>), grid, dim3(256), 0, st, A);
 #if defined(ART_LANE_PROBE)
   hipLaunchKernelGGL(k_probe_on, dim3(1), dim3(1), 0, st, 0);
 #endif
