@@ -120,11 +120,13 @@ struct DevPaths {
   const uint32_t* slot_id;
   uint32_t* final_flags;
   // Dense fold records (round 4; the compacted schedule).  fold_dense = 0: level k's e_k / w_k live at [k][slot] (the arrays above), a path's
-  // end at term / final_flags[slot]; a stage then scatters 4-byte words over every line of the level -- measured: 9 % of the shade stage's
-  // bytes, 18 % of its time.  fold_dense = 1: a level's records are indexed by the ITEM index of that bounce's input set, so every store
-  // is dense: item w of bounce k leaves { w_* [k][w] = its weight w_k, or the value its path ended with; child[k][w] = its item at bounce
-  // k + 1 (-1: the path ended here with that value; -2: a surface whose successor was not kept and counts as 0) } and, one bounce later,
-  // e_*[k + 1][w'] = its explicit light e_k at the index w' of that next item.  k_fold_level walks the levels from the deepest up.
+  // end at term / final_flags[slot]; a stage then scatters 4-byte words over every line of the level.  fold_dense = 1: a level's records are
+  // indexed by the ITEM index of that bounce's input set, so every store is dense.  Item w of bounce k leaves w_*[k][w] = its weight w_k, or
+  // the value its path ended with, and child[k][w] (art_shade.h fold_child_word: the item's index at bounce k + 1, or "ended here", or "a
+  // surface whose successor was not kept", plus one bit for the shadow test the item resolved for its predecessor); it also stores its
+  // explicit light e_k -- still subject to that shadow test -- where the fold will look for it: e_*[k + 1][w'], w' its successor's index.
+  // The successor only records the verdict in its own child word (k_resolve_last, after the last bounce, zeroes a shadowed e instead).
+  // k_fold_level walks the levels from the deepest up.  (The pending explicit colour thus needs no hot-state words: cand_* are unused.)
   int32_t* child;               // [max_depth][P]
   int32_t fold_dense;
   // 1 (the compacted schedule): what raygen would write for every camera ray alike, or what bounce 0 can recompute from the slot, is not

@@ -459,6 +459,15 @@ ART_HD void raygen_slot(const DevFrame& f, const DevScene& s, const DevPaths& q,
 // (identity layout) this is the plain in-place update; all reads of an item happen before its writes.
 ART_HD int item_slot(const DevPaths& q, int w) { return q.slot_id ? (int)q.slot_id[w] : w; }
 
+// the child word of a dense fold record: bits 0..27 the item at the next bounce, bits 28..29 the kind (0: that item exists; 1: the path ended
+// here, the record's w is its value; 2: a surface whose successor was not kept), bit 30: the shadow test this item resolved for its
+// PREDECESSOR came out "in shadow" (the predecessor's explicit light, e[this level][this item], then counts as 0)
+constexpr int32_t kFoldIndexMask = (1 << 28) - 1;
+ART_HD int32_t fold_child_word(int32_t child, bool shadowed) {
+  const int32_t kind = (child >= 0) ? 0 : (child == -1) ? 1 : 2;
+  return ((child >= 0) ? child : 0) | (kind << 28) | (shadowed ? (1 << 30) : 0);
+}
+
 // What shade_item(bounce) will do with item w, decided from the hit alone (flags, hit key, material type) before anything is shaded:
 // k_shade_compact sorts a workgroup's items by this class, so that a wave runs ONE material's code with (nearly) all its lanes -- measured
 // in round 4 on the unsorted kernel: 31 of 64 lanes enabled per VALU instruction; on C4 71 % of the waves ran the Phong path (four binary64
@@ -522,7 +531,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   // the shadow test the item may owe (its words exist for every item; asked for now, used below if the flag says so)
   const bool may_owe = (bounce > 0) && (f.render_type != PT_STUPID);
   DevHit hs = DevHit{0.0f, KEY_MISS, 0.0f, 0.0f}; float owed_min = 0.0f; f3 owed = mk3(0.0f, 0.0f, 0.0f);
-  if (may_owe) { hs = qi.hit[P + (size_t)w]; owed_min = qi.sh_min_t[w]; owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
+  if (may_owe) { hs = qi.hit[P + (size_t)w]; owed_min = qi.sh_min_t[w]; if (!qi.fold_dense) owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
   // (the extension ray is kept as six SoA words next to its trace record: reading it back out of the record would pull the whole
   // 128-byte line of the item's two records for 24 useful bytes)
   f3 o, d; float prev_pdf;
@@ -539,16 +548,21 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     prev_pdf = qi.prev_pdf[w];
   }
   const float t = hw.t, hu = hw.u, hv = hw.v;
+  // dense fold record of this item at this level (DevPaths::fold_dense): by default "the path ended here with value 0"; rec_shadowed: the
+  // shadow test this item resolves for its predecessor's explicit light came out "in shadow"
+  f3 rec_w = mk3(0.0f, 0.0f, 0.0f); int32_t rec_child = -1; bool rec_shadowed = false;
   if (fl & FLAG_SHADOW_PENDING) {
     ART_PROBE(1);
     // Compute_Shadow: hit and t < maxDist - eps2 (enforced by the ray's tfar clip) and t > 10*eps
-    if (!may_owe) { hs = qi.hit[P + (size_t)w]; owed_min = qi.sh_min_t[w]; owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
+    if (!may_owe) { hs = qi.hit[P + (size_t)w]; owed_min = qi.sh_min_t[w]; if (!qi.fold_dense) owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
     const bool in_shadow = (hs.key != KEY_MISS) && (hs.t > owed_min);
-    // e of the previous level: at [bounce - 1][slot], or (dense fold records) at [bounce][w], this item's own index
-    const size_t li = qi.fold_dense ? (size_t)bounce * P + (size_t)w : (size_t)(bounce - 1) * P + (size_t)slot;
-    qi.e_r[li] = in_shadow ? 0.0f : owed.x;
-    qi.e_g[li] = in_shadow ? 0.0f : owed.y;
-    qi.e_b[li] = in_shadow ? 0.0f : owed.z;
+    if (qi.fold_dense) rec_shadowed = in_shadow;      // dense fold records: the previous stage left the explicit colour itself at e[bounce][w]; this item's record says whether it counts
+    else {                                            // e of the previous level at [bounce - 1][slot]
+      const size_t li = (size_t)(bounce - 1) * P + (size_t)slot;
+      qi.e_r[li] = in_shadow ? 0.0f : owed.x;
+      qi.e_g[li] = in_shadow ? 0.0f : owed.y;
+      qi.e_b[li] = in_shadow ? 0.0f : owed.z;
+    }
     fl &= ~FLAG_SHADOW_PENDING;
   }
   // ---- what the output item will hold
@@ -557,8 +571,6 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   float s_tfar = -1.0f, sh_min = 0.0f, new_pdf = prev_pdf;
   f3 cand = mk3(0.0f, 0.0f, 0.0f);
   const f3 zero = mk3(0.0f, 0.0f, 0.0f);
-  // dense fold record of this item at this level (DevPaths::fold_dense): by default "the path ended here with value 0"
-  f3 rec_w = zero; int32_t rec_child = -1;
   auto kill = [&](int levels, f3 terminal) {       // the deepest PathTrace call returned `terminal`; `levels` fold levels were recorded
     fl = (fl & ~(FLAG_ALIVE | 0xffffff00u)) | ((uint32_t)levels << 8);
     if (qi.fold_dense) { if (levels == bounce) { rec_w = terminal; rec_child = -1; } }     // levels == bounce + 1: a surface at the last bounce, its record stands
@@ -660,7 +672,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   if (qi.fold_dense && !(ART_DIAG_SKIP & 16)) {                      // dense stores: consecutive items, consecutive addresses
     const size_t lw = (size_t)bounce * P + (size_t)w;
     qi.w_r[lw] = rec_w.x; qi.w_g[lw] = rec_w.y; qi.w_b[lw] = rec_w.z;
-    qi.child[lw] = (rec_child == -2 && wo >= 0) ? wo : rec_child;
+    qi.child[lw] = fold_child_word((rec_child == -2 && wo >= 0) ? wo : rec_child, rec_shadowed);
   }
   // ---- the output item
   if (wo < 0) {
@@ -677,7 +689,10 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   qo.prev_pdf[wo] = new_pdf;
   if (shadow) {
     qo.sh_min_t[wo] = sh_min;
-    qo.cand_r[wo] = cand.x; qo.cand_g[wo] = cand.y; qo.cand_b[wo] = cand.z;
+    if (qi.fold_dense) {      // the explicit colour goes straight to where the fold reads e of this level: level bounce + 1, the successor's index
+      const size_t le = (size_t)(bounce + 1) * P + (size_t)wo;
+      qi.e_r[le] = cand.x; qi.e_g[le] = cand.y; qi.e_b[le] = cand.z;
+    } else { qo.cand_r[wo] = cand.x; qo.cand_g[wo] = cand.y; qo.cand_b[wo] = cand.z; }
   }
   if (alive && !(ART_DIAG_SKIP & 4)) {
     qo.ray_ox[wo] = no.x; qo.ray_oy[wo] = no.y; qo.ray_oz[wo] = no.z;
@@ -722,10 +737,14 @@ ART_HD void resolve_last_shadow(const DevPaths& q, int w, int last_level) {
   const size_t si = (size_t)q.P + (size_t)w;
   const DevHit hs = q.hit[si];
   const bool in_shadow = (hs.key != KEY_MISS) && (hs.t > q.sh_min_t[w]);
-  const size_t li = q.fold_dense ? (size_t)(last_level + 1) * (size_t)q.P + (size_t)w : (size_t)last_level * (size_t)q.P + (size_t)slot;
-  q.e_r[li] = in_shadow ? 0.0f : q.cand_r[w];
-  q.e_g[li] = in_shadow ? 0.0f : q.cand_g[w];
-  q.e_b[li] = in_shadow ? 0.0f : q.cand_b[w];
+  if (q.fold_dense) {           // the last stage left the explicit colour at e[last_level + 1][w]; there is no record of that level to carry the bit: zero it
+    if (in_shadow) { const size_t li = (size_t)(last_level + 1) * (size_t)q.P + (size_t)w; q.e_r[li] = 0.0f; q.e_g[li] = 0.0f; q.e_b[li] = 0.0f; }
+  } else {
+    const size_t li = (size_t)last_level * (size_t)q.P + (size_t)slot;
+    q.e_r[li] = in_shadow ? 0.0f : q.cand_r[w];
+    q.e_g[li] = in_shadow ? 0.0f : q.cand_g[w];
+    q.e_b[li] = in_shadow ? 0.0f : q.cand_b[w];
+  }
   q.flags[w] = fl & ~FLAG_SHADOW_PENDING;
 }
 
@@ -743,22 +762,27 @@ ART_HD void fold_slot(const DevFrame& f, const DevPaths& q, int slot) {
 }
 
 // The same fold over dense records (DevPaths::fold_dense), one level per call from the deepest up: item w of bounce `level` gets
-//   L = its path's terminal value (child -1),  or  e_level + w_level * L(child)   -- L(child) = 0 at the deepest level and for child -2 --
+//   L = its path's terminal value (kind 1),  or  e_level + w_level * L(child)   -- L(child) = 0 at the deepest level and without a child,
+//   e_level = 0 when the child's record says its shadow test failed --
 // read from `nxt` (the level below, indexed by that level's items) and written to `cur`.  Level 0's items are the slots: its `cur` is rad.
 // The operations on a path's values are those of fold_slot in the same order, so the bits are the same.
 ART_HD void fold_level_item(const DevFrame& f, const DevPaths& q, int level, int w, bool deepest,
                             const float* nxt_r, const float* nxt_g, const float* nxt_b, float* cur_r, float* cur_g, float* cur_b) {
   const size_t lw = (size_t)level * (size_t)q.P + (size_t)w;
-  const int32_t c = q.child[lw];
+  const int32_t cw = q.child[lw];
+  const int32_t kind = (cw >> 28) & 3, c = cw & kFoldIndexMask;
   f3 L = mk3(q.w_r[lw], q.w_g[lw], q.w_b[lw]);
-  if (c != -1) {
+  if (kind != 1) {
     const f3 wv = L;
-    const bool has = (c >= 0);
+    const bool has = (kind == 0);
     const f3 Ln = (has && !deepest) ? mk3(nxt_r[c], nxt_g[c], nxt_b[c]) : mk3(0.0f, 0.0f, 0.0f);
     if (f.render_type == PT_STUPID) L = wv * Ln;
     else {
-      const size_t le = (size_t)(level + 1) * (size_t)q.P + (size_t)(has ? c : 0);
-      const f3 ev = has ? mk3(q.e_r[le], q.e_g[le], q.e_b[le]) : mk3(0.0f, 0.0f, 0.0f);
+      const size_t le = (size_t)(level + 1) * (size_t)q.P + (size_t)c;
+      // e of this level sits at the successor's index one level down; whether it counts is in the successor's record (at the deepest
+      // level k_resolve_last has zeroed it instead: there is no record below)
+      const bool counts = has && (deepest || ((q.child[le] >> 30) & 1) == 0);
+      const f3 ev = counts ? mk3(q.e_r[le], q.e_g[le], q.e_b[le]) : mk3(0.0f, 0.0f, 0.0f);
       L = ev + wv * Ln;
     }
   }
