@@ -874,7 +874,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
       ItemHint ih; ih.key = hk.x; ih.mat = (int32_t)(hk.y >> 9);
       const ItemHint* const hp = (ART_SHADE_HINT && (hk.y & 256u)) ? &ih : nullptr;
       if (keep) slot_out[wo] = (uint32_t)item_slot(Qi, w);
-      if (ART_SHADE_DEFER) n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cx, &ro, hp, CAMERA ? 1 : 0);
+      if (ART_SHADE_DEFER) n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cx, &ro, hp, CAMERA ? 1 : 0, 1);
       else {
         StageCtx cy = tables;
         if (staged) {
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
           cy.stage = s_stage[wave]; cy.stage_pitch = kStagePitch; cy.stage_item = lane; cy.stage_count = nk; cy.lost = lost;
           cy.rec_base[0] = first; cy.rec_base[1] = (per == 2) ? first + (size_t)nk : first;
         }
-        n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cy, nullptr, hp, CAMERA ? 1 : 0);
+        n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cy, nullptr, hp, CAMERA ? 1 : 0, 1);
       }
     }
     if (ART_SHADE_DEFER && Qo.rec != nullptr) {

@@ -510,8 +510,11 @@ ART_HD bool item_survives(const DevFrame& f, const DevScene& s, const DevPaths& 
 // triangle's normals and the material record are then requested together with the item's own words, one round trip instead of three
 // dependent ones (hit -> triangle shading record -> material).
 ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, const DevPaths& qo, int w, int wo, int bounce, unsigned long long* lost = nullptr,
-                      const StageCtx& cx = StageCtx(), RayOut* defer = nullptr, const ItemHint* hint = nullptr, int camera_mode = -1) {
+                      const StageCtx& cx = StageCtx(), RayOut* defer = nullptr, const ItemHint* hint = nullptr, int camera_mode = -1, int dense_mode = -1) {
   ART_PROBE(0);
+  // dense_mode: 1 / 0 = the caller knows which fold records the schedule keeps (k_shade_compact: dense; the dead branches and their
+  // pointer loads then drop out of the kernel), -1 = look at the bank
+  const bool dense = (dense_mode >= 0) ? (dense_mode != 0) : (qi.fold_dense != 0);
   const int slot = item_slot(qi, w);
   const size_t P = (size_t)qi.P;
   const bool camera = (camera_mode >= 0) ? (camera_mode != 0) : (qi.synth0 && qi.slot_id == nullptr);         // bounce 0 of the compacted schedule: raygen stored the hit and nothing else (DevPaths::synth0)
@@ -531,7 +534,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   // the shadow test the item may owe (its words exist for every item; asked for now, used below if the flag says so)
   const bool may_owe = (bounce > 0) && (f.render_type != PT_STUPID);
   DevHit hs = DevHit{0.0f, KEY_MISS, 0.0f, 0.0f}; float owed_min = 0.0f; f3 owed = mk3(0.0f, 0.0f, 0.0f);
-  if (may_owe) { hs = qi.hit[P + (size_t)w]; owed_min = qi.sh_min_t[w]; if (!qi.fold_dense) owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
+  if (may_owe) { hs = qi.hit[P + (size_t)w]; owed_min = qi.sh_min_t[w]; if (!dense) owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
   // (the extension ray is kept as six SoA words next to its trace record: reading it back out of the record would pull the whole
   // 128-byte line of the item's two records for 24 useful bytes)
   f3 o, d; float prev_pdf;
@@ -554,9 +557,9 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   if (fl & FLAG_SHADOW_PENDING) {
     ART_PROBE(1);
     // Compute_Shadow: hit and t < maxDist - eps2 (enforced by the ray's tfar clip) and t > 10*eps
-    if (!may_owe) { hs = qi.hit[P + (size_t)w]; owed_min = qi.sh_min_t[w]; if (!qi.fold_dense) owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
+    if (!may_owe) { hs = qi.hit[P + (size_t)w]; owed_min = qi.sh_min_t[w]; if (!dense) owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
     const bool in_shadow = (hs.key != KEY_MISS) && (hs.t > owed_min);
-    if (qi.fold_dense) rec_shadowed = in_shadow;      // dense fold records: the previous stage left the explicit colour itself at e[bounce][w]; this item's record says whether it counts
+    if (dense) rec_shadowed = in_shadow;      // dense fold records: the previous stage left the explicit colour itself at e[bounce][w]; this item's record says whether it counts
     else {                                            // e of the previous level at [bounce - 1][slot]
       const size_t li = (size_t)(bounce - 1) * P + (size_t)slot;
       qi.e_r[li] = in_shadow ? 0.0f : owed.x;
@@ -573,7 +576,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   const f3 zero = mk3(0.0f, 0.0f, 0.0f);
   auto kill = [&](int levels, f3 terminal) {       // the deepest PathTrace call returned `terminal`; `levels` fold levels were recorded
     fl = (fl & ~(FLAG_ALIVE | 0xffffff00u)) | ((uint32_t)levels << 8);
-    if (qi.fold_dense) { if (levels == bounce) { rec_w = terminal; rec_child = -1; } }     // levels == bounce + 1: a surface at the last bounce, its record stands
+    if (dense) { if (levels == bounce) { rec_w = terminal; rec_child = -1; } }     // levels == bounce + 1: a surface at the last bounce, its record stands
     else {
       qi.term_r[slot] = terminal.x; qi.term_g[slot] = terminal.y; qi.term_b[slot] = terminal.z;
       qi.final_flags[slot] = fl;
@@ -650,7 +653,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
         sh_min = 10.0f * eps;
         shadow = true;
         fl |= FLAG_SHADOW_PENDING;
-      } else if (!qi.fold_dense) {
+      } else if (!dense) {
         qi.e_r[li] = 0.0f; qi.e_g[li] = 0.0f; qi.e_b[li] = 0.0f;
       }
       ART_PROBE(8);
@@ -661,7 +664,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
       no = hpos + (asign(ct) * n) * kGEpsilon;
       nd = bs.dir;
       const f3 wv = fabsf(ct) * bxv;
-      if (qi.fold_dense) { rec_w = wv; rec_child = -2; }          // a surface: its successor's index is known below
+      if (dense) { rec_w = wv; rec_child = -2; }          // a surface: its successor's index is known below
       else { qi.w_r[li] = wv.x; qi.w_g[li] = wv.y; qi.w_b[li] = wv.z; }
       new_pdf = bs.pdf;
       fl = bs.specular ? (fl | FLAG_PREV_SPEC) : (fl & ~FLAG_PREV_SPEC);
@@ -669,7 +672,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     }
   }
   ART_PROBE(40);
-  if (qi.fold_dense && !(ART_DIAG_SKIP & 16)) {                      // dense stores: consecutive items, consecutive addresses
+  if (dense && !(ART_DIAG_SKIP & 16)) {                      // dense stores: consecutive items, consecutive addresses
     const size_t lw = (size_t)bounce * P + (size_t)w;
     qi.w_r[lw] = rec_w.x; qi.w_g[lw] = rec_w.y; qi.w_b[lw] = rec_w.z;
     qi.child[lw] = fold_child_word((rec_child == -2 && wo >= 0) ? wo : rec_child, rec_shadowed);
@@ -689,7 +692,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   qo.prev_pdf[wo] = new_pdf;
   if (shadow) {
     qo.sh_min_t[wo] = sh_min;
-    if (qi.fold_dense) {      // the explicit colour goes straight to where the fold reads e of this level: level bounce + 1, the successor's index
+    if (dense) {      // the explicit colour goes straight to where the fold reads e of this level: level bounce + 1, the successor's index
       const size_t le = (size_t)(bounce + 1) * P + (size_t)wo;
       qi.e_r[le] = cand.x; qi.e_g[le] = cand.y; qi.e_b[le] = cand.z;
     } else { qo.cand_r[wo] = cand.x; qo.cand_g[wo] = cand.y; qo.cand_b[wo] = cand.z; }
