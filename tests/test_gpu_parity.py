@@ -599,3 +599,53 @@ def test_structured_mesh_scene_bit_exact(art, backend):
     ref, _, cnt = orc.render(osc.scene, orc.make_params(80, 64, orc.PT_MIS, True, 8, 2, seed=9))
     assert_radiance_equal(accum, ref, spp)
     assert backend.stats().rays == cnt.rays
+
+
+def test_gcore_single_ray_host_walk_equals_the_gpu_batch_on_edge_rays(art, backend):
+    """The host walk of a single-ray gcore_closest_hit (round 4) against the GPU batch on the rays that stress the window and the slab
+    arithmetic: axis-parallel directions (zero components: 1/d is replaced by +-1e30), t_near > 0 cutting the first hit off, a t_far in
+    front of every triangle, an empty and an inverted window, unnormalised directions, rays starting on a triangle's plane, NaN / inf
+    components.  found flags and every byte of the HitCpp must agree (two-level and flattened scene)."""
+    L = backend.lib
+    F = np.float32
+    rng = np.random.default_rng(21)
+    verts = (rng.random((900, 3)) * 4 - 2).astype(F)
+    idx = rng.integers(0, 900, 2400).astype(np.int32)
+    n = 4000
+    o = (rng.random((n, 3)) * 6 - 3).astype(F)
+    d = rng.normal(size=(n, 3)).astype(F)
+    d[:600] = np.eye(3, dtype=F)[rng.integers(0, 3, 600)] * rng.choice([-1.0, 1.0], 600)[:, None]     # axis-parallel
+    d[600:900, rng.integers(0, 3)] = 0.0                                                                    # one zero component
+    d[900:1200] *= 7.5                                                                                      # unnormalised
+    tn = np.zeros(n, F); tf = np.full(n, 1.0e5, F)
+    tn[1200:1800] = rng.random(600).astype(F) * 3.0                                                         # near cut
+    tf[1800:2400] = rng.random(600).astype(F) * 0.5                                                         # far cut
+    tn[2400:2500] = 2.0; tf[2400:2500] = 2.0                                                                # empty window
+    tn[2500:2600] = 3.0; tf[2500:2600] = 1.0                                                                # inverted window
+    tri = idx[:300].reshape(-1, 3)
+    o[2600:2700] = verts[tri[:, 0]] * F(0.4) + verts[tri[:, 1]] * F(0.3) + verts[tri[:, 2]] * F(0.3)       # origin on a triangle
+    d[2700:2710, 0] = np.nan; d[2710:2720, 1] = np.inf; o[2720:2730, 2] = np.nan
+    for two_level, mats in ((0, np.eye(4, dtype=F)[None]), (1, np.stack([np.eye(4, dtype=F) + np.array([[0, 0, 0, 5.0 * k], [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]], F) for k in range(3)]))):
+        L.gcore_set_two_level(two_level)
+        try:
+            L.gcore_init_and_clear()
+            mid = L.gcore_add_mesh_3f(verts.ctypes.data_as(art.f32p), 900, idx.ctypes.data_as(art.i32p), 2400)
+            mm = np.ascontiguousarray(mats.reshape(-1, 16))
+            L.gcore_instance_meshes(mid, mm.ctypes.data_as(art.f32p), mm.shape[0])
+            L.gcore_commit_scene()
+            hits = (art.HitCpp * n)(); found = (C.c_ubyte * n)()
+            L.gcore_closest_hit_n(n, o.ctypes.data_as(art.f32p), d.ctypes.data_as(art.f32p), tn.ctypes.data_as(art.f32p), tf.ctypes.data_as(art.f32p), hits, found)
+            batch = np.frombuffer(hits, np.uint8).reshape(n, C.sizeof(art.HitCpp)).copy()
+            one = np.zeros_like(batch); f1 = np.zeros(n, np.uint8)
+            for i in range(n):
+                h = art.HitCpp()
+                f1[i] = 1 if L.gcore_closest_hit(o[i].ctypes.data_as(art.f32p), d[i].ctypes.data_as(art.f32p), float(tn[i]), float(tf[i]), C.byref(h)) else 0
+                if f1[i]:
+                    one[i] = np.frombuffer(h, np.uint8)
+            fb = np.array([found[i] for i in range(n)], np.uint8)
+            assert np.array_equal(f1, fb), "found differs on %d rays" % (f1 != fb).sum()
+            assert np.array_equal(one[f1 == 1], batch[f1 == 1])
+            assert f1[:1200].sum() > 100 and f1[2400:2600].sum() == 0 and f1[2700:2730].sum() == 0
+        finally:
+            L.gcore_set_two_level(-1)
+            L.gcore_destroy()
