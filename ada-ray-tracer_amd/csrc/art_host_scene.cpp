@@ -13,6 +13,7 @@ static bool finite3(const float* p) { return std::isfinite(p[0]) && std::isfinit
 bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& out, std::string& err) {
   out = HostScene();
   if (d.n_spheres < 0 || d.n_lights < 1 || d.n_materials < 1 || d.n_meshes < 0) { err = "scene: negative count, or no light / no material (Light_At(0) must exist, scene.adb:45-48)"; return false; }
+  if (d.n_materials >= (1 << 22)) { err = "scene: more than 4 M materials (the shade stage packs a material index into 23 bits of its classification hint)"; return false; }
   if ((d.n_spheres && !d.spheres) || !d.lights || !d.materials || (d.n_meshes && !d.meshes)) { err = "scene: null array pointer"; return false; }
   if (d.n_spheres >= (1 << 28) || d.n_lights > 64) { err = "scene: too many spheres / lights (max 64 lights)"; return false; }
   auto mat_ok = [&](int32_t m) { return m >= 0 && m < d.n_materials; };

@@ -759,6 +759,7 @@ struct ShadeKernArgs {
 #ifndef ART_SHADE_KERNARG
 #define ART_SHADE_KERNARG 1
 #endif
+static_assert(sizeof(ShadeKernArgs) <= 4096 && __is_trivially_copyable(ShadeKernArgs), "ShadeKernArgs is the kernel's ONLY parameter: it sits at offset 0 of the kernarg segment");
 typedef const __attribute__((address_space(4))) ShadeKernArgs* ShadeKArgs;
 __device__ __forceinline__ ShadeKArgs launder_kargs(ShadeKArgs k) { unsigned long long r = (unsigned long long)k; asm volatile("" : "+s"(r)); return (ShadeKArgs)r; }
 

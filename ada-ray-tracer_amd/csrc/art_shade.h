@@ -462,7 +462,7 @@ ART_HD int item_slot(const DevPaths& q, int w) { return q.slot_id ? (int)q.slot_
 // the child word of a dense fold record: bits 0..27 the item at the next bounce, bits 28..29 the kind (0: that item exists; 1: the path ended
 // here, the record's w is its value; 2: a surface whose successor was not kept), bit 30: the shadow test this item resolved for its
 // PREDECESSOR came out "in shadow" (the predecessor's explicit light, e[this level][this item], then counts as 0)
-constexpr int32_t kFoldIndexMask = (1 << 28) - 1;
+constexpr int32_t kFoldIndexMask = (1 << 28) - 1;      // (a batch has at most 2^27 items: art_api.cpp refuses more than 2^28 rays per trace launch)
 ART_HD int32_t fold_child_word(int32_t child, bool shadowed) {
   const int32_t kind = (child >= 0) ? 0 : (child == -1) ? 1 : 2;
   return ((child >= 0) ? child : 0) | (kind << 28) | (shadowed ? (1 << 30) : 0);

@@ -282,7 +282,11 @@ static inline __attribute__((always_inline)) bool host_walk_body(const float* po
 }
 __attribute__((target("fma"))) bool host_walk_fma(const float* pos, const float* dir, float t_near, float t_far, HitCpp* pHit) { return host_walk_body(pos, dir, t_near, t_far, pHit); }
 bool host_walk_generic(const float* pos, const float* dir, float t_near, float t_far, HitCpp* pHit) { return host_walk_body(pos, dir, t_near, t_far, pHit); }
-const bool g_cpu_has_fma = __builtin_cpu_supports("fma") != 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+const bool g_cpu_has_fma = false;                                                             // (the file's device pass: host-only code, never run there)
+#else
+const bool g_cpu_has_fma = (__builtin_cpu_init(), __builtin_cpu_supports("fma") != 0);      // (a static initialiser may run before libgcc's own constructor)
+#endif
 int g_force_gpu_single = 0;          // gcore_set_single_ray_on_gpu (tests): 1 = the flat-combined GPU launches of rounds 2-3
 
 // answers reqs[0..n) with ONE launch (art_trace_rays without statistics: no events, no counter read-back)

@@ -649,3 +649,31 @@ def test_gcore_single_ray_host_walk_equals_the_gpu_batch_on_edge_rays(art, backe
         finally:
             L.gcore_set_two_level(-1)
             L.gcore_destroy()
+
+
+def test_more_spheres_and_lights_than_the_stages_keep_in_lds(art, backend):
+    """The stages keep up to 64 spheres and 8 (shade) / 16 (raygen) lights in LDS and read the scene's own tables otherwise.  A scene with 70
+    spheres and 10 sphere lights + a BVH mesh takes the global-table path in every stage: the accum buffer bit for bit, for MIS and the
+    shadow-ray integrator."""
+    from ada_ray_tracer_amd import scenes
+    rng = np.random.default_rng(5)
+    mats = scenes.cornell_materials()
+    lights, spheres = [], []
+    for k in range(10):
+        mats.append(dict(type=art.MAT_LIGHT, light=k)) if k else mats.__setitem__(4, dict(type=art.MAT_LIGHT, light=0))
+        m = 4 if k == 0 else len(mats) - 1
+        l = scenes.sphere_light(-2.0 + 0.44 * k, m, cy=4.4, cz=1.0 + 0.3 * k, radius=0.12)
+        lights.append(l); spheres.append((l["center"], l["radius"], m))
+    for k in range(60):
+        p = (float(-2.1 + 4.2 * rng.random()), float(0.3 + 3.2 * rng.random()), float(0.4 + 4.0 * rng.random()))
+        spheres.append((p, 0.12, (0, 1, 2, 3, 8)[k % 5]))
+    mesh = scenes.random_triangles(1500, 0xADA5EED0 + 33)
+    sd = art.SceneDesc(spheres=spheres, lights=lights, materials=mats, meshes=[mesh], cornell=scenes.CORNELL_BOX, cam_pos=scenes.REFERENCE_CAMERA)
+    osc = conv.OracleScene(sd)
+    backend.upload_scene(sd)
+    for rt in ("PT_MIS", "PT_SHADOW"):
+        backend.resize(72, 56)
+        accum, _, spp = backend.render_pass(art.Backend.pass_params(getattr(art, rt), True, 6, 2, seed=13), 0)
+        ref, _, cnt = orc.render(osc.scene, orc.make_params(72, 56, getattr(orc, rt), True, 6, 2, seed=13))
+        assert_radiance_equal(accum, ref, spp)
+        assert backend.stats().lost_paths == 0
