@@ -210,22 +210,25 @@ static int download_from(const float* acc_dev, float* accum_host, uint32_t* scre
 // explicit colour, item -> slot map, and the extension ray once more as six SoA words for the next stage: 21 words per bank + 32 words of
 // records in one array shared by the banks.  Plain layout (one-ray-per-lane schedule, debug pass): rays as SoA arrays, 29 words.
 constexpr size_t kRecSlack = 4096;       // records past the last one the trace kernel's chunk prefetch may touch
-static size_t hot_floats(size_t P, bool rec) { return (rec ? (6 + 8 + 7) : (14 + 8 + 7)) * P; }
+// (record schedule: 6 ray words, ONE 16-byte hit record + the shadow ray's result word, 7 per-path words)
+static size_t hot_floats(size_t P, bool rec) { return (rec ? (6 + 4 + 1 + 7) : (14 + 8 + 7)) * P; }
 // (the trace records are not double-banked: a bank's records are dead once its rays are traced, and the next stage reads none of them)
 // cold state: e (depth + 1 levels: dense fold records keep e_k at level k + 1) and w (depth levels) x 3, child (depth levels), term, rad, final flags
-static size_t path_floats(size_t P, int depth, bool rec) { return 2 * hot_floats(P, rec) + (rec ? 32 * P + kRecSlack * 16 + 16 : 0) + (7 * (size_t)depth + 3 + 3 + 3 + 1) * P + 64; }
+// (+ 4 P words: the queue of the items k_shade_compact defers to its heavy-material instantiation, 16 B each, worst case every item)
+static size_t path_floats(size_t P, int depth, bool rec) { return 2 * hot_floats(P, rec) + (rec ? 32 * P + kRecSlack * 16 + 16 + 4 * P + 4 : 0) + (7 * (size_t)depth + 3 + 3 + 3 + 1) * P + 64; }
 
 static int ensure_paths(size_t P, int depth, bool rec) { return ensure(g_ctx.b_paths, path_floats(P, depth, rec) * 4 + 256); }
 
 // q[0], q[1]: the two banks (slot_id = their own map); both share the cold arrays.  An identity-layout user takes q[0] with slot_id = nullptr
 // and final_flags = flags.
-static void carve(DevPaths q[2], int P, int depth, bool rec) {
+static void carve(DevPaths q[2], int P, int depth, bool rec, uint4** heavy = nullptr) {
   float* const f0 = (float*)g_ctx.b_paths.p;
   float* f = f0; const size_t p = (size_t)P;
   auto take = [&](size_t n) { float* r = f; f += n; return r; };
   auto align = [&](size_t floats) { f += (floats - ((size_t)(f - f0) & (floats - 1))) & (floats - 1); };
   Rec4* records = nullptr;
   if (rec) { align(16); records = (Rec4*)take(32 * p + kRecSlack * 16); }       // 64-byte records, ONE array for both banks
+  if (rec) { uint4* const h = (uint4*)take(4 * p); if (heavy) *heavy = h; }     // (still 16-byte aligned)
   for (int k = 0; k < 2; ++k) {
     DevPaths& b = q[k];
     if (rec) {
@@ -238,7 +241,8 @@ static void carve(DevPaths q[2], int P, int depth, bool rec) {
       b.ray_dx = take(2 * p); b.ray_dy = take(2 * p); b.ray_dz = take(2 * p); b.ray_tfar = take(2 * p);
     }
     align(4);                                                                   // 16-byte hit records
-    b.hit = (DevHit*)take(8 * p);
+    if (rec) { b.hit = (DevHit*)take(4 * p); b.sh_t = take(p); }                // the extension ray's hit record; the shadow ray's result is one word (DevPaths::sh_t)
+    else { b.hit = (DevHit*)take(8 * p); b.sh_t = nullptr; }
     b.prev_pdf = take(p); b.flags = (uint32_t*)take(p); b.sh_min_t = take(p);
     b.cand_r = take(p); b.cand_g = take(p); b.cand_b = take(p);
     b.slot_id = (const uint32_t*)take(p);
@@ -285,7 +289,7 @@ static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
   { int e; bool o; stack_plan(c.trace_kernel, e, o); a.stack_entries = e; a.stack_overflow = o ? 1 : 0; }
   a.node_min = c.node_min; a.refill_min = c.refill_min; a.segments = c.queue_segments; a.chunk = c.ray_chunk;
   a.ray_ox = q.ray_ox; a.ray_oy = q.ray_oy; a.ray_oz = q.ray_oz; a.ray_dx = q.ray_dx; a.ray_dy = q.ray_dy; a.ray_dz = q.ray_dz; a.ray_tfar = q.ray_tfar;
-  a.hit = q.hit;
+  a.hit = q.hit; a.sh_t = q.sh_t;
   a.nodes = c.scene.nodes; a.qnodes = (const uint32_t*)c.b_qnodes.p; a.tris = c.scene.tris; a.qtris = (const float*)c.b_qtris.p; a.n_tris = c.scene.n_tris;
   a.sh_min = (c.shadow_anyhit && q.sh_min_t && n_rays > q.P) ? q.sh_min_t : nullptr; a.shadow_begin = q.P;
   a.cursor = c.d_cursor; a.stats = c.d_counters + 3; a.live_rays = c.d_counters;
@@ -436,7 +440,8 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
         const int sn = std::min(sc, S - s0);
         DevPaths bank[2]; std::memset(bank, 0, sizeof bank);
         for (DevPaths& b : bank) { b.P = pn * sn; b.npix = pn; b.pixmap = (const uint32_t*)c.b_pixmap.p + px0; b.sample_base = (uint32_t)(c.spp + s0); }
-        carve(bank, bank[0].P, p->max_depth, c.trace_kernel == TRACE_COOP);
+        uint4* heavy = nullptr;
+        carve(bank, bank[0].P, p->max_depth, c.trace_kernel == TRACE_COOP, &heavy);
         c.camera_rays += (uint64_t)bank[0].P;
         if (c.trace_kernel == TRACE_COOP) {
           // Compacted work sets: raygen fills bank 0 (one item per slot); stage b shades the items of bank b & 1 and writes the survivors
@@ -456,9 +461,9 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
             const bool last = b + 1 >= p->max_depth;
             bank[out].rec_mode = (p->render_type == ART_PT_STUPID) ? REC_EXT : (last ? REC_SHADOW : REC_BOTH);
             int* const n_in = c.d_live + 32 * b; int* const n_out = c.d_live + 32 * (b + 1);      // per level: the fold walks them again
-            HIP_TRY(hipMemsetAsync(n_out, 0, sizeof(int), c.stream));
+            HIP_TRY(hipMemsetAsync(n_out, 0, 2 * sizeof(int), c.stream));         // n_out[1]: the items this stage defers to its heavy-material kernel
             launch_shade_compact(c.stream, F, c.scene, qi, bank[out], b, b == 0 ? nullptr : n_in, n_out,
-                                 const_cast<uint32_t*>(bank[out].slot_id), c.d_counters + 15, c.d_counters, rays_b);
+                                 const_cast<uint32_t*>(bank[out].slot_id), c.d_counters + 15, c.d_counters, rays_b, c.shade_split ? heavy : nullptr, n_out + 1);
             if (g_debug_live) {
               int n = -1; unsigned long long r0 = 0;
               (void)hipStreamSynchronize(c.stream); (void)hipMemcpy(&n, n_out, 4, hipMemcpyDeviceToHost); (void)hipMemcpy(&r0, c.d_counters, 8, hipMemcpyDeviceToHost);
@@ -766,7 +771,7 @@ int art_init_devices(int32_t n, const int32_t* ordinals) {
     Ctx& c = g_devs[k];
     c = Ctx();
     c.trace_kernel = opts.trace_kernel; c.batch_paths = opts.batch_paths; c.bvh_params = opts.bvh_params; c.node_min = opts.node_min; c.refill_min = opts.refill_min;
-    c.queue_segments = opts.queue_segments; c.ray_chunk = opts.ray_chunk; c.shadow_anyhit = opts.shadow_anyhit; c.lds_stack_cap = opts.lds_stack_cap;
+    c.queue_segments = opts.queue_segments; c.ray_chunk = opts.ray_chunk; c.shadow_anyhit = opts.shadow_anyhit; c.shade_split = opts.shade_split; c.lds_stack_cap = opts.lds_stack_cap;
     c.opt_blocks_per_cu = opts.opt_blocks_per_cu; c.count_tests = opts.count_tests;
     c.device = ord[k]; c.rank = k; c.nranks = n; c.tile = 32;
     if (use_dev(k) || ensure_device()) { shutdown(); return 1; }
@@ -910,6 +915,7 @@ static int set_option_one(const std::string& n, int64_t value) {
   else if (n == "blocks_per_cu") { g_ctx.opt_blocks_per_cu = (int)value; g_ctx.blocks_per_cu = 0; }
   else if (n == "count_tests") { g_ctx.count_tests = value != 0; }
   else if (n == "shadow_anyhit") { g_ctx.shadow_anyhit = value != 0; }
+  else if (n == "shade_split") { g_ctx.shade_split = value != 0; }
   else if (n == "ray_chunk") { if (value < 16 || value > 4096 || (value & 15)) return fail("ray_chunk: a multiple of 16, 16..4096"); g_ctx.ray_chunk = (int)value; }
   else if (n == "refill_min") { if (value < 1 || value > 8) return fail("refill_min: 1..8"); g_ctx.refill_min = (int)value; }
   else if (n == "node_min") { if (value < 1 || value > 8) return fail("node_min: 1..8"); g_ctx.node_min = (int)value; }

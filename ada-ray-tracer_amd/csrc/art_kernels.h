@@ -26,6 +26,7 @@ struct TraceArgs {
   // sh_min[i - shadow_begin] = 10*eps.  nullptr: every ray is a closest-hit query.
   const float* sh_min; int32_t shadow_begin;
   DevHit* hit;
+  float* sh_t;                  // record schedule: a record whose hit-slot word has kShadowWord set leaves its result as ONE float, sh_t[word & ~kShadowWord] = t of the hit (DevPaths::sh_t)
   const float* nodes; const uint32_t* qnodes; const float* tris; const float* qtris; int32_t n_tris;   // qnodes: 64-byte quantised nodes (width 4, art_qnode.h)   // BVH of the closest-hit mesh (hot-loop operands)
   int32_t chunk;                // trace records a wave claims per atomic on the cursor (a multiple of 16: prefetched 16 records per load)
   int* cursor;                  // work cursors, zeroed before every launch: segment k's cursor is cursor[32 * (k + 1)] (cursor[0] serves the
@@ -52,7 +53,8 @@ void launch_finish(hipStream_t st, const DevFrame& F, const DevPaths& Q, int las
 // compacted work sets (k_shade_compact): shade the items of Qi, write the survivors densely to Qo (+ their slot ids); n_in nullptr: all Qi.P items
 // rays_a / rays_b: += the rays the stage emits as trace records (Qo.rec != nullptr); rays_b may be nullptr
 void launch_shade_compact(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Qi, const DevPaths& Qo, int bounce,
-                          const int* n_in, int* n_out, uint32_t* slot_out, unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b);
+                          const int* n_in, int* n_out, uint32_t* slot_out, unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b,
+                          uint4* heavy = nullptr, int* n_heavy = nullptr);      // heavy: the queue of deferred items (16 B x Qi.P), n_heavy: its count (zeroed by the caller); nullptr: one kernel for every material
 void launch_resolve_last(hipStream_t st, const DevPaths& Q, const int* n, int last_level);
 void launch_fold(hipStream_t st, const DevFrame& F, const DevPaths& Q);
 void launch_fold_levels(hipStream_t st, const DevFrame& F, const DevPaths& Q, int max_depth, const int* counts);     // dense fold records: counts[32 k] = items of level k

@@ -19,6 +19,8 @@
 // Replaces Scene.Find_Closest_Hit (scene.adb:56-86), the Embree bridge (embree_connect.cpp:196-238),
 // PathTrace (ray_tracer-integrators.adb:82-301) and the DoPass pixel loop (integrators.adb:25-71).
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <type_traits>
 #include "art_kernels.h"
 
 namespace art {
@@ -189,8 +191,7 @@ __device__ __forceinline__ uint32_t key_masked(mask_t hit, uint32_t tmn_bits, ui
 }
 
 // scalar base + 32-bit byte offset: the address costs no vector instruction (a 64-bit pointer per array costs a v_lshl_add_u64 each)
-template <class T> __device__ __forceinline__ T ld_off(const T* base, uint32_t byte_off) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off); }
-template <class T> __device__ __forceinline__ void st_off(T* base, uint32_t byte_off, T v) { *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v; }
+// (ld_off / st_off: art_math.h)
 
 // ------------------------------------------------------------------------------------------------
 // cooperative persistent trace kernel
@@ -416,7 +417,10 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       if (lane_of(done)) {
         // Only a hit found by THIS kernel needs storing, by the lane that holds it and as one 16-byte record: the starting bound (no hit,
         // or an analytic / brute-force hit) was stored by k_analytic, a shadow ray's far hit at the moment it was found (below).
-        if (best_key != KEY_MISS && held_key == best_key) st_off(A.hit, (uint32_t)ray << 4, DevHit{best_t, best_key, held_u, held_v});
+        if (best_key != KEY_MISS && held_key == best_key) {
+          if (ray < 0) st_off(A.sh_t, ((uint32_t)ray & ~kShadowWord) << 2, best_t);           // a shadow ray of the record schedule: its t is all the stage asks for
+          else st_off(A.hit, (uint32_t)ray << 4, DevHit{best_t, best_key, held_u, held_v});
+        }
       }
       has_ray &= ~done;
     }
@@ -455,7 +459,10 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       if (ballot64(sh_hit) != 0) {                         // shadow_rule, group-uniform
         const bool near = sh_hit && (win_t <= shm);
         const bool far = sh_hit && !near;                  // first far hit (afterwards the bound is <= shm)
-        if (far && j == 0) st_off(A.hit, (uint32_t)ray << 4, DevHit{win_t, (uint32_t)win, 0.0f, 0.0f});
+        if (far && j == 0) {
+          if (ray < 0) st_off(A.sh_t, ((uint32_t)ray & ~kShadowWord) << 2, win_t);
+          else st_off(A.hit, (uint32_t)ray << 4, DevHit{win_t, (uint32_t)win, 0.0f, 0.0f});
+        }
         far_found = far_found || far;
         best_t = far ? next_up_pos(shm) : best_t;
         best_key = far ? KEY_MISS : best_key;
@@ -494,8 +501,10 @@ __global__ __launch_bounds__(256) void k_trace_overflow(const DevScene* __restri
     Cand best; best.t = r0.w; best.key = __builtin_bit_cast(uint32_t, r1.w); best.u = 0.0f; best.v = 0.0f;
     ShadowState sh; sh.shm = r2.w; sh.far = far0; sh.rep = best;
     bvh_closest<STATS>(S, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), best, &st, sh);
-    if (best.key != KEY_MISS && (best.key & ~KEY_INDEX_MASK) == KEY_TRI) A.hit[i] = DevHit{best.t, best.key, best.u, best.v};
-    else if (sh.far && !far0) A.hit[i] = DevHit{sh.rep.t, sh.rep.key, 0.0f, 0.0f};
+    const bool word = i < 0;                                   // kShadowWord: the result is one float (DevPaths::sh_t)
+    const uint32_t wi = (uint32_t)i & ~kShadowWord;
+    if (best.key != KEY_MISS && (best.key & ~KEY_INDEX_MASK) == KEY_TRI) { if (word) A.sh_t[wi] = best.t; else A.hit[i] = DevHit{best.t, best.key, best.u, best.v}; }
+    else if (sh.far && !far0) { if (word) A.sh_t[wi] = sh.rep.t; else A.hit[i] = DevHit{sh.rep.t, sh.rep.key, 0.0f, 0.0f}; }
   }
 }
 
@@ -755,6 +764,7 @@ constexpr int kShadePerThread = ART_SHADE_PER;
 struct ShadeKernArgs {
   DevFrame F; DevScene S; DevPaths Qi; DevPaths Qo; int bounce;
   const int* n_in_ptr; int* n_out_ptr; uint32_t* slot_out; unsigned long long* lost; unsigned long long* rays_a; unsigned long long* rays_b;
+  uint4* heavy; int* n_heavy_ptr;          // the deferred items of the heavy material classes (SET_LIGHT appends, SET_HEAVY consumes) and their count
 };
 #ifndef ART_SHADE_KERNARG
 #define ART_SHADE_KERNARG 1
@@ -763,9 +773,41 @@ static_assert(sizeof(ShadeKernArgs) <= 4096 && __is_trivially_copyable(ShadeKern
 typedef const __attribute__((address_space(4))) ShadeKernArgs* ShadeKArgs;
 __device__ __forceinline__ ShadeKArgs launder_kargs(ShadeKArgs k) { unsigned long long r = (unsigned long long)k; asm volatile("" : "+s"(r)); return (ShadeKArgs)r; }
 
-template <int PER, bool CAMERA>
-// 6 waves per SIMD (80 VGPRs): left to itself the compiler takes 111 VGPRs = 4 waves (6.6 -> 6.2 ms per launch on C4, round 3)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_WAVES))) void k_shade_compact(const ShadeKernArgs A_by_value) {
+// ---- one instantiation per REGISTER CLASS (round 5).  Until round 4 ONE kernel carried every material: it sat at the 80-VGPR cap of 6 waves
+// per SIMD with spills, for a Lambert majority that needs none of Phong's four binary64 pow evaluations or the glass branch.  Now:
+//   SET_LIGHT   shades the classes outside kHeavyClasses (Lambert, mirror, and the paths that end: CLS_CHEAP) and contains no instruction of
+//               the heavy materials; the heavy items it meets are appended, { item, hit key, material | class << 24 }, to a queue in HBM
+//               (one global atomic per workgroup, 16 B per deferred item);
+//   SET_HEAVY   a second launch over that queue: the same three steps (sort by class, reserve, shade), compiled for the heavy materials only.
+//               Its survivors follow the light kernel's in the output bank (the order of the items of a bank carries no meaning: item -> slot
+//               map, fold records linked by child index).
+//   SET_ALL     the round-4 kernel (every class in one instantiation), kept for A/B: -DART_SHADE_SPLIT=0.
+enum ShadeSet : int { SET_ALL = 0, SET_LIGHT = 1, SET_HEAVY = 2 };
+#ifndef ART_SHADE_SPLIT
+#define ART_SHADE_SPLIT 1
+#endif
+#ifndef ART_HEAVY_CLASSES
+#define ART_HEAVY_CLASSES ((1 << CLS_PHONG) | (1 << CLS_GLASS))
+#endif
+constexpr int kHeavyClasses = ART_HEAVY_CLASSES;
+constexpr int kHeavyMats = ((kHeavyClasses >> CLS_PHONG & 1) ? mat_bit(MAT_PHONG) : 0) | ((kHeavyClasses >> CLS_GLASS & 1) ? mat_bit(MAT_GLASS) : 0) |
+                           ((kHeavyClasses >> CLS_MIRROR & 1) ? mat_bit(MAT_MIRROR) : 0) | ((kHeavyClasses >> CLS_LAMBERT & 1) ? mat_bit(MAT_LAMBERT) : 0);
+constexpr int set_mats(int set) { return set == SET_ALL ? kMatsAll : set == SET_LIGHT ? (kMatsAll & ~kHeavyMats) : (kHeavyMats | mat_bit(MAT_NULL)); }
+constexpr bool class_in_set(int set, int q) { return set == SET_ALL ? true : set == SET_LIGHT ? !(kHeavyClasses >> q & 1) : (kHeavyClasses >> q & 1) != 0; }
+#ifndef ART_SHADE_LIGHT_HINT
+#define ART_SHADE_LIGHT_HINT 1
+#endif
+#ifndef ART_SHADE_WAVES_LIGHT
+#define ART_SHADE_WAVES_LIGHT ART_SHADE_WAVES
+#endif
+#ifndef ART_SHADE_WAVES_HEAVY
+#define ART_SHADE_WAVES_HEAVY ART_SHADE_WAVES
+#endif
+constexpr int set_waves(int set) { return set == SET_LIGHT ? ART_SHADE_WAVES_LIGHT : set == SET_HEAVY ? ART_SHADE_WAVES_HEAVY : ART_SHADE_WAVES; }
+
+template <int PER, bool CAMERA, int SET>
+// SET_ALL: 6 waves per SIMD (80 VGPRs): left to itself the compiler takes 111 VGPRs = 4 waves (6.6 -> 6.2 ms per launch on C4, round 3)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(set_waves(SET)))) void k_shade_compact(const ShadeKernArgs A_by_value) {
 #if ART_SHADE_KERNARG
   ShadeKArgs K = launder_kargs((ShadeKArgs)__builtin_amdgcn_kernarg_segment_ptr());
 #define ART_KREF(T, field) (*(const T*)&K->field)
@@ -773,25 +815,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
   const ShadeKernArgs* const K = &A_by_value;
 #define ART_KREF(T, field) (K->field)
 #endif
+  constexpr int MATS = set_mats(SET);
   const DevFrame& F = ART_KREF(DevFrame, F); const DevScene& S = ART_KREF(DevScene, S); const DevPaths& Qi = ART_KREF(DevPaths, Qi); const DevPaths& Qo = ART_KREF(DevPaths, Qo);
   const int bounce_arg = K->bounce;
-  const int* const n_in_ptr = K->n_in_ptr; int* const n_out_ptr = K->n_out_ptr; uint32_t* const slot_out = K->slot_out;
-  unsigned long long* const lost = K->lost; unsigned long long* const rays_a = K->rays_a; unsigned long long* const rays_b = K->rays_b;
+  const int* const n_in_ptr = K->n_in_ptr; int* const n_out_ptr = K->n_out_ptr;
+  unsigned long long* const rays_a = K->rays_a; unsigned long long* const rays_b = K->rays_b;
   const int bounce = CAMERA ? 0 : bounce_arg;            // (a literal for the camera instantiation: no shadow test can be owed, nothing is pending)
   constexpr int kShadeChunk = 256 * PER;
   __shared__ int s_tot[PER * kItemClasses];                // items of each class in each round (256 items) of the chunk
-  __shared__ int s_base, s_rays;
+  __shared__ int s_base, s_rays, s_hbase;
   __shared__ int s_nall[PER], s_nkeep[PER], s_out0[PER];   // per round: items, survivors, first output item (relative to s_base)
   // [round][sorted position] -> { hit key, thread that classified the item | surface flag << 8 | material index << 9 }: what the
   // classification fetched goes along (ItemHint), so that shade_item asks for the triangle's normals and the material record at once
-  __shared__ uint2 s_hint[kShadeChunk];
+  constexpr bool kHints = (ART_SHADE_HINT != 0) && !(SET == SET_LIGHT && ART_SHADE_LIGHT_HINT == 0);      // SET_LIGHT without hints: one byte per item (the thread that classified it) -- 1 KB instead of 8: with it the workgroup's LDS fits 8 times into a CU
+  __shared__ typename std::conditional<kHints, uint2, uint8_t>::type s_hint[kShadeChunk];
   // a wave's trace records of one kind, [quarter][record] (+1: four consecutive records' quarters fall into four banks)
   constexpr int kStagePitch = 64 + 1;
   __shared__ Rec4 s_stage[4][4 * kStagePitch];
   constexpr int kShadeLdsLights = 8;                    // (8, not k_analytic's 16: with the hints the workgroup's LDS must stay below 160 KB / 6)
   __shared__ DevSphere s_sph[kAnalyticLdsSpheres];      // the scene's spheres and lights, fetched once per workgroup (every emitted ray is tested against them)
   __shared__ DevLight s_lgt[kShadeLdsLights];
-  const int n_in = n_in_ptr ? *n_in_ptr : Qi.P;
+  // the input set: the bank's items (n_in of them), or -- SET_HEAVY -- the entries of the deferred queue
+  const int n_in = (SET == SET_HEAVY) ? *K->n_heavy_ptr : (n_in_ptr ? *n_in_ptr : Qi.P);
   const int c0 = blockIdx.x * kShadeChunk;
   if (c0 >= n_in) return;                                // the grid covers Qi.P items; the work set has shrunk to n_in
   // (the material table stays in global memory: a 40-byte per-lane-indexed record out of LDS measured 7 % slower than the cached global read)
@@ -809,14 +854,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
   const uint64_t lanes_below = (1ull << lane) - 1ull;
   // ---- 1. classify; a wave's items of one class take consecutive places in the class (of their round)
   int cls[PER], rank[PER]; ItemHint hint[PER];
-#pragma unroll      // the PER classifications are independent chains of loads (flags, hit -> triangle record -> material): issued together (-6 %)
+  {
+    // the PER classifications as ONE batch of loads per step (item_classes: 3 memory round trips; item by item through item_class they were 20)
+    int wk[PER]; bool on[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { wk[k] = c0 + k * 256 + (int)threadIdx.x; on[k] = wk[k] < n_in; hint[k].key = KEY_MISS; hint[k].mat = 0; cls[k] = kItemClasses; }
+    if (SET == SET_HEAVY) {
+      uint4 e[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) e[k] = K->heavy[on[k] ? wk[k] : 0];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) if (on[k]) { hint[k].key = e[k].y; hint[k].mat = (int32_t)(e[k].z & 0xffffffu); cls[k] = (int)(e[k].z >> 24); }
+    } else item_classes<PER>(S, Qi, wk, on, tables, CAMERA, cls, hint);
+  }
+#pragma unroll
   for (int k = 0; k < PER; ++k) {
-    const int w = c0 + k * 256 + threadIdx.x;
-    hint[k].key = KEY_MISS; hint[k].mat = 0;
-    int c = (w < n_in) ? item_class(S, Qi, w, tables, &hint[k], CAMERA ? 1 : 0) : kItemClasses;
+    int c = cls[k];
     const bool surface = c < CLS_CHEAP;
-    hint[k].mat = (int32_t)(threadIdx.x | (surface ? 256u : 0u) | ((uint32_t)hint[k].mat << 9));
-    if (!ART_SHADE_SORT && c < CLS_CHEAP) c = CLS_LAMBERT;
+    if (SET == SET_LIGHT && c < kItemClasses && !class_in_set(SET_LIGHT, c)) hint[k].mat |= c << 24;          // (a deferred item's queue entry carries its class)
+    else hint[k].mat = (int32_t)(threadIdx.x | (surface ? 256u : 0u) | ((uint32_t)hint[k].mat << 9));
+    if (!ART_SHADE_SORT && SET == SET_ALL && c < CLS_CHEAP) c = CLS_LAMBERT;
     cls[k] = c; rank[k] = 0;
 #pragma unroll
     for (int q = 0; q < kItemClasses; ++q) {
@@ -834,23 +891,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
   // The sort stays inside a round's 256 items: the four waves of the workgroup then read one 1-KB window of every array at the same time
   // (sorted over the whole chunk, a wave's loads touched lines whose other halves were fetched again three rounds later: +43 % bytes
   // fetched, +22 % written back, 16-27 % slower although it ran 29 % fewer VALU instructions -- profiles/r4_shade/ab_sort_chunk.txt)
+  // SET_LIGHT: the classes of kHeavyClasses are left out of the rounds; their items go to the deferred queue, class by class and round by round
   const bool keeps = stage_keeps_surfaces(F, bounce);
-  int total_keep = 0;
+  if (SET == SET_LIGHT) {
+    if (threadIdx.x == 0) {
+      int nh = 0;
+      for (int k = 0; k < PER; ++k)
+        for (int q = 0; q < kItemClasses; ++q) if (!class_in_set(SET_LIGHT, q)) nh += s_tot[k * kItemClasses + q];
+      s_hbase = nh ? atomicAdd(K->n_heavy_ptr, nh) : 0;
+    }
+  }
+  int total_keep = 0, total_heavy = 0;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
-    int st = 0, mine = 0, nkeep = 0;
+    int st = 0, mine = 0, nkeep = 0, hv = total_heavy, hmine = 0;
 #pragma unroll
     for (int q = 0; q < kItemClasses; ++q) {
-      mine = (cls[k] == q) ? st : mine;
       if (q == CLS_CHEAP) nkeep = keeps ? st : 0;
-      st += s_tot[k * kItemClasses + q];
+      const int nq = s_tot[k * kItemClasses + q];
+      if (SET == SET_LIGHT && !class_in_set(SET_LIGHT, q)) { hmine = (cls[k] == q) ? hv : hmine; hv += nq; continue; }
+      mine = (cls[k] == q) ? st : mine;
+      st += nq;
     }
     if (threadIdx.x == 0) { s_nall[k] = st; s_nkeep[k] = nkeep; s_out0[k] = total_keep; }
-    total_keep += nkeep;
-    if (cls[k] < kItemClasses) s_hint[k * 256 + mine + rank[k]] = make_uint2(hint[k].key, (uint32_t)hint[k].mat);
+    total_keep += nkeep; total_heavy = hv;
+    const bool deferred = (SET == SET_LIGHT) && cls[k] < kItemClasses && !class_in_set(SET_LIGHT, cls[k]);
+    if (deferred) rank[k] += hmine - (1 << 30);           // its place in the workgroup's piece of the queue (marked: written once s_hbase is known)
+    else if (cls[k] < kItemClasses) {
+      if constexpr (kHints) s_hint[k * 256 + mine + rank[k]] = make_uint2(hint[k].key, (uint32_t)hint[k].mat);
+      else s_hint[k * 256 + mine + rank[k]] = (uint8_t)threadIdx.x;
+    }
   }
   if (threadIdx.x == 0) s_base = total_keep ? atomicAdd(n_out_ptr, total_keep) : 0;
   __syncthreads();
+  if (SET == SET_LIGHT) {
+    const int hbase = s_hbase;
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+      if (rank[k] < 0) K->heavy[hbase + rank[k] + (1 << 30)] = make_uint4((uint32_t)(c0 + k * 256 + (int)threadIdx.x), hint[k].key, (uint32_t)hint[k].mat, 0u);
+  }
   const int base = s_base;
   // ---- 3. shade in sorted order
   const bool staged = (Qo.rec != nullptr) && Qo.has_bvh;
@@ -863,6 +942,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
     const ShadeKArgs K2 = launder_kargs(K);               // the round's own view of the arguments: nothing loaded before survives in a register
     const DevFrame& F = *(const DevFrame*)&K2->F; const DevScene& S = *(const DevScene*)&K2->S; const DevPaths& Qi = *(const DevPaths*)&K2->Qi; const DevPaths& Qo = *(const DevPaths*)&K2->Qo;
     uint32_t* const slot_out = K2->slot_out; unsigned long long* const lost = K2->lost;
+#else
+    uint32_t* const slot_out = K->slot_out; unsigned long long* const lost = K->lost;
+    const ShadeKernArgs* const K2 = K;
 #endif
     const int r = (int)threadIdx.x;                       // position in the sorted round
     const int n_all_k = s_nall[k], n_keep_k = s_nkeep[k], out0_k = s_out0[k];
@@ -870,12 +952,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
     const int wo = keep ? base + out0_k + r : -1;
     RayOut ro; ro.alive = false; ro.shadow = false; ro.no = ro.nd = ro.so = ro.sd = mk3(0.0f, 0.0f, 0.0f); ro.s_tfar = -1.0f; ro.sh_min = 0.0f;
     if (r < n_all_k) {
-      const uint2 hk = s_hint[k * 256 + r];
-      const int w = c0 + k * 256 + (int)(hk.y & 255u);
+      uint2 hk;
+      if constexpr (kHints) hk = s_hint[k * 256 + r]; else hk = make_uint2(KEY_MISS, (uint32_t)s_hint[k * 256 + r]);
+      int w = c0 + k * 256 + (int)(hk.y & 255u);
+      if (SET == SET_HEAVY) w = (int)K2->heavy[w].x;       // the queue entry names the item
       ItemHint ih; ih.key = hk.x; ih.mat = (int32_t)(hk.y >> 9);
       const ItemHint* const hp = (ART_SHADE_HINT && (hk.y & 256u)) ? &ih : nullptr;
-      if (keep) slot_out[wo] = (uint32_t)item_slot(Qi, w);
-      if (ART_SHADE_DEFER) n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cx, &ro, hp, CAMERA ? 1 : 0, 1);
+      // (the output item's slot word is written by shade_item with the item's other words: qo.slot_id IS slot_out)
+      if (ART_SHADE_DEFER) n_rays += shade_item<MATS>(F, S, Qi, Qo, w, wo, bounce, lost, cx, &ro, hp, CAMERA ? 1 : 0, 1);
       else {
         StageCtx cy = tables;
         if (staged) {
@@ -884,7 +968,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
           cy.stage = s_stage[wave]; cy.stage_pitch = kStagePitch; cy.stage_item = lane; cy.stage_count = nk; cy.lost = lost;
           cy.rec_base[0] = first; cy.rec_base[1] = (per == 2) ? first + (size_t)nk : first;
         }
-        n_rays += shade_item(F, S, Qi, Qo, w, wo, bounce, lost, cy, nullptr, hp, CAMERA ? 1 : 0, 1);
+        n_rays += shade_item<MATS>(F, S, Qi, Qo, w, wo, bounce, lost, cy, nullptr, hp, CAMERA ? 1 : 0, 1);
       }
     }
     if (ART_SHADE_DEFER && Qo.rec != nullptr) {
@@ -900,7 +984,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ART_SHADE_W
           TraceRec t;
           if (keep) {
             t = (kind == 0) ? make_record(S, Qo, (size_t)wo, ro.alive, ro.no, ro.nd, kInfinity, -1.0f, cx)
-                            : make_record(S, Qo, (size_t)Qo.P + (size_t)wo, ro.shadow, ro.so, ro.sd, ro.s_tfar, Qo.shadow_rule ? ro.sh_min : -1.0f, cx);
+                            : make_record(S, Qo, Qo.sh_t ? (size_t)(kShadowWord | (uint32_t)wo) : (size_t)Qo.P + (size_t)wo, ro.shadow, ro.so, ro.sd, ro.s_tfar, Qo.shadow_rule ? ro.sh_min : -1.0f, cx);
           }
           if (staged) {
             Rec4* const stage = s_stage[wave];
@@ -1036,15 +1120,31 @@ void launch_shade(hipStream_t st, const DevFrame& F, const DevScene& S, const De
 __global__ void k_probe_on(int v) { g_lane_probe_on = v; }
 #endif
 void launch_shade_compact(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Qi, const DevPaths& Qo, int bounce,
-                          const int* n_in, int* n_out, uint32_t* slot_out, unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b) {
+                          const int* n_in, int* n_out, uint32_t* slot_out, unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b,
+                          uint4* heavy, int* n_heavy) {
   const bool camera = Qi.synth0 && Qi.slot_id == nullptr;
   const dim3 grid((Qi.P + 256 * kShadePerThread - 1) / (256 * kShadePerThread));
 #if defined(ART_LANE_PROBE)
   hipLaunchKernelGGL(k_probe_on, dim3(1), dim3(1), 0, st, 1);
 #endif
   ShadeKernArgs A; A.F = F; A.S = S; A.Qi = Qi; A.Qo = Qo; A.bounce = bounce; A.n_in_ptr = n_in; A.n_out_ptr = n_out; A.slot_out = slot_out; A.lost = lost; A.rays_a = rays_a; A.rays_b = rays_b;
-  if (camera) hipLaunchKernelGGL((k_shade_compact<kShadePerThread, true>), grid, dim3(256), 0, st, A);
-  else hipLaunchKernelGGL((k_shade_compact<kShadePerThread, false>), grid, dim3(256), 0, st, A);
+  A.heavy = heavy; A.n_heavy_ptr = n_heavy;
+  const bool split = ART_SHADE_SPLIT && heavy != nullptr && n_heavy != nullptr;
+  if (!split) {
+    if (camera) hipLaunchKernelGGL((k_shade_compact<kShadePerThread, true, SET_ALL>), grid, dim3(256), 0, st, A);
+    else hipLaunchKernelGGL((k_shade_compact<kShadePerThread, false, SET_ALL>), grid, dim3(256), 0, st, A);
+  } else {
+    // the light classes, then the deferred items of the heavy ones (their count is only known on the device: the grid covers the
+    // worst case, workgroups past the queue's end return at once)
+    const dim3 hgrid = grid;
+    if (camera) {
+      hipLaunchKernelGGL((k_shade_compact<kShadePerThread, true, SET_LIGHT>), grid, dim3(256), 0, st, A);
+      hipLaunchKernelGGL((k_shade_compact<kShadePerThread, true, SET_HEAVY>), hgrid, dim3(256), 0, st, A);
+    } else {
+      hipLaunchKernelGGL((k_shade_compact<kShadePerThread, false, SET_LIGHT>), grid, dim3(256), 0, st, A);
+      hipLaunchKernelGGL((k_shade_compact<kShadePerThread, false, SET_HEAVY>), hgrid, dim3(256), 0, st, A);
+    }
+  }
 #if defined(ART_LANE_PROBE)
   hipLaunchKernelGGL(k_probe_on, dim3(1), dim3(1), 0, st, 0);
 #endif

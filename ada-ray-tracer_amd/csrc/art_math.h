@@ -21,6 +21,14 @@ namespace art {
 
 struct f3 { float x, y, z; };
 
+// scalar base + 32-bit byte offset: on the device the address costs no vector instruction and no VGPR pair (a 64-bit pointer per array costs a
+// v_lshl_add_u64 and two registers each).  The caller guarantees that the offset fits 32 bits.  at(base, i) = base[i] through it.
+template <class T> ART_HD T ld_off(const T* base, uint32_t byte_off) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off); }
+template <class T> ART_HD void st_off(T* base, uint32_t byte_off, T v) { *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v; }
+// at(base, i) / put(base, i, v): base[i] that way -- every per-item array of a path bank has fewer than 2^27 items of at most 16 bytes
+template <class T> ART_HD T at(const T* base, int i) { return ld_off(base, (uint32_t)i * (uint32_t)sizeof(T)); }
+template <class T> ART_HD void put(T* base, int i, T v) { st_off(base, (uint32_t)i * (uint32_t)sizeof(T), v); }
+
 constexpr float kInfinity = 3.4028234663852886e38f;  // vector_math.ads:17 (Float'Last, finite)
 constexpr float kPi       = 0x1.921fb6p+1f;          // vector_math.ads:19
 constexpr float kInvPi    = 0x1.45f306p-2f;          // vector_math.ads:20

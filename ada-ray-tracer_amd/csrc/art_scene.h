@@ -102,6 +102,11 @@ struct DevPaths {
   float* ray_tfar;
   // hits, same indexing
   DevHit* hit;
+  // Record schedule (round 5): a SHADOW ray's result is ONE word, sh_t[item] = t of the closest hit the search ended with, or -1 (none) --
+  // Compute_Shadow only asks whether that t lies above 10 eps (ray_tracer.adb:122), so the 16-byte record (key, u, v) was 12 bytes
+  // written by the stage, 12 read by the next one and a 16-byte store of the trace kernel for nothing.  The record names the word by
+  // kShadowWord | item (art_kernels.h TraceArgs::sh_t).  nullptr: the plain layout, shadow hits at hit[P + item].
+  float* sh_t;
   // per-path
   float* prev_pdf;              // MatSample.pdf of the previous bounce
   uint32_t* flags;              // bit0 alive, bit1 prev pureSpecular, bit2 shadow pending, bits 8.. levels recorded
@@ -147,5 +152,6 @@ struct DevPaths {
 };
 
 constexpr uint32_t FLAG_ALIVE = 1u, FLAG_PREV_SPEC = 2u, FLAG_SHADOW_PENDING = 4u;
+constexpr uint32_t kShadowWord = 0x80000000u;      // hit-slot word of a trace record: bit 31 set = the result goes to sh_t[word & ~bit 31] as one float
 
 }  // namespace art

@@ -186,6 +186,14 @@ ART_HD LightSample light_sample(const DevLight& l, float u1, float u2, f3 p) {
 // ---------------------------------------------------------------- materials
 struct BsdfSample { f3 color, dir; float pdf; bool specular; };
 
+// Material sets (round 5).  The per-item code below is compiled once per SET of material types (template parameter MATS, one bit per
+// MatType): a kernel instantiated for a set contains no instruction of the other materials, so that the Lambert majority of a scene does
+// not carry the registers of Phong's binary64 pow or of the glass branch (k_shade_compact: one instantiation per register class).
+// A material outside the set cannot reach the instantiation (the caller sorts the items by class first); should one ever, it shades
+// as MaterialLight's default (black) and shade_item counts a lost path.
+constexpr int mat_bit(int type) { return ((unsigned)type < 8u) ? (1 << type) : 0; }
+constexpr int kMatsAll = mat_bit(MAT_NULL) | mat_bit(MAT_LIGHT) | mat_bit(MAT_LAMBERT) | mat_bit(MAT_MIRROR) | mat_bit(MAT_GLASS) | mat_bit(MAT_PHONG);
+
 ART_HD float fresnel_unpolarised(float cos1, float eta_ext_in, float eta_int_in) {   // materials.adb:70-99
   float ext = eta_ext_in, in = eta_int_in;
   if (cos1 < 0.0f) { const float tmp = ext; ext = in; in = tmp; }
@@ -199,10 +207,12 @@ ART_HD float fresnel_unpolarised(float cos1, float eta_ext_in, float eta_int_in)
   return (rs * rs + rp * rp) / 2.0f;
 }
 
+template <int MATS = kMatsAll>
 ART_HD BsdfSample bsdf_sample(const DevMaterial& m, float xi1, float xi2, f3 ray_dir, f3 n) {
   BsdfSample r;
-  switch (m.type) {
-    case MAT_LAMBERT: {                                         // materials.adb:197-215
+  const int32_t type = (MATS & mat_bit(m.type)) ? m.type : (int32_t)MAT_LIGHT;      // outside the set: the default case
+  switch (type) {
+    case MAT_LAMBERT: if (MATS & mat_bit(MAT_LAMBERT)) {        // materials.adb:197-215
       ART_PROBE(20);
       const f3 nd = sample_cosine(xi1, xi2, n, n, 1.0f);
       const float ct = dot(nd, n);
@@ -211,15 +221,15 @@ ART_HD BsdfSample bsdf_sample(const DevMaterial& m, float xi1, float xi2, f3 ray
       if (ct < kEpsCos) r.color = mk3(0.0f, 0.0f, 0.0f);
       r.dir = nd; r.specular = false;
       return r;
-    }
-    case MAT_MIRROR: {                                          // :247-254
+    } break;
+    case MAT_MIRROR: if (MATS & mat_bit(MAT_MIRROR)) {          // :247-254
       ART_PROBE(21);
       const f3 nd = reflect(ray_dir, n);
       const float cdiv = 1.0f / amax(dot(nd, n), kEpsDiv);
       r.color = ld3(m.p) * cdiv; r.dir = nd; r.pdf = 1.0f; r.specular = true;
       return r;
-    }
-    case MAT_GLASS: {                                           // :285-331
+    } break;
+    case MAT_GLASS: if (MATS & mat_bit(MAT_GLASS)) {            // :285-331
       ART_PROBE(22);
       const float ior = m.p[6];
       const float f = fresnel_unpolarised(dot(ray_dir, n), ior, 1.0f);
@@ -248,8 +258,8 @@ ART_HD BsdfSample bsdf_sample(const DevMaterial& m, float xi1, float xi2, f3 ray
       const float cdiv = 1.0f / amax(fabsf(dot(nd, n)), kEpsDiv);
       r.color = bx * cdiv; r.dir = nd; r.pdf = 1.0f; r.specular = true;
       return r;
-    }
-    case MAT_PHONG: {                                           // :363-387
+    } break;
+    case MAT_PHONG: if (MATS & mat_bit(MAT_PHONG)) {            // :363-387
       ART_PROBE(23);
       const float pw = m.p[3];
       const f3 rr = reflect(ray_dir, n);
@@ -263,20 +273,23 @@ ART_HD BsdfSample bsdf_sample(const DevMaterial& m, float xi1, float xi2, f3 ray
       if (cg < kEpsCos) col = mk3(0.0f, 0.0f, 0.0f);
       r.color = col * cdiv; r.dir = nd; r.specular = false;
       return r;
-    }
-    default:                                                    // MaterialLight :163-166
-      r.color = mk3(0.0f, 0.0f, 0.0f); r.dir = r.color; r.pdf = 1.0f; r.specular = false;
-      return r;
+    } break;
+    default: break;
   }
+  r.color = mk3(0.0f, 0.0f, 0.0f); r.dir = r.color; r.pdf = 1.0f; r.specular = false;      // MaterialLight :163-166
+  return r;
 }
 
+template <int MATS = kMatsAll>
 ART_HD void bsdf_eval(const DevMaterial& m, f3 l, f3 v, f3 n, f3& bxdf, float& pdf) {
-  switch (m.type) {
-    case MAT_LAMBERT:                                           // :217-226
+  const int32_t type = (MATS & mat_bit(m.type)) ? m.type : (int32_t)MAT_LIGHT;
+  switch (type) {
+    case MAT_LAMBERT: if (MATS & mat_bit(MAT_LAMBERT)) {        // :217-226
       bxdf = ld3(m.p) * kInvPi;
       pdf = amax(dot(n, l), 0.0f) * kInvPi;
       return;
-    case MAT_PHONG: {                                           // :389-410
+    } break;
+    case MAT_PHONG: if (MATS & mat_bit(MAT_PHONG)) {            // :389-410
       const float pw = m.p[3];
       const f3 rr = reflect(neg(v), n);
       const float ct = aclamp(dot(l, rr), 0.0f, kPhongClamp);
@@ -285,11 +298,10 @@ ART_HD void bsdf_eval(const DevMaterial& m, f3 l, f3 v, f3 n, f3& bxdf, float& p
       bxdf = ((((ld3(m.p) * (pw + 2.0f)) * 0.5f) * kInvPi) * lobe) * cdiv;
       pdf = lobe * (pw + 1.0f) * (0.5f * kInvPi);
       return;
-    }
-    default:                                                    // light / mirror / glass
-      bxdf = mk3(0.0f, 0.0f, 0.0f); pdf = 1.0f;
-      return;
+    } break;
+    default: break;
   }
+  bxdf = mk3(0.0f, 0.0f, 0.0f); pdf = 1.0f;                       // light / mirror / glass
 }
 
 // ---------------------------------------------------------------- hit record -> shading frame
@@ -353,15 +365,19 @@ ART_HD size_t rec_slot(int mode, int w, bool shadow_ray) { return (mode == REC_B
 // the visibility rule (art_isect.h shadow_rule).  A ray that does not exist (live = false) or is already decided leaves a record whose
 // bound is negative: the trace kernel takes it and retires it at once.
 struct TraceRec { Rec4 r0, r1, r2, r3; };
+// hit_index: the ray's hit slot in qo.hit, or kShadowWord | item: a shadow ray of the record schedule, whose result is the word qo.sh_t[item]
 ART_HD TraceRec make_record(const DevScene& s, const DevPaths& qo, size_t hit_index, bool live, f3 o, f3 d, float tfar, float shm, const StageCtx& cx = StageCtx()) {
   TraceRec t;
+  const bool word = ((uint32_t)hit_index & kShadowWord) != 0u;
+  if (word && !live) put(qo.sh_t, (int)((uint32_t)hit_index & ~kShadowWord), -1.0f);       // (an item without a shadow ray: never read, kept defined)
   t.r0 = Rec4{0.0f, 0.0f, 0.0f, -1.0f}; t.r1 = Rec4{0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, KEY_MISS)}; t.r2 = Rec4{0.0f, 0.0f, 0.0f, -1.0f};
   t.r3 = Rec4{0.0f, __builtin_bit_cast(float, (uint32_t)hit_index), 0.0f, 0.0f};
   ART_PROBE(30);
   if (live) {
     ART_PROBE(31);
     const Cand best = analytic_bound(s, cx, o, d, tfar);
-    if (!(ART_DIAG_SKIP & 8)) qo.hit[hit_index] = DevHit{best.t, best.key, best.u, best.v};
+    if (word) put(qo.sh_t, (int)((uint32_t)hit_index & ~kShadowWord), (best.key != KEY_MISS) ? best.t : -1.0f);
+    else if (!(ART_DIAG_SKIP & 8)) qo.hit[hit_index] = DevHit{best.t, best.key, best.u, best.v};
     const bool near_done = (shm >= 0.0f) && (best.key != KEY_MISS) && (best.t <= shm);       // shadow_rule: decided
     if (!near_done && qo.has_bvh) {
       ART_PROBE(32);
@@ -457,7 +473,7 @@ ART_HD void raygen_slot(const DevFrame& f, const DevScene& s, const DevPaths& q,
 // Work items and slots (art_scene.h): item w of the INPUT set `qi` is path slot item_slot(qi, w); what the path needs for its next
 // bounce is written to item `wo` of the OUTPUT set `qo` (wo < 0: the path is known to need nothing more).  With qi == qo and wo == w
 // (identity layout) this is the plain in-place update; all reads of an item happen before its writes.
-ART_HD int item_slot(const DevPaths& q, int w) { return q.slot_id ? (int)q.slot_id[w] : w; }
+ART_HD int item_slot(const DevPaths& q, int w) { return q.slot_id ? (int)at(q.slot_id, w) : w; }
 
 // the child word of a dense fold record: bits 0..27 the item at the next bounce, bits 28..29 the kind (0: that item exists; 1: the path ended
 // here, the record's w is its value; 2: a surface whose successor was not kept), bit 30: the shadow test this item resolved for its
@@ -499,6 +515,84 @@ ART_HD int32_t item_class(const DevScene& s, const DevPaths& qi, int w, const St
   if (hint) { hint->key = key; hint->mat = mat; }
   return (type == MAT_LAMBERT) ? CLS_LAMBERT : (type == MAT_PHONG) ? CLS_PHONG : (type == MAT_GLASS) ? CLS_GLASS : (type == MAT_MIRROR) ? CLS_MIRROR : CLS_CHEAP;
 }
+// item_class for N items at once, written so that the N independent chains of loads overlap (round 5).  item_class() returns early at
+// every step, so the compiler emitted its four loads (flags, hit key -> triangle's shading record -> material type) as four waits one after
+// the other, and the items of a thread one after the other: 20 memory round trips in a row per workgroup of k_shade_compact, during which
+// the wave does nothing else (the stage spent 65 % of its wave-cycles in s_waitcnt, profiles/r4_final).  Here every step issues the loads of
+// all N items with addresses made safe by selection (a lane without a triangle hit reads record 0's word; a lane without a material reads
+// material 0), and looks at the values afterwards: three round trips.  Same results as item_class for every item.
+// (device: an empty asm that names the N loaded values -- they must all have arrived there, so the N loads are issued before it, together)
+template <class T, int N> ART_HD void pin_loads(T (&a)[N]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (N == 4) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+  else if constexpr (N == 2) asm volatile("" : "+v"(a[0]), "+v"(a[1]));
+  else if constexpr (N == 8) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+  else for (int k = 0; k < N; ++k) asm volatile("" : "+v"(a[k]));
+#else
+  (void)a;
+#endif
+}
+template <int N>
+ART_HD void item_classes(const DevScene& s, const DevPaths& qi, const int (&w)[N], const bool (&on)[N], const StageCtx& cx, bool camera, int32_t (&cls_out)[N], ItemHint (&hint)[N]) {
+  uint32_t fl[N], key[N];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int k = 0; k < N; ++k) {                                   // step 1: flags and hit keys
+    const int wk = on[k] ? w[k] : 0;
+    fl[k] = camera ? (FLAG_ALIVE | FLAG_PREV_SPEC) : qi.flags[wk];
+    key[k] = qi.hit[wk].key;
+  }
+  if (!camera) pin_loads(fl);
+  pin_loads(key);
+  int32_t m_tri[N], m_sph[N]; bool surf[N], tri[N], sph[N];
+  const float* const shade0 = s.m_shade ? s.m_shade : (const float*)(const void*)s.materials;      // (a scene without a BVH mesh: any readable word)
+  const int32_t* const smat0 = s.sphere_mat ? s.sphere_mat : (const int32_t*)(const void*)s.materials;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int k = 0; k < N; ++k) {                                   // step 2: the material index (triangle: a word of its shading record; sphere: the sphere's)
+    surf[k] = on[k] && (fl[k] & FLAG_ALIVE) && key[k] != KEY_MISS;
+    const uint32_t c = key[k] & ~KEY_INDEX_MASK, idx = key[k] & KEY_INDEX_MASK;
+    tri[k] = surf[k] && c == KEY_TRI; sph[k] = surf[k] && c == KEY_SPHERE;
+    m_tri[k] = __builtin_bit_cast(int32_t, shade0[tri[k] ? (size_t)kTriShadeFloats * (size_t)idx + 9 : (size_t)0]);
+    m_sph[k] = smat0[sph[k] ? idx : 0u];
+  }
+  pin_loads(m_tri); pin_loads(m_sph);
+  int32_t mat[N], type[N];
+  const DevMaterial* const mats = cx.materials ? cx.materials : s.materials;
+  const int32_t cb[6] = {s.cb_mat[0], s.cb_mat[1], s.cb_mat[2], s.cb_mat[3], s.cb_mat[4], s.cb_mat[5]};
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int k = 0; k < N; ++k) {
+    const uint32_t c = key[k] & ~KEY_INDEX_MASK, idx = key[k] & KEY_INDEX_MASK;
+    int32_t m = tri[k] ? m_tri[k] : m_sph[k];
+    // the Cornell box's six materials are scene header words (wave-uniform: selected, no memory access per item -- a wall is what most
+    // rays of the Cornell scenes end on); the reference's brute-force mesh has material 2 (geometry.adb:311)
+    const int32_t m_cb = (idx == 0u) ? cb[0] : (idx == 1u) ? cb[1] : (idx == 2u) ? cb[2] : (idx == 3u) ? cb[3] : (idx == 4u) ? cb[4] : cb[5];
+    m = (c == KEY_CORNELL) ? m_cb : (c == KEY_BFTRI) ? 2 : m;
+    if (surf[k] && c == KEY_QUAD) m = (cx.lights ? cx.lights : s.lights)[idx].mat;      // a rect light (rare): the lights table
+    mat[k] = m;
+    surf[k] = surf[k] && m >= 0 && m < s.n_materials;
+  }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int k = 0; k < N; ++k) type[k] = mats[surf[k] ? mat[k] : 0].type;      // step 3: the material's type (a loop of its own: no branch between the N loads)
+  pin_loads(type);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int k = 0; k < N; ++k) {
+    int32_t c = CLS_CHEAP;
+    if (surf[k]) {
+      hint[k].key = key[k]; hint[k].mat = mat[k];
+      c = (type[k] == MAT_LAMBERT) ? CLS_LAMBERT : (type[k] == MAT_PHONG) ? CLS_PHONG : (type[k] == MAT_GLASS) ? CLS_GLASS : (type[k] == MAT_MIRROR) ? CLS_MIRROR : CLS_CHEAP;
+    }
+    cls_out[k] = on[k] ? c : (int32_t)kItemClasses;
+  }
+}
 ART_HD bool stage_keeps_surfaces(const DevFrame& f, int bounce) { return (f.render_type != PT_STUPID) || (bounce + 1 < f.max_depth); }
 ART_HD bool item_survives(const DevFrame& f, const DevScene& s, const DevPaths& qi, int w, int bounce, const StageCtx& cx = StageCtx()) {
   return item_class(s, qi, w, cx) != CLS_CHEAP && stage_keeps_surfaces(f, bounce);
@@ -509,47 +603,74 @@ ART_HD bool item_survives(const DevFrame& f, const DevScene& s, const DevPaths& 
 // hint != nullptr: the item is a surface item and *hint holds its hit key and material index (k_shade_compact's classification): the
 // triangle's normals and the material record are then requested together with the item's own words, one round trip instead of three
 // dependent ones (hit -> triangle shading record -> material).
+template <int MATS = kMatsAll>
 ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, const DevPaths& qo, int w, int wo, int bounce, unsigned long long* lost = nullptr,
                       const StageCtx& cx = StageCtx(), RayOut* defer = nullptr, const ItemHint* hint = nullptr, int camera_mode = -1, int dense_mode = -1) {
   ART_PROBE(0);
   // dense_mode: 1 / 0 = the caller knows which fold records the schedule keeps (k_shade_compact: dense; the dead branches and their
   // pointer loads then drop out of the kernel), -1 = look at the bank
   const bool dense = (dense_mode >= 0) ? (dense_mode != 0) : (qi.fold_dense != 0);
-  const int slot = item_slot(qi, w);
+  const int slot_loaded = item_slot(qi, w);
   const size_t P = (size_t)qi.P;
   const bool camera = (camera_mode >= 0) ? (camera_mode != 0) : (qi.synth0 && qi.slot_id == nullptr);         // bounce 0 of the compacted schedule: raygen stored the hit and nothing else (DevPaths::synth0)
-  uint32_t fl = camera ? (FLAG_ALIVE | FLAG_PREV_SPEC) : qi.flags[w];
-  // ---- everything the item holds is read first
-  const DevHit hw = qi.hit[w];
+  uint32_t fl = camera ? (FLAG_ALIVE | FLAG_PREV_SPEC) : at(qi.flags, w);
+  // ---- everything the item holds is read first: ONE batch of independent loads (round 5).  Written as conditional loads the compiler sank
+  // each into the branch that uses it and waited for them one by one -- eight memory round trips in a row at the head of every item, at the
+  // stage's 80-VGPR cap -- so the loads a hint makes possible are unconditional (an item without a hint reads record 0 / material 0 and
+  // ignores them), and on the device an empty asm that names every loaded value pins them all before the first use.
+  DevHit hw = at(qi.hit, w);
   const uint32_t key = hint ? hint->key : hw.key;
   PreNormals pre_n = PreNormals{{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, false};
   DevMaterial pre_m = DevMaterial{MAT_NULL, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
-  if (hint) {
-    pre_m = (cx.materials ? cx.materials : s.materials)[hint->mat];
-    if (!(ART_DIAG_SKIP & 2) && (hint->key & ~KEY_INDEX_MASK) == KEY_TRI) {
-      const float* r = s.m_shade + (size_t)kTriShadeFloats * (size_t)(hint->key & KEY_INDEX_MASK);
-      pre_n.a = ld3(r); pre_n.b = ld3(r + 3); pre_n.c = ld3(r + 6); pre_n.on = true;
+  const bool batch = (dense_mode == 1);                // k_shade_compact: hints exist, the record schedule's arrays exist
+  if (hint || batch) {
+    pre_m = (cx.materials ? cx.materials : s.materials)[hint ? hint->mat : 0];
+    const bool tri = hint && !(ART_DIAG_SKIP & 2) && (hint->key & ~KEY_INDEX_MASK) == KEY_TRI;
+    if (tri || batch) {
+      const float* r = (s.m_shade ? s.m_shade : (const float*)(const void*)s.materials) + (size_t)kTriShadeFloats * (size_t)(tri ? (hint->key & KEY_INDEX_MASK) : 0u);
+      pre_n.a = ld3(r); pre_n.b = ld3(r + 3); pre_n.c = ld3(r + 6); pre_n.on = tri;
     }
   }
   // the shadow test the item may owe (its words exist for every item; asked for now, used below if the flag says so)
   const bool may_owe = (bounce > 0) && (f.render_type != PT_STUPID);
-  DevHit hs = DevHit{0.0f, KEY_MISS, 0.0f, 0.0f}; float owed_min = 0.0f; f3 owed = mk3(0.0f, 0.0f, 0.0f);
-  if (may_owe) { hs = qi.hit[P + (size_t)w]; owed_min = qi.sh_min_t[w]; if (!dense) owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
+  // (hs_t: t of the shadow ray's closest hit, -1 = none: the word sh_t[w] of the record schedule, else from the hit record at [P + w])
+  float hs_t = -1.0f, owed_min = 0.0f; f3 owed = mk3(0.0f, 0.0f, 0.0f);
+  auto shadow_t = [&]() { if (qi.sh_t) return at(qi.sh_t, w); const DevHit h = qi.hit[P + (size_t)w]; return (h.key != KEY_MISS) ? h.t : -1.0f; };
+  if (may_owe || (batch && !camera)) { hs_t = shadow_t(); owed_min = at(qi.sh_min_t, w); if (!dense) owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
   // (the extension ray is kept as six SoA words next to its trace record: reading it back out of the record would pull the whole
   // 128-byte line of the item's two records for 24 useful bytes)
   f3 o, d; float prev_pdf;
+  int slot_v = slot_loaded;
   if (camera) {
     o = ld3(s.cam_pos); prev_pdf = 1.0f;
     if (ART_SYNTH_DIR) {
       uint32_t cpix, csam;
-      slot_to_sample(qi, slot, cpix, csam);
+      slot_to_sample(qi, slot_loaded, cpix, csam);
       d = camera_dir(f, s, cpix, csam);                                         // raygen_slot's own expression: the same bits
-    } else d = mk3(qi.ray_dx[w], qi.ray_dy[w], qi.ray_dz[w]);
+    } else d = mk3(at(qi.ray_dx, w), at(qi.ray_dy, w), at(qi.ray_dz, w));
   } else {
-    o = mk3(qi.ray_ox[w], qi.ray_oy[w], qi.ray_oz[w]);
-    d = mk3(qi.ray_dx[w], qi.ray_dy[w], qi.ray_dz[w]);
-    prev_pdf = qi.prev_pdf[w];
+    o = mk3(at(qi.ray_ox, w), at(qi.ray_oy, w), at(qi.ray_oz, w));
+    d = mk3(at(qi.ray_dx, w), at(qi.ray_dy, w), at(qi.ray_dz, w));
+    prev_pdf = at(qi.prev_pdf, w);
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (batch) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v mp0 = {pre_m.p[0], pre_m.p[1], pre_m.p[2], pre_m.p[3]}, mp1 = {pre_m.p[4], pre_m.p[5], pre_m.p[6], pre_m.p[7]};
+    if (camera) {
+      asm volatile("; the item's loads are in flight together" : "+v"(slot_v), "+v"(hw.t), "+v"(hw.key), "+v"(hw.u), "+v"(hw.v),
+                   "+v"(pre_n.a.x), "+v"(pre_n.a.y), "+v"(pre_n.a.z), "+v"(pre_n.b.x), "+v"(pre_n.b.y), "+v"(pre_n.b.z), "+v"(pre_n.c.x), "+v"(pre_n.c.y), "+v"(pre_n.c.z),
+                   "+v"(pre_m.type), "+v"(pre_m.light), "+v"(mp0), "+v"(mp1));
+    } else {
+      asm volatile("; the item's loads are in flight together" : "+v"(slot_v), "+v"(fl), "+v"(hw.t), "+v"(hw.key), "+v"(hw.u), "+v"(hw.v), "+v"(hs_t), "+v"(owed_min), "+v"(prev_pdf),
+                   "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(d.x), "+v"(d.y), "+v"(d.z),
+                   "+v"(pre_n.a.x), "+v"(pre_n.a.y), "+v"(pre_n.a.z), "+v"(pre_n.b.x), "+v"(pre_n.b.y), "+v"(pre_n.b.z), "+v"(pre_n.c.x), "+v"(pre_n.c.y), "+v"(pre_n.c.z),
+                   "+v"(pre_m.type), "+v"(pre_m.light), "+v"(mp0), "+v"(mp1));
+    }
+    pre_m.p[0] = mp0.x; pre_m.p[1] = mp0.y; pre_m.p[2] = mp0.z; pre_m.p[3] = mp0.w; pre_m.p[4] = mp1.x; pre_m.p[5] = mp1.y; pre_m.p[6] = mp1.z; pre_m.p[7] = mp1.w;
+  }
+#endif
+  const int slot = slot_v;
   const float t = hw.t, hu = hw.u, hv = hw.v;
   // dense fold record of this item at this level (DevPaths::fold_dense): by default "the path ended here with value 0"; rec_shadowed: the
   // shadow test this item resolves for its predecessor's explicit light came out "in shadow"
@@ -557,8 +678,8 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   if (fl & FLAG_SHADOW_PENDING) {
     ART_PROBE(1);
     // Compute_Shadow: hit and t < maxDist - eps2 (enforced by the ray's tfar clip) and t > 10*eps
-    if (!may_owe) { hs = qi.hit[P + (size_t)w]; owed_min = qi.sh_min_t[w]; if (!dense) owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
-    const bool in_shadow = (hs.key != KEY_MISS) && (hs.t > owed_min);
+    if (!may_owe) { hs_t = shadow_t(); owed_min = at(qi.sh_min_t, w); if (!dense) owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
+    const bool in_shadow = (hs_t >= 0.0f) && (hs_t > owed_min);       // hit, and beyond 10 eps (a hit's t is positive; -1: no hit)
     if (dense) rec_shadowed = in_shadow;      // dense fold records: the previous stage left the explicit colour itself at e[bounce][w]; this item's record says whether it counts
     else {                                            // e of the previous level at [bounce - 1][slot]
       const size_t li = (size_t)(bounce - 1) * P + (size_t)slot;
@@ -590,8 +711,13 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     const bool mat_ok = hint ? true : ((key != KEY_MISS) && sf.mat >= 0 && sf.mat < s.n_materials);
     const DevMaterial m = hint ? pre_m : (mat_ok ? (cx.materials ? cx.materials : s.materials)[sf.mat] : DevMaterial{MAT_NULL, 0, {0, 0, 0, 0, 0, 0, 0, 0}});
     ART_PROBE(3);
+    if (MATS != kMatsAll && mat_ok && !(MATS & mat_bit(m.type)) && lost != nullptr) {   // a material this instantiation was not compiled for: the caller's sort is broken
+#if defined(__HIP_DEVICE_COMPILE__)
+      atomicAdd(lost, 1ull);
+#endif
+    }
     if (!mat_ok || m.type == MAT_NULL) kill(bounce, zero);                            // integrators.adb:218-220
-    else if (m.type == MAT_LIGHT) {                                                   // :102-108 / :155-157 / :222-247
+    else if ((MATS & mat_bit(MAT_LIGHT)) && m.type == MAT_LIGHT) {                    // :102-108 / :155-157 / :222-247
       ART_PROBE(4);
       const f3 n = sf.normal;
       const float sel_pdf = 1.0f / (float)s.n_lights;
@@ -632,7 +758,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
         const float lp = ls.pdf * sel_pdf;
         ART_PROBE(7);
         f3 bx; float bp;
-        bsdf_eval(m, sdir, neg(d), n, bx, bp);
+        bsdf_eval<MATS>(m, sdir, neg(d), n, bx, bp);
         const float c1 = amax(dot(sdir, n), 0.0f);
         if (f.render_type == PT_MIS) {
           const float mis = lp * lp / (lp * lp + bp * bp);
@@ -657,7 +783,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
         qi.e_r[li] = 0.0f; qi.e_g[li] = 0.0f; qi.e_b[li] = 0.0f;
       }
       ART_PROBE(8);
-      const BsdfSample bs = bsdf_sample(m, u01(rnd.z), u01(rnd.w), d, n);                // :116-124 / :183-191 / :291-299
+      const BsdfSample bs = bsdf_sample<MATS>(m, u01(rnd.z), u01(rnd.w), d, n);          // :116-124 / :183-191 / :291-299
       ART_PROBE(9);
       const f3 bxv = bs.color * (1.0f / amax(bs.pdf, kGEpsilonDiv));
       const float ct = dot(bs.dir, n);
@@ -673,9 +799,9 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   }
   ART_PROBE(40);
   if (dense && !(ART_DIAG_SKIP & 16)) {                      // dense stores: consecutive items, consecutive addresses
-    const size_t lw = (size_t)bounce * P + (size_t)w;
-    qi.w_r[lw] = rec_w.x; qi.w_g[lw] = rec_w.y; qi.w_b[lw] = rec_w.z;
-    qi.child[lw] = fold_child_word((rec_child == -2 && wo >= 0) ? wo : rec_child, rec_shadowed);
+    const size_t l0 = (size_t)bounce * P;                   // (the level's base is wave-uniform: a scalar add; the item's offset stays 32 bits)
+    put(qi.w_r + l0, w, rec_w.x); put(qi.w_g + l0, w, rec_w.y); put(qi.w_b + l0, w, rec_w.z);
+    put(qi.child + l0, w, fold_child_word((rec_child == -2 && wo >= 0) ? wo : rec_child, rec_shadowed));
   }
   // ---- the output item
   if (wo < 0) {
@@ -688,18 +814,19 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   }
   ART_PROBE(41);
   const size_t so_i = (size_t)qo.P + (size_t)wo;
-  qo.flags[wo] = fl;
-  qo.prev_pdf[wo] = new_pdf;
+  if (qo.slot_id != nullptr) put(const_cast<uint32_t*>(qo.slot_id), wo, (uint32_t)slot);      // compacted banks: the output item's slot
+  put(qo.flags, wo, fl);
+  put(qo.prev_pdf, wo, new_pdf);
   if (shadow) {
-    qo.sh_min_t[wo] = sh_min;
+    put(qo.sh_min_t, wo, sh_min);
     if (dense) {      // the explicit colour goes straight to where the fold reads e of this level: level bounce + 1, the successor's index
-      const size_t le = (size_t)(bounce + 1) * P + (size_t)wo;
-      qi.e_r[le] = cand.x; qi.e_g[le] = cand.y; qi.e_b[le] = cand.z;
+      const size_t l1 = (size_t)(bounce + 1) * P;
+      put(qi.e_r + l1, wo, cand.x); put(qi.e_g + l1, wo, cand.y); put(qi.e_b + l1, wo, cand.z);
     } else { qo.cand_r[wo] = cand.x; qo.cand_g[wo] = cand.y; qo.cand_b[wo] = cand.z; }
   }
   if (alive && !(ART_DIAG_SKIP & 4)) {
-    qo.ray_ox[wo] = no.x; qo.ray_oy[wo] = no.y; qo.ray_oz[wo] = no.z;
-    qo.ray_dx[wo] = nd.x; qo.ray_dy[wo] = nd.y; qo.ray_dz[wo] = nd.z;
+    put(qo.ray_ox, wo, no.x); put(qo.ray_oy, wo, no.y); put(qo.ray_oz, wo, no.z);
+    put(qo.ray_dx, wo, nd.x); put(qo.ray_dy, wo, nd.y); put(qo.ray_dz, wo, nd.z);
   }
   if (qo.rec) {
     // the item's rays go out as trace records, at positions given by the item index (REC_BOTH: 2 wo and 2 wo + 1).  A ray the bank's
@@ -711,7 +838,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
       const int per = (mode == REC_BOTH) ? 2 : 1;
       const bool blocks = cx.stage_count > 0;      // k_shade_compact: each kind of ray is its own contiguous block of the wave's records
       if (mode != REC_SHADOW) emit_ray(s, qo, (size_t)wo, rec_slot(mode, wo, false), alive, no, nd, kInfinity, -1.0f, cx, blocks ? cx.stage_item : per * cx.stage_item, 0);
-      if (mode != REC_EXT) emit_ray(s, qo, so_i, rec_slot(mode, wo, true), shadow, so, sd, s_tfar, qo.shadow_rule ? sh_min : -1.0f, cx, blocks ? cx.stage_item : per * cx.stage_item + (per - 1), 1);
+      if (mode != REC_EXT) emit_ray(s, qo, qo.sh_t ? (size_t)(kShadowWord | (uint32_t)wo) : so_i, rec_slot(mode, wo, true), shadow, so, sd, s_tfar, qo.shadow_rule ? sh_min : -1.0f, cx, blocks ? cx.stage_item : per * cx.stage_item + (per - 1), 1);
     }
     if (lost != nullptr && ((mode == REC_SHADOW && alive) || (mode == REC_EXT && shadow))) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -737,9 +864,10 @@ ART_HD void resolve_last_shadow(const DevPaths& q, int w, int last_level) {
   const uint32_t fl = q.flags[w];
   if (!(fl & FLAG_SHADOW_PENDING)) return;
   const int slot = item_slot(q, w);
-  const size_t si = (size_t)q.P + (size_t)w;
-  const DevHit hs = q.hit[si];
-  const bool in_shadow = (hs.key != KEY_MISS) && (hs.t > q.sh_min_t[w]);
+  float hs_t;
+  if (q.sh_t) hs_t = q.sh_t[w];
+  else { const DevHit hs = q.hit[(size_t)q.P + (size_t)w]; hs_t = (hs.key != KEY_MISS) ? hs.t : -1.0f; }
+  const bool in_shadow = (hs_t >= 0.0f) && (hs_t > q.sh_min_t[w]);
   if (q.fold_dense) {           // the last stage left the explicit colour at e[last_level + 1][w]; there is no record of that level to carry the bit: zero it
     if (in_shadow) { const size_t li = (size_t)(last_level + 1) * (size_t)q.P + (size_t)w; q.e_r[li] = 0.0f; q.e_g[li] = 0.0f; q.e_b[li] = 0.0f; }
   } else {

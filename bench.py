@@ -339,6 +339,7 @@ def main():
         line = {
             "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": (1 if args.contexts > 1 else n_gpus), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / max(1, args.steps), 3), "higher_is_better": True, "scaling": "strong",
+            "trace_ms_per_step": round(trace_ms / max(1, args.steps), 3),        # HIP events around every trace launch (device 0 / this rank)
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, %dx%d, PT_MIS depth 8, 2x2 AA, %d spp per step" % (scene_name, W, H, 4 * args.vthreads),
                        "spp_per_step": 4 * args.vthreads, "rays_per_sample": round(total_rays / max(1.0, total_samples), 3),
