@@ -10,8 +10,11 @@
 // Diagnostic builds only (-DART_LANE_PROBE, profiles/r4_probe.sh): ART_PROBE(k) adds, for every wave passing the point, its number of
 // enabled lanes to g_lane_probe[2k] and 1 to g_lane_probe[2k + 1] -- where a stage loses its lanes (round 4: k_shade_compact ran at 31 of
 // 64 lanes per VALU instruction).  Expands to nothing in the product build.
+#if defined(ART_TIME_PROBE) && !defined(ART_LANE_PROBE)
+#define ART_LANE_PROBE 1
+#endif
 #if defined(ART_LANE_PROBE) && defined(__HIPCC__)
-static __device__ unsigned long long g_lane_probe[2 * 64];
+static __device__ unsigned long long g_lane_probe[2 * 96];
 static __device__ int g_lane_probe_on;        // set around the launches of the kernel under study (k_shade_compact)
 #endif
 #if defined(ART_LANE_PROBE) && defined(__HIP_DEVICE_COMPILE__)
@@ -21,11 +24,22 @@ static __device__ int g_lane_probe_on;        // set around the launches of the 
 #else
 #define ART_PROBE(k) do { } while (0)
 #endif
+// -DART_TIME_PROBE (round 5, profiles/time_probe.py): ART_TPROBE(tp, k) adds the shader-clock cycles the wave spent since its previous time
+// probe to g_lane_probe[2k] (and 1 to [2k + 1]); tp: the wave's own word in LDS holding the time of that previous probe.  Where a wave of
+// k_shade_compact spends its wall time -- waiting for its loads, for the store queue, at the barriers, or issuing instructions.
+#if defined(ART_TIME_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+#define ART_TPROBE(tp, k) do { if ((tp) != nullptr && g_lane_probe_on) { const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true); \
+    if ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == __builtin_ctzll(m_)) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+      atomicAdd(&g_lane_probe[2 * (k)], now_ - *(volatile unsigned long long*)(tp)); atomicAdd(&g_lane_probe[2 * (k) + 1], 1ull); *(volatile unsigned long long*)(tp) = now_; } } } while (0)
+#else
+#define ART_TPROBE(tp, k) do { } while (0)
+#endif
 
 
 namespace art {
 
-ART_HD f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+template <class P> ART_HD f3 ld3(P p) { return mk3(p[0], p[1], p[2]); }      // (P: any pointer to floats, LDS-qualified ones included)
+template <class P> ART_HD DevSphere load_sphere(P p, int i) { DevSphere r; r.x = p[i].x; r.y = p[i].y; r.z = p[i].z; r.r = p[i].r; return r; }
 
 struct Cand { float t; uint32_t key; float u, v; };
 
@@ -88,11 +102,12 @@ ART_HD void isect_cornell(f3 o, f3 d, const DevScene& s, Cand& best) {
 }
 
 // IntersectFlatLight for rect light `index`
-ART_HD void isect_quad(f3 o, f3 d, const DevLight& l, uint32_t index, Cand& best) {
+template <class L>      // L: pointer to the light (generic or LDS)
+ART_HD void isect_quad(f3 o, f3 d, L l, uint32_t index, Cand& best) {
   const float inv_y = 1.0f / d.y;
-  const float t = (l.boxMax[1] - o.y) * inv_y;
+  const float t = (l->boxMax[1] - o.y) * inv_y;
   const f3 hp = o + t * d;
-  const bool hit = (hp.x > l.boxMin[0]) && (hp.x < l.boxMax[0]) && (hp.z > l.boxMin[2]) && (hp.z < l.boxMax[2]) && (t >= 0.0f);
+  const bool hit = (hp.x > l->boxMin[0]) && (hp.x < l->boxMax[0]) && (hp.z > l->boxMin[2]) && (hp.z < l->boxMax[2]) && (t >= 0.0f);
   if (hit) cand_take(best, t, KEY_QUAD | index, 0.0f, 0.0f);
 }
 
@@ -235,7 +250,7 @@ ART_HD Cand closest_hit(const DevScene& s, f3 o, f3 d, float tfar, BvhStats* st,
   for (int i = 0; i < s.n_spheres; ++i) isect_sphere(o, d, s.spheres[i], (uint32_t)i, best);
   if (s.has_cornell) isect_cornell(o, d, s, best);
   for (int i = 0; i < s.n_lights; ++i)
-    if (s.lights[i].shape == LIGHT_RECT) isect_quad(o, d, s.lights[i], (uint32_t)i, best);
+    if (s.lights[i].shape == LIGHT_RECT) isect_quad(o, d, s.lights + i, (uint32_t)i, best);
   isect_bf_mesh(o, d, s, best);
   ShadowState sh; sh.shm = shm; sh.far = false; sh.rep = best;
   if (shadow_rule(sh, best)) return best;

@@ -563,9 +563,9 @@ __global__ __launch_bounds__(256) void k_analytic(const DevScene S, const TraceA
         for (int k = n_sph_lds; k < S.n_spheres; ++k) isect_sphere(o, d, S.spheres[k], (uint32_t)k, best);
         if (S.has_cornell) isect_cornell(o, d, S, best);
         for (int k = 0; k < n_lgt_lds; ++k)
-          if (s_lgt[k].shape == LIGHT_RECT) isect_quad(o, d, s_lgt[k], (uint32_t)k, best);
+          if (s_lgt[k].shape == LIGHT_RECT) isect_quad(o, d, &s_lgt[k], (uint32_t)k, best);
         for (int k = n_lgt_lds; k < S.n_lights; ++k)
-          if (S.lights[k].shape == LIGHT_RECT) isect_quad(o, d, S.lights[k], (uint32_t)k, best);
+          if (S.lights[k].shape == LIGHT_RECT) isect_quad(o, d, S.lights + k, (uint32_t)k, best);
         isect_bf_mesh(o, d, S, best);
         A.hit[i] = DevHit{best.t, best.key, best.u, best.v};
         const bool near_done = (shm >= 0.0f) && (best.key != KEY_MISS) && (best.t <= shm);   // shadow_rule: decided
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) void k_raygen(const DevFrame F, const DevScene
     if ((int)threadIdx.x < S.n_spheres) s_sph[threadIdx.x] = S.spheres[threadIdx.x];
     if ((int)threadIdx.x < S.n_lights) s_lgt[threadIdx.x] = S.lights[threadIdx.x];
     __syncthreads();
-    cx.spheres = s_sph; cx.lights = s_lgt;
+    cx.lds_spheres = (const ART_LDS DevSphere*)(uint32_t)(uintptr_t)s_sph; cx.lds_lights = (const ART_LDS DevLight*)(uint32_t)(uintptr_t)s_lgt;      // (the low 32 bits of a generic LDS address are the LDS address)
   }
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
   // record mode: a wave's 64 records are 4 KB of consecutive bytes; staged through LDS so that every store instruction writes one
@@ -849,9 +849,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(set_waves(S
   if (threadIdx.x == 0) s_rays = 0;
   __syncthreads();
   StageCtx tables;
-  if (tables_in_lds) { tables.spheres = s_sph; tables.lights = s_lgt; }
+  if (tables_in_lds) { tables.lds_spheres = (const ART_LDS DevSphere*)(uint32_t)(uintptr_t)s_sph; tables.lds_lights = (const ART_LDS DevLight*)(uint32_t)(uintptr_t)s_lgt; }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t lanes_below = (1ull << lane) - 1ull;
+#if defined(ART_TIME_PROBE)
+  __shared__ unsigned long long s_tprobe[4];
+  if (lane == 0) s_tprobe[wave] = __builtin_readcyclecounter();
+  tables.tprobe = &s_tprobe[wave];
+#endif
   // ---- 1. classify; a wave's items of one class take consecutive places in the class (of their round)
   int cls[PER], rank[PER]; ItemHint hint[PER];
   {
@@ -867,6 +872,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(set_waves(S
       for (int k = 0; k < PER; ++k) if (on[k]) { hint[k].key = e[k].y; hint[k].mat = (int32_t)(e[k].z & 0xffffffu); cls[k] = (int)(e[k].z >> 24); }
     } else item_classes<PER>(S, Qi, wk, on, tables, CAMERA, cls, hint);
   }
+  ART_TPROBE(tables.tprobe, 64);      // classification loads
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     int c = cls[k];
@@ -886,7 +892,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(set_waves(S
       }
     }
   }
+  ART_TPROBE(tables.tprobe, 65);      // class ranks (ballots + LDS atomics)
   __syncthreads();
+  ART_TPROBE(tables.tprobe, 66);      // barrier 1
   // ---- 2. sort every round: class q starts where the classes before it end; the surface classes (the survivors) come first.
   // The sort stays inside a round's 256 items: the four waves of the workgroup then read one 1-KB window of every array at the same time
   // (sorted over the whole chunk, a wave's loads touched lines whose other halves were fetched again three rounds later: +43 % bytes
@@ -931,6 +939,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(set_waves(S
       if (rank[k] < 0) K->heavy[hbase + rank[k] + (1 << 30)] = make_uint4((uint32_t)(c0 + k * 256 + (int)threadIdx.x), hint[k].key, (uint32_t)hint[k].mat, 0u);
   }
   const int base = s_base;
+  ART_TPROBE(tables.tprobe, 67);      // sort, output reservation (global atomic), barrier 2
   // ---- 3. shade in sorted order
   const bool staged = (Qo.rec != nullptr) && Qo.has_bvh;
   const int mode = Qo.rec_mode;
@@ -946,6 +955,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(set_waves(S
     uint32_t* const slot_out = K->slot_out; unsigned long long* const lost = K->lost;
     const ShadeKernArgs* const K2 = K;
 #endif
+    ART_TPROBE(tables.tprobe, 70);    // round bookkeeping (and, after the first round, whatever followed the last probe of the item before)
     const int r = (int)threadIdx.x;                       // position in the sorted round
     const int n_all_k = s_nall[k], n_keep_k = s_nkeep[k], out0_k = s_out0[k];
     const bool keep = r < n_keep_k;
@@ -998,6 +1008,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(set_waves(S
       }
     }
   }
+  ART_TPROBE(tables.tprobe, 68);      // end of the last round
   // record mode: the rays just emitted are the closest-hit queries of the next trace launch (k_analytic counts them in the plain layout)
   if (Qo.rec != nullptr && rays_a != nullptr) {
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_xor(n_rays, off);
@@ -1239,8 +1250,8 @@ void launch_trace(hipStream_t st, const DevScene* S, const TraceArgs& A, int ker
 #if defined(ART_LANE_PROBE)
 // diagnostic build: read (and clear) the lane probes of art_isect.h
 extern "C" int art_debug_lane_probe(unsigned long long* out, int n) {
-  unsigned long long z[2 * 64] = {};
-  if (n > 2 * 64) n = 2 * 64;
+  unsigned long long z[2 * 96] = {};
+  if (n > 2 * 96) n = 2 * 96;
   if (hipDeviceSynchronize() != hipSuccess) return 1;
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lane_probe), (size_t)n * 8) != hipSuccess) return 1;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_lane_probe), z, sizeof z) != hipSuccess;

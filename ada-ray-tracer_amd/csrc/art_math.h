@@ -21,6 +21,15 @@ namespace art {
 
 struct f3 { float x, y, z; };
 
+// A pointer that is KNOWN to point into LDS (device pass; an ordinary pointer elsewhere).  Reads through it are ds_read instructions, which
+// wait on lgkmcnt alone; the same table behind a generic pointer is read with flat_load, whose s_waitcnt vmcnt(0) also waits for every
+// store the wave still has in flight -- in k_shade_compact that put a store-queue drain in front of each ray's sphere loop (round 5).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ART_LDS __attribute__((address_space(3)))
+#else
+#define ART_LDS
+#endif
+
 // scalar base + 32-bit byte offset: on the device the address costs no vector instruction and no VGPR pair (a 64-bit pointer per array costs a
 // v_lshl_add_u64 and two registers each).  The caller guarantees that the offset fits 32 bits.  at(base, i) = base[i] through it.
 template <class T> ART_HD T ld_off(const T* base, uint32_t byte_off) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off); }

@@ -20,10 +20,14 @@ constexpr float kPhongClamp = 0x1.921eaep+0f;  // static M_PI*0.499995 (material
 // stage at 3.3 TB/s), and the LDS staging of the records a wave emits (emit_ray).  All optional: the host simulation passes none.
 struct StageCtx {
   const DevSphere* spheres = nullptr; const DevLight* lights = nullptr; const DevMaterial* materials = nullptr;   // nullptr: the scene's own tables
+  // the same two tables as LDS-qualified pointers (k_shade_compact, k_raygen: the kernel's __shared__ copies).  When set they are what the
+  // per-item code reads (ds_read: no vmcnt wait, art_math.h ART_LDS); `spheres` / `lights` above then stay unused
+  const ART_LDS DevSphere* lds_spheres = nullptr; const ART_LDS DevLight* lds_lights = nullptr;
   Rec4* stage = nullptr; int stage_pitch = 0; int stage_item = 0;     // LDS staging of the wave's records (emit_ray): k_raygen copies them out itself
   // k_shade_compact: stage_count > 0 lanes of the wave emit together (stage_item = this lane's rank among them) and copy the records out
   // themselves, one kind of ray at a time; rec_base[0 / 1]: first record of the wave's extension / shadow rays in the output bank
   int stage_count = 0; size_t rec_base[2] = {0, 0};
+  unsigned long long* tprobe = nullptr;        // -DART_TIME_PROBE: the wave's time-probe word (LDS)
   unsigned long long* lost = nullptr;          // the self-check counter (ArtStats::lost_paths): a staged record read before its lane wrote it is counted there
 };
 
@@ -99,41 +103,47 @@ ART_HD float pdf_area_to_solid(float pdfA, float dist, float cos_there) {   // P
 
 ART_HD float dist2(f3 a, f3 b) { const f3 q = b - a; return dot(q, q); }
 
-ART_HD float sphere_light_pdf(const DevLight& l, f3 p) {   // SphereLight.EvalPDF
-  const f3 c = ld3(l.center);
-  if (dist2(p, c) - l.radius * l.radius < 1.0e-4f) return 1.0f / l.surfaceArea;
-  const float s2 = l.radius * l.radius / dist2(p, c);
+// (L: a pointer to the light, generic or LDS-qualified -- light_at() below hands the per-item code whichever the kernel provides)
+template <class L>
+ART_HD float sphere_light_pdf(L l, f3 p) {   // SphereLight.EvalPDF
+  const f3 c = ld3(l->center);
+  const float radius = l->radius;
+  if (dist2(p, c) - radius * radius < 1.0e-4f) return 1.0f / l->surfaceArea;
+  const float s2 = radius * radius / dist2(p, c);
   const float cmax = sqrtf(amax(0.0f, 1.0f - s2));
   return 1.0f / (2.0f * kPi * (1.0f - cmax));
 }
 
-ART_HD float light_eval_pdf(const DevLight& l, f3 p, f3 ray_dir, float hit_dist) {
-  if (l.shape == LIGHT_RECT) {
-    const float ct = amax(dot(ray_dir, neg(ld3(l.normal))), 0.0f);
-    return pdf_area_to_solid(1.0f / l.surfaceArea, hit_dist, ct);
+template <class L>
+ART_HD float light_eval_pdf(L l, f3 p, f3 ray_dir, float hit_dist) {
+  if (l->shape == LIGHT_RECT) {
+    const float ct = amax(dot(ray_dir, neg(ld3(l->normal))), 0.0f);
+    return pdf_area_to_solid(1.0f / l->surfaceArea, hit_dist, ct);
   }
   return sphere_light_pdf(l, p);
 }
 
-ART_HD LightSample light_sample(const DevLight& l, float u1, float u2, f3 p) {
+template <class L>
+ART_HD LightSample light_sample(L lp, float u1, float u2, f3 p) {
   LightSample r;
   r.pos = mk3(0.0f, 0.0f, 0.0f); r.dir = r.pos; r.pdf = 1.0f;
-  r.intensity = ld3(l.intensity);
+  r.intensity = ld3(lp->intensity);
   ART_PROBE(10);
-  if (l.shape == LIGHT_RECT) {                                   // AreaLight.Sample
+  if (lp->shape == LIGHT_RECT) {                                 // AreaLight.Sample
     ART_PROBE(11);
-    r.pos.x = l.boxMin[0] + u1 * (l.boxMax[0] - l.boxMin[0]);
-    r.pos.y = l.boxMin[1];
-    r.pos.z = l.boxMin[2] + u2 * (l.boxMax[2] - l.boxMin[2]);
-    r.dir = ld3(l.normal);
+    r.pos.x = lp->boxMin[0] + u1 * (lp->boxMax[0] - lp->boxMin[0]);
+    r.pos.y = lp->boxMin[1];
+    r.pos.z = lp->boxMin[2] + u2 * (lp->boxMax[2] - lp->boxMin[2]);
+    r.dir = ld3(lp->normal);
     f3 rd = r.pos - p;
     const float dd = length(rd);
     rd = rd * (1.0f / dd);
-    const float ct = amax(dot(rd, neg(ld3(l.normal))), 0.0f);
-    r.pdf = pdf_area_to_solid(1.0f / l.surfaceArea, dd, ct);
+    const float ct = amax(dot(rd, neg(ld3(lp->normal))), 0.0f);
+    r.pdf = pdf_area_to_solid(1.0f / lp->surfaceArea, dd, ct);
     return r;
   }
-  const f3 c = ld3(l.center);                                    // SphereLight.Sample
+  struct { float radius; } l = {lp->radius};                     // (the sphere light's radius, read once)
+  const f3 c = ld3(lp->center);                                  // SphereLight.Sample
   if (dist2(p, c) - l.radius * l.radius < 1.0e-4f) {
     ART_PROBE(12);
     const float z = 1.0f - 2.0f * u1;                            // UniformSampleSphere
@@ -179,7 +189,7 @@ ART_HD LightSample light_sample(const DevLight& l, float u1, float u2, f3 p) {
   ART_PROBE(17);
   r.pos = rpos + thit * rdir;
   r.dir = normalize(r.pos - c);
-  r.pdf = sphere_light_pdf(l, p);
+  r.pdf = sphere_light_pdf(lp, p);
   return r;
 }
 
@@ -304,6 +314,9 @@ ART_HD void bsdf_eval(const DevMaterial& m, f3 l, f3 v, f3 n, f3& bxdf, float& p
   bxdf = mk3(0.0f, 0.0f, 0.0f); pdf = 1.0f;                       // light / mirror / glass
 }
 
+// material of rect light `idx` (the flat light's quad, geometry.adb:132-141)
+ART_HD int32_t light_mat(const DevScene& s, const StageCtx& cx, uint32_t idx) { return cx.lds_lights ? cx.lds_lights[idx].mat : (cx.lights ? cx.lights : s.lights)[idx].mat; }
+
 // ---------------------------------------------------------------- hit record -> shading frame
 struct Surface { f3 normal; int32_t mat; int32_t mat_id; };
 
@@ -314,7 +327,7 @@ ART_HD Surface surface_at(const DevScene& s, f3 o, f3 d, float t, uint32_t key, 
   Surface sf;
   const uint32_t cls = key & ~KEY_INDEX_MASK, idx = key & KEY_INDEX_MASK;
   if (cls == KEY_SPHERE) {                                      // geometry.adb:88,95-96
-    const DevSphere sp = (cx.spheres ? cx.spheres : s.spheres)[idx];
+    const DevSphere sp = cx.lds_spheres ? load_sphere(cx.lds_spheres, (int)idx) : load_sphere(cx.spheres ? cx.spheres : s.spheres, (int)idx);
     sf.normal = normalize((o + d * t) - mk3(sp.x, sp.y, sp.z));
     sf.mat = s.sphere_mat[idx]; sf.mat_id = 0;
   } else if (cls == KEY_CORNELL) {                              // geometry.adb:215-224 + scene.adb:80-82
@@ -322,7 +335,7 @@ ART_HD Surface surface_at(const DevScene& s, f3 o, f3 d, float t, uint32_t key, 
     sf.mat_id = s.cb_mat[idx]; sf.mat = sf.mat_id;
   } else if (cls == KEY_QUAD) {                                 // geometry.adb:132-141
     sf.normal = mk3(0.0f, -1.0f, 0.0f);
-    sf.mat = (cx.lights ? cx.lights : s.lights)[idx].mat; sf.mat_id = 0;
+    sf.mat = light_mat(s, cx, idx); sf.mat_id = 0;
   } else {
     const float w = 1.0f - u - v;                               // geometry.adb:301
     if (cls == KEY_BFTRI) {
@@ -346,16 +359,19 @@ ART_HD Surface surface_at(const DevScene& s, f3 o, f3 d, float t, uint32_t key, 
 // ---------------------------------------------------------------- rays leave a stage as trace records (round 3)
 // Candidates 1-4 of Scene.Find_Closest_Hit (scene.adb:62-69: spheres, Cornell box, rect lights, the reference's brute-force mesh):
 // the starting bound of the BVH search.  The same calls in the same order as k_analytic and closest_hit().
-ART_HD Cand analytic_bound(const DevScene& s, const StageCtx& cx, f3 o, f3 d, float tfar) {
-  const DevSphere* sph = cx.spheres ? cx.spheres : s.spheres;
-  const DevLight* lgt = cx.lights ? cx.lights : s.lights;
+template <class SP, class LP>
+ART_HD Cand analytic_bound_t(const DevScene& s, SP sph, LP lgt, f3 o, f3 d, float tfar) {
   Cand best = cand_init(tfar);
-  for (int i = 0; i < s.n_spheres; ++i) isect_sphere(o, d, sph[i], (uint32_t)i, best);
+  for (int i = 0; i < s.n_spheres; ++i) isect_sphere(o, d, load_sphere(sph, i), (uint32_t)i, best);
   if (s.has_cornell) isect_cornell(o, d, s, best);
   for (int i = 0; i < s.n_lights; ++i)
-    if (lgt[i].shape == LIGHT_RECT) isect_quad(o, d, lgt[i], (uint32_t)i, best);
+    if (lgt[i].shape == LIGHT_RECT) isect_quad(o, d, lgt + i, (uint32_t)i, best);
   isect_bf_mesh(o, d, s, best);
   return best;
+}
+ART_HD Cand analytic_bound(const DevScene& s, const StageCtx& cx, f3 o, f3 d, float tfar) {
+  if (cx.lds_spheres) return analytic_bound_t(s, cx.lds_spheres, cx.lds_lights, o, d, tfar);      // the kernel's LDS copies (both tables or neither)
+  return analytic_bound_t(s, cx.spheres ? cx.spheres : s.spheres, cx.lights ? cx.lights : s.lights, o, d, tfar);
 }
 
 ART_HD size_t rec_slot(int mode, int w, bool shadow_ray) { return (mode == REC_BOTH) ? 2 * (size_t)w + (shadow_ray ? 1u : 0u) : (size_t)w; }
@@ -507,7 +523,7 @@ ART_HD int32_t item_class(const DevScene& s, const DevPaths& qi, int w, const St
   int32_t mat;
   if (cls == KEY_SPHERE) mat = s.sphere_mat[idx];
   else if (cls == KEY_CORNELL) mat = s.cb_mat[idx];
-  else if (cls == KEY_QUAD) mat = (cx.lights ? cx.lights : s.lights)[idx].mat;
+  else if (cls == KEY_QUAD) mat = light_mat(s, cx, idx);
   else if (cls == KEY_BFTRI) mat = 2;
   else mat = __builtin_bit_cast(int32_t, s.m_shade[(size_t)kTriShadeFloats * (size_t)idx + 9]);
   if (mat < 0 || mat >= s.n_materials) return CLS_CHEAP;
@@ -572,7 +588,7 @@ ART_HD void item_classes(const DevScene& s, const DevPaths& qi, const int (&w)[N
     // rays of the Cornell scenes end on); the reference's brute-force mesh has material 2 (geometry.adb:311)
     const int32_t m_cb = (idx == 0u) ? cb[0] : (idx == 1u) ? cb[1] : (idx == 2u) ? cb[2] : (idx == 3u) ? cb[3] : (idx == 4u) ? cb[4] : cb[5];
     m = (c == KEY_CORNELL) ? m_cb : (c == KEY_BFTRI) ? 2 : m;
-    if (surf[k] && c == KEY_QUAD) m = (cx.lights ? cx.lights : s.lights)[idx].mat;      // a rect light (rare): the lights table
+    if (surf[k] && c == KEY_QUAD) m = light_mat(s, cx, idx);      // a rect light (rare): the lights table
     mat[k] = m;
     surf[k] = surf[k] && m >= 0 && m < s.n_materials;
   }
@@ -671,6 +687,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   }
 #endif
   const int slot = slot_v;
+  ART_TPROBE(cx.tprobe, 71);      // the item's loads have arrived
   const float t = hw.t, hu = hw.u, hv = hw.v;
   // dense fold record of this item at this level (DevPaths::fold_dense): by default "the path ended here with value 0"; rec_shadowed: the
   // shadow test this item resolves for its predecessor's explicit light came out "in shadow"
@@ -707,7 +724,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   if (alive) {
     ART_PROBE(2);
     const Surface sf = (key != KEY_MISS) ? surface_at(s, o, d, t, key, hu, hv, cx, pre_n) : Surface{zero, -1, -1};
-    const DevLight* const lights = cx.lights ? cx.lights : s.lights;
+    const DevLight* const lights = cx.lights ? cx.lights : s.lights;      // (read only when the kernel gave no LDS copy)
     const bool mat_ok = hint ? true : ((key != KEY_MISS) && sf.mat >= 0 && sf.mat < s.n_materials);
     const DevMaterial m = hint ? pre_m : (mat_ok ? (cx.materials ? cx.materials : s.materials)[sf.mat] : DevMaterial{MAT_NULL, 0, {0, 0, 0, 0, 0, 0, 0, 0}});
     ART_PROBE(3);
@@ -723,12 +740,12 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
       const float sel_pdf = 1.0f / (float)s.n_lights;
       f3 out = zero;
       if (f.render_type != PT_SHADOW && !(dot(neg(d), n) < 0.0f)) {
-        const f3 emit = (m.light >= 0 && m.light < s.n_lights) ? ld3(lights[m.light].intensity) : zero;
+        const f3 emit = (m.light >= 0 && m.light < s.n_lights) ? (cx.lds_lights ? ld3(cx.lds_lights[m.light].intensity) : ld3(lights[m.light].intensity)) : zero;
         if (f.render_type == PT_STUPID) out = emit;
         else {
           float mis = 1.0f;
           if (!(fl & FLAG_PREV_SPEC)) {
-            const float lp = light_eval_pdf(lights[m.light], o, d, t) * sel_pdf;
+            const float lp = (cx.lds_lights ? light_eval_pdf(cx.lds_lights + m.light, o, d, t) : light_eval_pdf(lights + m.light, o, d, t)) * sel_pdf;
             const float bp = prev_pdf;
             mis = bp * bp / (lp * lp + bp * bp);
           }
@@ -753,7 +770,8 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
           if (light > s.n_lights - 1) light = s.n_lights - 1;
         }
         ART_PROBE(6);
-        const LightSample ls = light_sample(lights[light], u01(rnd.x), u01(rnd.y), hpos);
+        ART_TPROBE(cx.tprobe, 72);  // surface + material + philox done
+        const LightSample ls = cx.lds_lights ? light_sample(cx.lds_lights + light, u01(rnd.x), u01(rnd.y), hpos) : light_sample(lights + light, u01(rnd.x), u01(rnd.y), hpos);
         const f3 sdir = normalize(ls.pos - hpos);
         const float lp = ls.pdf * sel_pdf;
         ART_PROBE(7);
@@ -783,6 +801,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
         qi.e_r[li] = 0.0f; qi.e_g[li] = 0.0f; qi.e_b[li] = 0.0f;
       }
       ART_PROBE(8);
+      ART_TPROBE(cx.tprobe, 73);    // light sample, bsdf_eval, shadow ray done
       const BsdfSample bs = bsdf_sample<MATS>(m, u01(rnd.z), u01(rnd.w), d, n);          // :116-124 / :183-191 / :291-299
       ART_PROBE(9);
       const f3 bxv = bs.color * (1.0f / amax(bs.pdf, kGEpsilonDiv));
@@ -798,6 +817,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     }
   }
   ART_PROBE(40);
+  ART_TPROBE(cx.tprobe, 74);        // bsdf_sample done (all lanes)
   if (dense && !(ART_DIAG_SKIP & 16)) {                      // dense stores: consecutive items, consecutive addresses
     const size_t l0 = (size_t)bounce * P;                   // (the level's base is wave-uniform: a scalar add; the item's offset stays 32 bits)
     put(qi.w_r + l0, w, rec_w.x); put(qi.w_g + l0, w, rec_w.y); put(qi.w_b + l0, w, rec_w.z);
@@ -828,6 +848,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     put(qo.ray_ox, wo, no.x); put(qo.ray_oy, wo, no.y); put(qo.ray_oz, wo, no.z);
     put(qo.ray_dx, wo, nd.x); put(qo.ray_dy, wo, nd.y); put(qo.ray_dz, wo, nd.z);
   }
+  ART_TPROBE(cx.tprobe, 75);        // fold record + output words stored
   if (qo.rec) {
     // the item's rays go out as trace records, at positions given by the item index (REC_BOTH: 2 wo and 2 wo + 1).  A ray the bank's
     // mode has no record for cannot exist (the modes follow the integrator: art_api.cpp); should it ever, the self-check counts it.
@@ -838,8 +859,10 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
       const int per = (mode == REC_BOTH) ? 2 : 1;
       const bool blocks = cx.stage_count > 0;      // k_shade_compact: each kind of ray is its own contiguous block of the wave's records
       if (mode != REC_SHADOW) emit_ray(s, qo, (size_t)wo, rec_slot(mode, wo, false), alive, no, nd, kInfinity, -1.0f, cx, blocks ? cx.stage_item : per * cx.stage_item, 0);
+      ART_TPROBE(cx.tprobe, 76);    // extension ray's record out
       if (mode != REC_EXT) emit_ray(s, qo, qo.sh_t ? (size_t)(kShadowWord | (uint32_t)wo) : so_i, rec_slot(mode, wo, true), shadow, so, sd, s_tfar, qo.shadow_rule ? sh_min : -1.0f, cx, blocks ? cx.stage_item : per * cx.stage_item + (per - 1), 1);
     }
+    ART_TPROBE(cx.tprobe, 77);      // shadow ray's record out
     if (lost != nullptr && ((mode == REC_SHADOW && alive) || (mode == REC_EXT && shadow))) {
 #if defined(__HIP_DEVICE_COMPILE__)
       atomicAdd(lost, 1ull);

@@ -150,13 +150,13 @@ extern "C" int hs_bvh(const ArtSceneDesc* sd, float* nodes, long long node_cap, 
 static_assert(sizeof(ArtLight) == sizeof(DevLight) && sizeof(ArtMaterial) == sizeof(DevMaterial), "ABI records are the device records");
 extern "C" void hs_kat_light_sample(const ArtLight* l, float u1, float u2, const float p[3], float out10[10]) {
   DevLight d; std::memcpy(&d, l, sizeof d);
-  const LightSample r = light_sample(d, u1, u2, ld3(p));
+  const LightSample r = light_sample(&d, u1, u2, ld3(p));
   out10[0] = r.pos.x; out10[1] = r.pos.y; out10[2] = r.pos.z; out10[3] = r.dir.x; out10[4] = r.dir.y; out10[5] = r.dir.z;
   out10[6] = r.intensity.x; out10[7] = r.intensity.y; out10[8] = r.intensity.z; out10[9] = r.pdf;
 }
 extern "C" float hs_kat_light_eval_pdf(const ArtLight* l, const float p[3], const float ray_dir[3], float hit_dist) {
   DevLight d; std::memcpy(&d, l, sizeof d);
-  return light_eval_pdf(d, ld3(p), ld3(ray_dir), hit_dist);
+  return light_eval_pdf(&d, ld3(p), ld3(ray_dir), hit_dist);
 }
 extern "C" void hs_kat_mat_sample(const ArtMaterial* m, float xi1, float xi2, const float ray_dir[3], const float normal[3], float out8[8]) {
   DevMaterial d; std::memcpy(&d, m, sizeof d);
