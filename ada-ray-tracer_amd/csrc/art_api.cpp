@@ -211,7 +211,8 @@ static int download_from(const float* acc_dev, float* accum_host, uint32_t* scre
 // records in one array shared by the banks.  Plain layout (one-ray-per-lane schedule, debug pass): rays as SoA arrays, 29 words.
 constexpr size_t kRecSlack = 4096;       // records past the last one the trace kernel's chunk prefetch may touch
 // (record schedule: 6 ray words, ONE 16-byte hit record + the shadow ray's result word, 7 per-path words)
-static size_t hot_floats(size_t P, bool rec) { return (rec ? (6 + 4 + 1 + 7) : (14 + 8 + 7)) * P; }
+static size_t hot_stride(size_t P) { return (P + 63) & ~(size_t)63; }
+static size_t hot_floats(size_t P, bool rec) { return rec ? (size_t)kHotFields * hot_stride(P) + 64 : (14 + 8 + 7) * P; }
 // (the trace records are not double-banked: a bank's records are dead once its rays are traced, and the next stage reads none of them)
 // cold state: e (depth + 1 levels: dense fold records keep e_k at level k + 1) and w (depth levels) x 3, child (depth levels), term, rad, final flags
 // (+ 4 P words: the queue of the items k_shade_compact defers to its heavy-material instantiation, 16 B each, worst case every item)
@@ -232,17 +233,27 @@ static void carve(DevPaths q[2], int P, int depth, bool rec, uint4** heavy = nul
   for (int k = 0; k < 2; ++k) {
     DevPaths& b = q[k];
     if (rec) {
+      // the bank as ONE block (art_scene.h HotField); the pointer fields name its pieces for the kernels that take them one by one
       b.rec = records;
-      b.ray_ox = take(p); b.ray_oy = take(p); b.ray_oz = take(p); b.ray_dx = take(p); b.ray_dy = take(p); b.ray_dz = take(p);   // the extension ray, for the next stage
+      align(64);
+      const size_t st = hot_stride(p);
+      float* const h = take((size_t)kHotFields * st);
+      b.hot = h; b.stride = (int32_t)st;
+      b.ray_ox = h + HF_OX * st; b.ray_oy = h + HF_OY * st; b.ray_oz = h + HF_OZ * st; b.ray_dx = h + HF_DX * st; b.ray_dy = h + HF_DY * st; b.ray_dz = h + HF_DZ * st;
       b.ray_tfar = nullptr;
+      b.hit = (DevHit*)(h + HF_HIT * st); b.sh_t = h + HF_SHT * st;
+      b.prev_pdf = h + HF_PDF * st; b.flags = (uint32_t*)(h + HF_FLAGS * st); b.sh_min_t = h + HF_SHMIN * st; b.slot_id = (const uint32_t*)(h + HF_SLOT * st);
+      b.cand_r = b.cand_g = b.cand_b = nullptr;                                 // (dense fold records: the pending colour has no hot words)
+      b.shadow_rule = g_ctx.shadow_anyhit ? 1 : 0; b.has_bvh = g_ctx.scene.n_tris > 0 ? 1 : 0;
+      continue;
     } else {
+      b.hot = nullptr; b.stride = 0;
       b.rec = nullptr; b.rec_mode = REC_NONE;
       b.ray_ox = take(2 * p); b.ray_oy = take(2 * p); b.ray_oz = take(2 * p);
       b.ray_dx = take(2 * p); b.ray_dy = take(2 * p); b.ray_dz = take(2 * p); b.ray_tfar = take(2 * p);
     }
     align(4);                                                                   // 16-byte hit records
-    if (rec) { b.hit = (DevHit*)take(4 * p); b.sh_t = take(p); }                // the extension ray's hit record; the shadow ray's result is one word (DevPaths::sh_t)
-    else { b.hit = (DevHit*)take(8 * p); b.sh_t = nullptr; }
+    b.hit = (DevHit*)take(8 * p); b.sh_t = nullptr;
     b.prev_pdf = take(p); b.flags = (uint32_t*)take(p); b.sh_min_t = take(p);
     b.cand_r = take(p); b.cand_g = take(p); b.cand_b = take(p);
     b.slot_id = (const uint32_t*)take(p);
@@ -252,6 +263,7 @@ static void carve(DevPaths q[2], int P, int depth, bool rec, uint4** heavy = nul
   a.e_r = take((depth + 1) * p); a.e_g = take((depth + 1) * p); a.e_b = take((depth + 1) * p);
   a.w_r = take(depth * p); a.w_g = take(depth * p); a.w_b = take(depth * p);
   a.child = (int32_t*)take(depth * p);
+  a.cold = rec ? a.e_r : nullptr; a.depth = depth;       // (the seven takes above are consecutive: ONE block, art_scene.h DevPaths::cold)
   a.fold_dense = rec ? 1 : 0;                   // the compacted (record) schedule keeps dense fold records; the plain one folds by slot
   a.synth0 = rec ? 1 : 0;                       // ... and lets bounce 0 recompute the camera ray instead of reading it back (nothing else reads raygen's bank)
   a.term_r = take(p); a.term_g = take(p); a.term_b = take(p);
@@ -260,7 +272,7 @@ static void carve(DevPaths q[2], int P, int depth, bool rec, uint4** heavy = nul
   DevPaths& c = q[1];
   c.e_r = a.e_r; c.e_g = a.e_g; c.e_b = a.e_b; c.w_r = a.w_r; c.w_g = a.w_g; c.w_b = a.w_b;
   c.term_r = a.term_r; c.term_g = a.term_g; c.term_b = a.term_b; c.rad_r = a.rad_r; c.rad_g = a.rad_g; c.rad_b = a.rad_b;
-  c.final_flags = a.final_flags; c.child = a.child; c.fold_dense = a.fold_dense; c.synth0 = a.synth0;
+  c.final_flags = a.final_flags; c.child = a.child; c.fold_dense = a.fold_dense; c.synth0 = a.synth0; c.cold = a.cold; c.depth = a.depth;
 }
 
 // LDS stack per ray: the tree's worst-case bound if 8 workgroups per CU (8 waves per SIMD) still fit in the CU's 160 KB, else the

@@ -849,6 +849,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(set_waves(S
   if (threadIdx.x == 0) s_rays = 0;
   __syncthreads();
   StageCtx tables;
+  tables.hot_layout = true;
   if (tables_in_lds) { tables.lds_spheres = (const ART_LDS DevSphere*)(uint32_t)(uintptr_t)s_sph; tables.lds_lights = (const ART_LDS DevLight*)(uint32_t)(uintptr_t)s_lgt; }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t lanes_below = (1ull << lane) - 1ull;
@@ -966,8 +967,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(set_waves(S
       if constexpr (kHints) hk = s_hint[k * 256 + r]; else hk = make_uint2(KEY_MISS, (uint32_t)s_hint[k * 256 + r]);
       int w = c0 + k * 256 + (int)(hk.y & 255u);
       if (SET == SET_HEAVY) w = (int)K2->heavy[w].x;       // the queue entry names the item
-      ItemHint ih; ih.key = hk.x; ih.mat = (int32_t)(hk.y >> 9);
-      const ItemHint* const hp = (ART_SHADE_HINT && (hk.y & 256u)) ? &ih : nullptr;
+      ItemHint ih; ih.key = hk.x; ih.mat = (ART_SHADE_HINT && (hk.y & 256u)) ? (int32_t)(hk.y >> 9) : -1;      // mat < 0: no hint (shade_item)
+      const ItemHint* const hp = &ih;
       // (the output item's slot word is written by shade_item with the item's other words: qo.slot_id IS slot_out)
       if (ART_SHADE_DEFER) n_rays += shade_item<MATS>(F, S, Qi, Qo, w, wo, bounce, lost, cx, &ro, hp, CAMERA ? 1 : 0, 1);
       else {

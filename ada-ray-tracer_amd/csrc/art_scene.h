@@ -90,9 +90,18 @@ struct DevFrame {
   float cam_z;          // -float(width)/safe_tan(fov/2)   ray_tracer.adb:67 (computed once on the host)
 };
 
+// Record schedule (round 5): a bank's per-item arrays are ONE block, field f of item w at hot[f * stride + w] (stride: P rounded up to 64
+// items), and the fold arrays ONE block `cold`.  k_shade_compact addresses everything from these two bases with scalar arithmetic: held as
+// ~50 separate pointers (the fields of DevPaths, which still name the same memory for the other kernels) they cost it 80 spilled SGPRs
+// and a scalar load + s_waitcnt in front of almost every access.
+enum HotField : int32_t { HF_OX = 0, HF_OY = 1, HF_OZ = 2, HF_DX = 3, HF_DY = 4, HF_DZ = 5, HF_HIT = 6 /* 4 words per item: fields 6..9 */,
+                          HF_SHT = 10, HF_PDF = 11, HF_FLAGS = 12, HF_SHMIN = 13, HF_SLOT = 14, kHotFields = 15 };
+
 // Wavefront state for a batch of P path slots (slot = local_sample * npix + local_pixel).  All SoA.
 struct DevPaths {
   int32_t P;                    // slots in this batch
+  float* hot; int32_t stride;   // record schedule: the bank's block (HotField); nullptr: only the pointer fields below exist
+  float* cold; int32_t depth;   // record schedule: e_c[level] = cold + (c (depth + 1) + level) P, w_c[level] = cold + (3 (depth + 1) + c depth + level) P, child[level] = cold + (3 (depth + 1) + 3 depth + level) P
   int32_t npix;                 // pixels owned by this device (shard)
   const uint32_t* pixmap;       // local pixel -> global pixel index (y*width + x); nullptr = identity
   uint32_t sample_base;         // global index of local sample 0

@@ -27,9 +27,16 @@ struct StageCtx {
   // k_shade_compact: stage_count > 0 lanes of the wave emit together (stage_item = this lane's rank among them) and copy the records out
   // themselves, one kind of ray at a time; rec_base[0 / 1]: first record of the wave's extension / shadow rays in the output bank
   int stage_count = 0; size_t rec_base[2] = {0, 0};
+  bool hot_layout = false;                     // k_shade_compact: the banks are addressed through DevPaths::hot (one base pointer per bank)
   unsigned long long* tprobe = nullptr;        // -DART_TIME_PROBE: the wave's time-probe word (LDS)
   unsigned long long* lost = nullptr;          // the self-check counter (ArtStats::lost_paths): a staged record read before its lane wrote it is counted there
 };
+
+// the record schedule's blocks (art_scene.h HotField, DevPaths::cold): a field's base is wave-uniform -- scalar arithmetic on one base pointer
+template <class T = float> ART_HD T* hotf(const DevPaths& q, int field) { return reinterpret_cast<T*>(q.hot + (size_t)field * (size_t)q.stride); }
+ART_HD float* cold_e(const DevPaths& q, int c, int level) { return q.cold + ((size_t)c * (size_t)(q.depth + 1) + (size_t)level) * (size_t)q.P; }
+ART_HD float* cold_w(const DevPaths& q, int c, int level) { return q.cold + ((size_t)3 * (size_t)(q.depth + 1) + (size_t)c * (size_t)q.depth + (size_t)level) * (size_t)q.P; }
+ART_HD int32_t* cold_child(const DevPaths& q, int level) { return reinterpret_cast<int32_t*>(q.cold + ((size_t)3 * (size_t)(q.depth + 1) + (size_t)3 * (size_t)q.depth + (size_t)level) * (size_t)q.P); }
 
 // The rays an item leaves a bounce with, for a caller that writes the trace records itself (k_shade_compact: the wave stages one kind of
 // ray at a time and copies it out at a point every lane of the wave reaches).
@@ -385,14 +392,16 @@ struct TraceRec { Rec4 r0, r1, r2, r3; };
 ART_HD TraceRec make_record(const DevScene& s, const DevPaths& qo, size_t hit_index, bool live, f3 o, f3 d, float tfar, float shm, const StageCtx& cx = StageCtx()) {
   TraceRec t;
   const bool word = ((uint32_t)hit_index & kShadowWord) != 0u;
-  if (word && !live) put(qo.sh_t, (int)((uint32_t)hit_index & ~kShadowWord), -1.0f);       // (an item without a shadow ray: never read, kept defined)
+  float* const sh_t_out = cx.hot_layout ? hotf(qo, HF_SHT) : qo.sh_t;
+  if (word && !live) put(sh_t_out, (int)((uint32_t)hit_index & ~kShadowWord), -1.0f);       // (an item without a shadow ray: never read, kept defined)
   t.r0 = Rec4{0.0f, 0.0f, 0.0f, -1.0f}; t.r1 = Rec4{0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, KEY_MISS)}; t.r2 = Rec4{0.0f, 0.0f, 0.0f, -1.0f};
   t.r3 = Rec4{0.0f, __builtin_bit_cast(float, (uint32_t)hit_index), 0.0f, 0.0f};
   ART_PROBE(30);
   if (live) {
     ART_PROBE(31);
     const Cand best = analytic_bound(s, cx, o, d, tfar);
-    if (word) put(qo.sh_t, (int)((uint32_t)hit_index & ~kShadowWord), (best.key != KEY_MISS) ? best.t : -1.0f);
+    if (word) put(sh_t_out, (int)((uint32_t)hit_index & ~kShadowWord), (best.key != KEY_MISS) ? best.t : -1.0f);
+    else if (cx.hot_layout) put(hotf<DevHit>(qo, HF_HIT), (int)hit_index, DevHit{best.t, best.key, best.u, best.v});
     else if (!(ART_DIAG_SKIP & 8)) qo.hit[hit_index] = DevHit{best.t, best.key, best.u, best.v};
     const bool near_done = (shm >= 0.0f) && (best.key != KEY_MISS) && (best.t <= shm);       // shadow_rule: decided
     if (!near_done && qo.has_bvh) {
@@ -556,8 +565,8 @@ ART_HD void item_classes(const DevScene& s, const DevPaths& qi, const int (&w)[N
 #endif
   for (int k = 0; k < N; ++k) {                                   // step 1: flags and hit keys
     const int wk = on[k] ? w[k] : 0;
-    fl[k] = camera ? (FLAG_ALIVE | FLAG_PREV_SPEC) : qi.flags[wk];
-    key[k] = qi.hit[wk].key;
+    fl[k] = camera ? (FLAG_ALIVE | FLAG_PREV_SPEC) : at(hotf<const uint32_t>(qi, HF_FLAGS), wk);      // (k_shade_compact only: the record schedule's block)
+    key[k] = ld_off(hotf<const uint32_t>(qi, HF_HIT), (uint32_t)wk * 16u + 4u);
   }
   if (!camera) pin_loads(fl);
   pin_loads(key);
@@ -621,29 +630,33 @@ ART_HD bool item_survives(const DevFrame& f, const DevScene& s, const DevPaths& 
 // dependent ones (hit -> triangle shading record -> material).
 template <int MATS = kMatsAll>
 ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, const DevPaths& qo, int w, int wo, int bounce, unsigned long long* lost = nullptr,
-                      const StageCtx& cx = StageCtx(), RayOut* defer = nullptr, const ItemHint* hint = nullptr, int camera_mode = -1, int dense_mode = -1) {
+                      const StageCtx& cx = StageCtx(), RayOut* defer = nullptr, const ItemHint* hint_in = nullptr, int camera_mode = -1, int dense_mode = -1) {
   ART_PROBE(0);
   // dense_mode: 1 / 0 = the caller knows which fold records the schedule keeps (k_shade_compact: dense; the dead branches and their
   // pointer loads then drop out of the kernel), -1 = look at the bank
   const bool dense = (dense_mode >= 0) ? (dense_mode != 0) : (qi.fold_dense != 0);
-  const int slot_loaded = item_slot(qi, w);
+  const bool batch = (dense_mode == 1);                // k_shade_compact: hints exist, the record schedule's blocks exist (DevPaths::hot / cold)
+  const int slot_loaded = batch ? ((camera_mode == 1) ? w : (int)at(hotf<const uint32_t>(qi, HF_SLOT), w)) : item_slot(qi, w);
   const size_t P = (size_t)qi.P;
   const bool camera = (camera_mode >= 0) ? (camera_mode != 0) : (qi.synth0 && qi.slot_id == nullptr);         // bounce 0 of the compacted schedule: raygen stored the hit and nothing else (DevPaths::synth0)
-  uint32_t fl = camera ? (FLAG_ALIVE | FLAG_PREV_SPEC) : at(qi.flags, w);
+  uint32_t fl = camera ? (FLAG_ALIVE | FLAG_PREV_SPEC) : at(batch ? hotf<const uint32_t>(qi, HF_FLAGS) : qi.flags, w);
   // ---- everything the item holds is read first: ONE batch of independent loads (round 5).  Written as conditional loads the compiler sank
   // each into the branch that uses it and waited for them one by one -- eight memory round trips in a row at the head of every item, at the
   // stage's 80-VGPR cap -- so the loads a hint makes possible are unconditional (an item without a hint reads record 0 / material 0 and
   // ignores them), and on the device an empty asm that names every loaded value pins them all before the first use.
-  DevHit hw = at(qi.hit, w);
-  const uint32_t key = hint ? hint->key : hw.key;
+  DevHit hw = at(batch ? hotf<const DevHit>(qi, HF_HIT) : qi.hit, w);
+  // (hint_in may point at a record that says "no hint" (mat < 0): the caller then need not choose between a pointer and nullptr per lane --
+  // which forced the record into scratch memory, with a scratch load and an s_waitcnt vmcnt(0) at each of its four uses, round 5)
+  const bool hinted = (hint_in != nullptr) && (hint_in->mat >= 0);
+  const ItemHint hint_v = hint_in ? *hint_in : ItemHint{KEY_MISS, -1};
+  const uint32_t key = hinted ? hint_v.key : hw.key;
   PreNormals pre_n = PreNormals{{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, false};
   DevMaterial pre_m = DevMaterial{MAT_NULL, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
-  const bool batch = (dense_mode == 1);                // k_shade_compact: hints exist, the record schedule's arrays exist
-  if (hint || batch) {
-    pre_m = (cx.materials ? cx.materials : s.materials)[hint ? hint->mat : 0];
-    const bool tri = hint && !(ART_DIAG_SKIP & 2) && (hint->key & ~KEY_INDEX_MASK) == KEY_TRI;
+  if (hinted || batch) {
+    pre_m = (cx.materials ? cx.materials : s.materials)[hinted ? hint_v.mat : 0];
+    const bool tri = hinted && !(ART_DIAG_SKIP & 2) && (hint_v.key & ~KEY_INDEX_MASK) == KEY_TRI;
     if (tri || batch) {
-      const float* r = (s.m_shade ? s.m_shade : (const float*)(const void*)s.materials) + (size_t)kTriShadeFloats * (size_t)(tri ? (hint->key & KEY_INDEX_MASK) : 0u);
+      const float* r = (s.m_shade ? s.m_shade : (const float*)(const void*)s.materials) + (size_t)kTriShadeFloats * (size_t)(tri ? (hint_v.key & KEY_INDEX_MASK) : 0u);
       pre_n.a = ld3(r); pre_n.b = ld3(r + 3); pre_n.c = ld3(r + 6); pre_n.on = tri;
     }
   }
@@ -651,8 +664,8 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   const bool may_owe = (bounce > 0) && (f.render_type != PT_STUPID);
   // (hs_t: t of the shadow ray's closest hit, -1 = none: the word sh_t[w] of the record schedule, else from the hit record at [P + w])
   float hs_t = -1.0f, owed_min = 0.0f; f3 owed = mk3(0.0f, 0.0f, 0.0f);
-  auto shadow_t = [&]() { if (qi.sh_t) return at(qi.sh_t, w); const DevHit h = qi.hit[P + (size_t)w]; return (h.key != KEY_MISS) ? h.t : -1.0f; };
-  if (may_owe || (batch && !camera)) { hs_t = shadow_t(); owed_min = at(qi.sh_min_t, w); if (!dense) owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
+  auto shadow_t = [&]() { if (batch) return at(hotf<const float>(qi, HF_SHT), w); if (qi.sh_t) return at(qi.sh_t, w); const DevHit h = qi.hit[P + (size_t)w]; return (h.key != KEY_MISS) ? h.t : -1.0f; };
+  if (may_owe || (batch && !camera)) { hs_t = shadow_t(); owed_min = at(batch ? hotf<const float>(qi, HF_SHMIN) : qi.sh_min_t, w); if (!dense) owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
   // (the extension ray is kept as six SoA words next to its trace record: reading it back out of the record would pull the whole
   // 128-byte line of the item's two records for 24 useful bytes)
   f3 o, d; float prev_pdf;
@@ -665,25 +678,30 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
       d = camera_dir(f, s, cpix, csam);                                         // raygen_slot's own expression: the same bits
     } else d = mk3(at(qi.ray_dx, w), at(qi.ray_dy, w), at(qi.ray_dz, w));
   } else {
-    o = mk3(at(qi.ray_ox, w), at(qi.ray_oy, w), at(qi.ray_oz, w));
-    d = mk3(at(qi.ray_dx, w), at(qi.ray_dy, w), at(qi.ray_dz, w));
-    prev_pdf = at(qi.prev_pdf, w);
+    if (batch) {
+      o = mk3(at(hotf<const float>(qi, HF_OX), w), at(hotf<const float>(qi, HF_OY), w), at(hotf<const float>(qi, HF_OZ), w));
+      d = mk3(at(hotf<const float>(qi, HF_DX), w), at(hotf<const float>(qi, HF_DY), w), at(hotf<const float>(qi, HF_DZ), w));
+      prev_pdf = at(hotf<const float>(qi, HF_PDF), w);
+    } else {
+      o = mk3(at(qi.ray_ox, w), at(qi.ray_oy, w), at(qi.ray_oz, w));
+      d = mk3(at(qi.ray_dx, w), at(qi.ray_dy, w), at(qi.ray_dz, w));
+      prev_pdf = at(qi.prev_pdf, w);
+    }
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   if (batch) {
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    f4v mp0 = {pre_m.p[0], pre_m.p[1], pre_m.p[2], pre_m.p[3]}, mp1 = {pre_m.p[4], pre_m.p[5], pre_m.p[6], pre_m.p[7]};
+    // (input operands only: tied in-out operands made the register allocator copy the loaded values around, and it put those copies --
+    // hence a wait -- between the first loads and the last)
     if (camera) {
-      asm volatile("; the item's loads are in flight together" : "+v"(slot_v), "+v"(hw.t), "+v"(hw.key), "+v"(hw.u), "+v"(hw.v),
-                   "+v"(pre_n.a.x), "+v"(pre_n.a.y), "+v"(pre_n.a.z), "+v"(pre_n.b.x), "+v"(pre_n.b.y), "+v"(pre_n.b.z), "+v"(pre_n.c.x), "+v"(pre_n.c.y), "+v"(pre_n.c.z),
-                   "+v"(pre_m.type), "+v"(pre_m.light), "+v"(mp0), "+v"(mp1));
+      asm volatile("; the item's loads are in flight together" :: "v"(slot_v), "v"(hw.t), "v"(hw.key), "v"(hw.u), "v"(hw.v),
+                   "v"(pre_n.a.x), "v"(pre_n.a.y), "v"(pre_n.a.z), "v"(pre_n.b.x), "v"(pre_n.b.y), "v"(pre_n.b.z), "v"(pre_n.c.x), "v"(pre_n.c.y), "v"(pre_n.c.z),
+                   "v"(pre_m.type), "v"(pre_m.light), "v"(pre_m.p[0]), "v"(pre_m.p[1]), "v"(pre_m.p[2]), "v"(pre_m.p[3]), "v"(pre_m.p[6]));
     } else {
-      asm volatile("; the item's loads are in flight together" : "+v"(slot_v), "+v"(fl), "+v"(hw.t), "+v"(hw.key), "+v"(hw.u), "+v"(hw.v), "+v"(hs_t), "+v"(owed_min), "+v"(prev_pdf),
-                   "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(d.x), "+v"(d.y), "+v"(d.z),
-                   "+v"(pre_n.a.x), "+v"(pre_n.a.y), "+v"(pre_n.a.z), "+v"(pre_n.b.x), "+v"(pre_n.b.y), "+v"(pre_n.b.z), "+v"(pre_n.c.x), "+v"(pre_n.c.y), "+v"(pre_n.c.z),
-                   "+v"(pre_m.type), "+v"(pre_m.light), "+v"(mp0), "+v"(mp1));
+      asm volatile("; the item's loads are in flight together" :: "v"(slot_v), "v"(fl), "v"(hw.t), "v"(hw.key), "v"(hw.u), "v"(hw.v), "v"(hs_t), "v"(owed_min), "v"(prev_pdf),
+                   "v"(o.x), "v"(o.y), "v"(o.z), "v"(d.x), "v"(d.y), "v"(d.z),
+                   "v"(pre_n.a.x), "v"(pre_n.a.y), "v"(pre_n.a.z), "v"(pre_n.b.x), "v"(pre_n.b.y), "v"(pre_n.b.z), "v"(pre_n.c.x), "v"(pre_n.c.y), "v"(pre_n.c.z),
+                   "v"(pre_m.type), "v"(pre_m.light), "v"(pre_m.p[0]), "v"(pre_m.p[1]), "v"(pre_m.p[2]), "v"(pre_m.p[3]));
     }
-    pre_m.p[0] = mp0.x; pre_m.p[1] = mp0.y; pre_m.p[2] = mp0.z; pre_m.p[3] = mp0.w; pre_m.p[4] = mp1.x; pre_m.p[5] = mp1.y; pre_m.p[6] = mp1.z; pre_m.p[7] = mp1.w;
   }
 #endif
   const int slot = slot_v;
@@ -695,7 +713,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   if (fl & FLAG_SHADOW_PENDING) {
     ART_PROBE(1);
     // Compute_Shadow: hit and t < maxDist - eps2 (enforced by the ray's tfar clip) and t > 10*eps
-    if (!may_owe) { hs_t = shadow_t(); owed_min = at(qi.sh_min_t, w); if (!dense) owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
+    if (!may_owe && !(batch && !camera)) { hs_t = shadow_t(); owed_min = at(qi.sh_min_t, w); if (!dense) owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
     const bool in_shadow = (hs_t >= 0.0f) && (hs_t > owed_min);       // hit, and beyond 10 eps (a hit's t is positive; -1: no hit)
     if (dense) rec_shadowed = in_shadow;      // dense fold records: the previous stage left the explicit colour itself at e[bounce][w]; this item's record says whether it counts
     else {                                            // e of the previous level at [bounce - 1][slot]
@@ -725,8 +743,8 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     ART_PROBE(2);
     const Surface sf = (key != KEY_MISS) ? surface_at(s, o, d, t, key, hu, hv, cx, pre_n) : Surface{zero, -1, -1};
     const DevLight* const lights = cx.lights ? cx.lights : s.lights;      // (read only when the kernel gave no LDS copy)
-    const bool mat_ok = hint ? true : ((key != KEY_MISS) && sf.mat >= 0 && sf.mat < s.n_materials);
-    const DevMaterial m = hint ? pre_m : (mat_ok ? (cx.materials ? cx.materials : s.materials)[sf.mat] : DevMaterial{MAT_NULL, 0, {0, 0, 0, 0, 0, 0, 0, 0}});
+    const bool mat_ok = hinted ? true : ((key != KEY_MISS) && sf.mat >= 0 && sf.mat < s.n_materials);
+    const DevMaterial m = hinted ? pre_m : (mat_ok ? (cx.materials ? cx.materials : s.materials)[sf.mat] : DevMaterial{MAT_NULL, 0, {0, 0, 0, 0, 0, 0, 0, 0}});
     ART_PROBE(3);
     if (MATS != kMatsAll && mat_ok && !(MATS & mat_bit(m.type)) && lost != nullptr) {   // a material this instantiation was not compiled for: the caller's sort is broken
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -820,8 +838,9 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   ART_TPROBE(cx.tprobe, 74);        // bsdf_sample done (all lanes)
   if (dense && !(ART_DIAG_SKIP & 16)) {                      // dense stores: consecutive items, consecutive addresses
     const size_t l0 = (size_t)bounce * P;                   // (the level's base is wave-uniform: a scalar add; the item's offset stays 32 bits)
-    put(qi.w_r + l0, w, rec_w.x); put(qi.w_g + l0, w, rec_w.y); put(qi.w_b + l0, w, rec_w.z);
-    put(qi.child + l0, w, fold_child_word((rec_child == -2 && wo >= 0) ? wo : rec_child, rec_shadowed));
+    const int32_t cw = fold_child_word((rec_child == -2 && wo >= 0) ? wo : rec_child, rec_shadowed);
+    if (batch) { put(cold_w(qi, 0, bounce), w, rec_w.x); put(cold_w(qi, 1, bounce), w, rec_w.y); put(cold_w(qi, 2, bounce), w, rec_w.z); put(cold_child(qi, bounce), w, cw); }
+    else { put(qi.w_r + l0, w, rec_w.x); put(qi.w_g + l0, w, rec_w.y); put(qi.w_b + l0, w, rec_w.z); put(qi.child + l0, w, cw); }
   }
   // ---- the output item
   if (wo < 0) {
@@ -834,6 +853,19 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   }
   ART_PROBE(41);
   const size_t so_i = (size_t)qo.P + (size_t)wo;
+  if (batch) {                                           // the record schedule: every word through the output bank's ONE base pointer
+    put(hotf<uint32_t>(qo, HF_SLOT), wo, (uint32_t)slot);
+    put(hotf<uint32_t>(qo, HF_FLAGS), wo, fl);
+    put(hotf<float>(qo, HF_PDF), wo, new_pdf);
+    if (shadow) {
+      put(hotf<float>(qo, HF_SHMIN), wo, sh_min);
+      put(cold_e(qi, 0, bounce + 1), wo, cand.x); put(cold_e(qi, 1, bounce + 1), wo, cand.y); put(cold_e(qi, 2, bounce + 1), wo, cand.z);
+    }
+    if (alive && !(ART_DIAG_SKIP & 4)) {
+      put(hotf<float>(qo, HF_OX), wo, no.x); put(hotf<float>(qo, HF_OY), wo, no.y); put(hotf<float>(qo, HF_OZ), wo, no.z);
+      put(hotf<float>(qo, HF_DX), wo, nd.x); put(hotf<float>(qo, HF_DY), wo, nd.y); put(hotf<float>(qo, HF_DZ), wo, nd.z);
+    }
+  } else {
   if (qo.slot_id != nullptr) put(const_cast<uint32_t*>(qo.slot_id), wo, (uint32_t)slot);      // compacted banks: the output item's slot
   put(qo.flags, wo, fl);
   put(qo.prev_pdf, wo, new_pdf);
@@ -848,6 +880,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     put(qo.ray_ox, wo, no.x); put(qo.ray_oy, wo, no.y); put(qo.ray_oz, wo, no.z);
     put(qo.ray_dx, wo, nd.x); put(qo.ray_dy, wo, nd.y); put(qo.ray_dz, wo, nd.z);
   }
+  }
   ART_TPROBE(cx.tprobe, 75);        // fold record + output words stored
   if (qo.rec) {
     // the item's rays go out as trace records, at positions given by the item index (REC_BOTH: 2 wo and 2 wo + 1).  A ray the bank's
@@ -860,7 +893,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
       const bool blocks = cx.stage_count > 0;      // k_shade_compact: each kind of ray is its own contiguous block of the wave's records
       if (mode != REC_SHADOW) emit_ray(s, qo, (size_t)wo, rec_slot(mode, wo, false), alive, no, nd, kInfinity, -1.0f, cx, blocks ? cx.stage_item : per * cx.stage_item, 0);
       ART_TPROBE(cx.tprobe, 76);    // extension ray's record out
-      if (mode != REC_EXT) emit_ray(s, qo, qo.sh_t ? (size_t)(kShadowWord | (uint32_t)wo) : so_i, rec_slot(mode, wo, true), shadow, so, sd, s_tfar, qo.shadow_rule ? sh_min : -1.0f, cx, blocks ? cx.stage_item : per * cx.stage_item + (per - 1), 1);
+      if (mode != REC_EXT) emit_ray(s, qo, (batch || qo.sh_t) ? (size_t)(kShadowWord | (uint32_t)wo) : so_i, rec_slot(mode, wo, true), shadow, so, sd, s_tfar, qo.shadow_rule ? sh_min : -1.0f, cx, blocks ? cx.stage_item : per * cx.stage_item + (per - 1), 1);
     }
     ART_TPROBE(cx.tprobe, 77);      // shadow ray's record out
     if (lost != nullptr && ((mode == REC_SHADOW && alive) || (mode == REC_EXT && shadow))) {
