@@ -28,9 +28,12 @@ static __device__ int g_lane_probe_on;        // set around the launches of the 
 // probe to g_lane_probe[2k] (and 1 to [2k + 1]); tp: the wave's own word in LDS holding the time of that previous probe.  Where a wave of
 // k_shade_compact spends its wall time -- waiting for its loads, for the store queue, at the barriers, or issuing instructions.
 #if defined(ART_TIME_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+// (tp[0]: the wave's previous probe time; the sums go to the workgroup's LDS table tp_acc -- flushed to g_lane_probe once per workgroup:
+// a global atomic per probe and wave made the probes themselves the slowest thing in the kernel)
 #define ART_TPROBE(tp, k) do { if ((tp) != nullptr && g_lane_probe_on) { const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true); \
     if ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == __builtin_ctzll(m_)) { const unsigned long long now_ = __builtin_readcyclecounter(); \
-      atomicAdd(&g_lane_probe[2 * (k)], now_ - *(volatile unsigned long long*)(tp)); atomicAdd(&g_lane_probe[2 * (k) + 1], 1ull); *(volatile unsigned long long*)(tp) = now_; } } } while (0)
+      unsigned long long* const acc_ = *(unsigned long long* volatile*)((tp) + 1); \
+      atomicAdd(&acc_[2 * ((k) - 64)], now_ - *(volatile unsigned long long*)(tp)); atomicAdd(&acc_[2 * ((k) - 64) + 1], 1ull); *(volatile unsigned long long*)(tp) = now_; } } } while (0)
 #else
 #define ART_TPROBE(tp, k) do { } while (0)
 #endif
@@ -71,9 +74,12 @@ ART_HD void isect_sphere(f3 o, f3 d, const DevSphere& s, uint32_t index, Cand& b
   }
 }
 
-// IntersectBox, verbatim slab arithmetic (compare-select min/max, 1/dir may be +-inf)
-ART_HD bool slab_reference(f3 o, f3 d, const float* bmin, const float* bmax, float& tmin, float& tmax) {
-  const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+// IntersectBox, verbatim slab arithmetic (compare-select min/max, 1/dir may be +-inf).  rcp = (1/d.x, 1/d.y, 1/d.z): the caller may have
+// them already (ray_rcp: a ray's three reciprocals are needed by the Cornell box, by the brute-force mesh's box and by the BVH's slab
+// set-up -- the same IEEE divisions of the same operands, done once per ray instead of up to three times)
+ART_HD f3 ray_rcp(f3 d) { return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
+ART_HD bool slab_reference(f3 o, f3 rcp, const float* bmin, const float* bmax, float& tmin, float& tmax) {
+  const float ix = rcp.x, iy = rcp.y, iz = rcp.z;
   const float lo = (bmax[0] - o.x) * ix, hi = (bmin[0] - o.x) * ix;
   const float lo1 = (bmax[1] - o.y) * iy, hi1 = (bmin[1] - o.y) * iy;
   const float lo2 = (bmax[2] - o.z) * iz, hi2 = (bmin[2] - o.z) * iz;
@@ -84,10 +90,10 @@ ART_HD bool slab_reference(f3 o, f3 d, const float* bmin, const float* bmax, flo
 }
 
 // IntersectCornellBox: exit distance, face by |p - bound| < 1e-5 with later faces overriding, open face 5
-ART_HD void isect_cornell(f3 o, f3 d, const DevScene& s, Cand& best) {
+ART_HD void isect_cornell(f3 o, f3 d, f3 rcp, const DevScene& s, Cand& best) {
   float tmin, tmax;
   ART_PROBE(52);
-  if (!slab_reference(o, d, s.cb_min, s.cb_max, tmin, tmax)) return;
+  if (!slab_reference(o, rcp, s.cb_min, s.cb_max, tmin, tmax)) return;
   ART_PROBE(53);
   const f3 p = o + tmax * d;
   const float eps = 1.0e-5f;
@@ -127,10 +133,10 @@ ART_HD bool tri_raw(f3 o, f3 d, f3 A, f3 B, f3 C, float& t, float& u, float& v) 
 
 // IntersectMeshBF with its (tmin, tmax) window semantics: triangles in index order, the window
 // collapses to (t, t+1e-6) after every accepted hit ("first hit wins").  One candidate results.
-ART_HD void isect_bf_mesh(f3 o, f3 d, const DevScene& s, Cand& best) {
+ART_HD void isect_bf_mesh(f3 o, f3 d, f3 rcp, const DevScene& s, Cand& best) {
   if (s.bf_ntris <= 0) return;
   float bt0, bt1;
-  if (!slab_reference(o, d, s.bf_bbmin, s.bf_bbmax, bt0, bt1)) return;
+  if (!slab_reference(o, rcp, s.bf_bbmin, s.bf_bbmax, bt0, bt1)) return;
   float wmin = 0.0f, wmax = 1000000.0f;
   bool any = false; uint32_t tri_id = 0; float ht = 0.0f, hu = 0.0f, hv = 0.0f;
   for (int i = 0; i < s.bf_ntris; ++i) {
@@ -160,6 +166,12 @@ ART_HD void slab_setup(f3 o, f3 d, f3& inv, f3& noi) {
   const float dy = (fabsf(d.y) < tiny) ? copysignf(tiny, d.y) : d.y;
   const float dz = (fabsf(d.z) < tiny) ? copysignf(tiny, d.z) : d.z;
   inv = mk3(1.0f / dx, 1.0f / dy, 1.0f / dz);
+  noi = mk3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+}
+// the same from the ray's reciprocals (ray_rcp): 1 / +-tiny is the constant +-(1 / tiny), every other component IS the reciprocal -- no division
+ART_HD void slab_setup_rcp(f3 o, f3 d, f3 rcp, f3& inv, f3& noi) {
+  const float tiny = 1.0e-30f, big = 1.0f / tiny;
+  inv = mk3((fabsf(d.x) < tiny) ? copysignf(big, d.x) : rcp.x, (fabsf(d.y) < tiny) ? copysignf(big, d.y) : rcp.y, (fabsf(d.z) < tiny) ? copysignf(big, d.z) : rcp.z);
   noi = mk3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
 }
 
@@ -248,10 +260,11 @@ template <bool STATS>
 ART_HD Cand closest_hit(const DevScene& s, f3 o, f3 d, float tfar, BvhStats* st, float shm = -1.0f) {
   Cand best = cand_init(tfar);
   for (int i = 0; i < s.n_spheres; ++i) isect_sphere(o, d, s.spheres[i], (uint32_t)i, best);
-  if (s.has_cornell) isect_cornell(o, d, s, best);
+  const f3 rcp = ray_rcp(d);
+  if (s.has_cornell) isect_cornell(o, d, rcp, s, best);
   for (int i = 0; i < s.n_lights; ++i)
     if (s.lights[i].shape == LIGHT_RECT) isect_quad(o, d, s.lights + i, (uint32_t)i, best);
-  isect_bf_mesh(o, d, s, best);
+  isect_bf_mesh(o, d, rcp, s, best);
   ShadowState sh; sh.shm = shm; sh.far = false; sh.rep = best;
   if (shadow_rule(sh, best)) return best;
   bvh_closest<STATS>(s, o, d, best, st, sh);

@@ -561,12 +561,13 @@ __global__ __launch_bounds__(256) void k_analytic(const DevScene S, const TraceA
         Cand best = cand_init(tfar);
         for (int k = 0; k < n_sph_lds; ++k) isect_sphere(o, d, s_sph[k], (uint32_t)k, best);
         for (int k = n_sph_lds; k < S.n_spheres; ++k) isect_sphere(o, d, S.spheres[k], (uint32_t)k, best);
-        if (S.has_cornell) isect_cornell(o, d, S, best);
+        const f3 rcp = ray_rcp(d);
+        if (S.has_cornell) isect_cornell(o, d, rcp, S, best);
         for (int k = 0; k < n_lgt_lds; ++k)
           if (s_lgt[k].shape == LIGHT_RECT) isect_quad(o, d, &s_lgt[k], (uint32_t)k, best);
         for (int k = n_lgt_lds; k < S.n_lights; ++k)
           if (S.lights[k].shape == LIGHT_RECT) isect_quad(o, d, S.lights + k, (uint32_t)k, best);
-        isect_bf_mesh(o, d, S, best);
+        isect_bf_mesh(o, d, rcp, S, best);
         A.hit[i] = DevHit{best.t, best.key, best.u, best.v};
         const bool near_done = (shm >= 0.0f) && (best.key != KEY_MISS) && (best.t <= shm);   // shadow_rule: decided
         queue_it = (A.n_tris > 0) && !near_done;
@@ -854,9 +855,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(set_waves(S
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t lanes_below = (1ull << lane) - 1ull;
 #if defined(ART_TIME_PROBE)
-  __shared__ unsigned long long s_tprobe[4];
-  if (lane == 0) s_tprobe[wave] = __builtin_readcyclecounter();
-  tables.tprobe = &s_tprobe[wave];
+  __shared__ unsigned long long s_tprobe[4][2];        // per wave: { time of the previous probe, address of the workgroup's table }
+  __shared__ unsigned long long s_tacc[2 * 32];
+  if (threadIdx.x < 64) s_tacc[threadIdx.x] = 0;
+  if (lane == 0) { s_tprobe[wave][0] = __builtin_readcyclecounter(); s_tprobe[wave][1] = (unsigned long long)(uintptr_t)s_tacc; }
+  __syncthreads();
+  tables.tprobe = &s_tprobe[wave][0];
 #endif
   // ---- 1. classify; a wave's items of one class take consecutive places in the class (of their round)
   int cls[PER], rank[PER]; ItemHint hint[PER];
@@ -957,7 +961,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(set_waves(S
     const ShadeKernArgs* const K2 = K;
 #endif
     ART_TPROBE(tables.tprobe, 70);    // round bookkeeping (and, after the first round, whatever followed the last probe of the item before)
-    const int r = (int)threadIdx.x;                       // position in the sorted round
+    // Which 64 sorted positions of the round this wave takes: tile (wave + k) mod 4 (round 5).  A sorted round is [Lambert ...][Phong][glass]
+    // [mirror][cheap]: its last tile is where the classes meet -- on C4 a few Lambert lanes, the round's 13 Phong items and its ~33 ended
+    // paths, three code paths one after the other, about three times a one-class tile's time.  With tile = wave that tile went to wave 3 of
+    // every workgroup in every round, i.e. to the same SIMD of the CU (a workgroup's four waves sit on its four SIMDs); rotated, every wave
+    // gets it once per chunk.
+#ifndef ART_SHADE_ROTATE
+#define ART_SHADE_ROTATE 0   // measured (profiles/r5_shade/ab8_rotate.txt): no gain on C3 / C5, bounce 0 4 % slower on C4 / S4 -- the hardware does not pin wave 3 to one SIMD
+#endif
+    const int tile = ART_SHADE_ROTATE ? ((wave + k) & 3) : wave;
+    const int r = tile * 64 + lane;                       // position in the sorted round
     const int n_all_k = s_nall[k], n_keep_k = s_nkeep[k], out0_k = s_out0[k];
     const bool keep = r < n_keep_k;
     const int wo = keep ? base + out0_k + r : -1;
@@ -974,8 +987,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(set_waves(S
       else {
         StageCtx cy = tables;
         if (staged) {
-          const int nk = min(64, max(0, n_keep_k - wave * 64)), per = (Qo.rec_mode == REC_BOTH) ? 2 : 1;
-          const size_t first = (size_t)per * (size_t)(base + out0_k + wave * 64);
+          const int nk = min(64, max(0, n_keep_k - tile * 64)), per = (Qo.rec_mode == REC_BOTH) ? 2 : 1;
+          const size_t first = (size_t)per * (size_t)(base + out0_k + tile * 64);
           cy.stage = s_stage[wave]; cy.stage_pitch = kStagePitch; cy.stage_item = lane; cy.stage_count = nk; cy.lost = lost;
           cy.rec_base[0] = first; cy.rec_base[1] = (per == 2) ? first + (size_t)nk : first;
         }
@@ -984,7 +997,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(set_waves(S
     }
     if (ART_SHADE_DEFER && Qo.rec != nullptr) {
       // every lane of the wave is here.  The wave's survivors of this round are its lanes [0, nk): consecutive output items.
-      const int r0 = wave * 64;
+      const int r0 = tile * 64;
       const int nk = min(64, max(0, n_keep_k - r0));
       if (nk > 0) {                                        // wave-uniform
         const int per = (mode == REC_BOTH) ? 2 : 1;
@@ -1010,6 +1023,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(set_waves(S
     }
   }
   ART_TPROBE(tables.tprobe, 68);      // end of the last round
+#if defined(ART_TIME_PROBE)
+  __syncthreads();
+  if (threadIdx.x < 64 && s_tacc[threadIdx.x] != 0) atomicAdd(&g_lane_probe[2 * 64 + threadIdx.x], s_tacc[threadIdx.x]);
+#endif
   // record mode: the rays just emitted are the closest-hit queries of the next trace launch (k_analytic counts them in the plain layout)
   if (Qo.rec != nullptr && rays_a != nullptr) {
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_xor(n_rays, off);

@@ -37,6 +37,32 @@ template <class T> ART_HD void st_off(T* base, uint32_t byte_off, T v) { *reinte
 // at(base, i) / put(base, i, v): base[i] that way -- every per-item array of a path bank has fewer than 2^27 items of at most 16 bytes
 template <class T> ART_HD T at(const T* base, int i) { return ld_off(base, (uint32_t)i * (uint32_t)sizeof(T)); }
 template <class T> ART_HD void put(T* base, int i, T v) { st_off(base, (uint32_t)i * (uint32_t)sizeof(T), v); }
+// Streaming variants (round 5): what a wavefront stage reads was written by another kernel and is read once; what it writes is read once by
+// a later kernel.  Non-temporal accesses keep that traffic from displacing the lines that ARE re-used (the triangles' shading records, the
+// material table, the next rounds' windows).  ART_NT bits: 1 stores, 2 loads.
+#ifndef ART_NT
+#define ART_NT 1
+#endif
+template <class T> ART_HD void put_s(T* base, int i, T v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr ((ART_NT & 1) != 0 && sizeof(T) == 4) { __builtin_nontemporal_store(v, reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (uint32_t)i * 4u)); return; }
+  else if constexpr ((ART_NT & 1) != 0 && sizeof(T) == 16) {
+    typedef float f4nt __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(__builtin_bit_cast(f4nt, v), reinterpret_cast<f4nt*>(reinterpret_cast<char*>(base) + (uint32_t)i * 16u)); return;
+  }
+#endif
+  put(base, i, v);
+}
+template <class T> ART_HD T at_s(const T* base, int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr ((ART_NT & 2) != 0 && sizeof(T) == 4) return __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (uint32_t)i * 4u));
+  else if constexpr ((ART_NT & 2) != 0 && sizeof(T) == 16) {
+    typedef float f4nt __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(T, __builtin_nontemporal_load(reinterpret_cast<const f4nt*>(reinterpret_cast<const char*>(base) + (uint32_t)i * 16u)));
+  }
+#endif
+  return at(base, i);
+}
 
 constexpr float kInfinity = 3.4028234663852886e38f;  // vector_math.ads:17 (Float'Last, finite)
 constexpr float kPi       = 0x1.921fb6p+1f;          // vector_math.ads:19

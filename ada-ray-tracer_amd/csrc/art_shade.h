@@ -367,18 +367,19 @@ ART_HD Surface surface_at(const DevScene& s, f3 o, f3 d, float t, uint32_t key, 
 // Candidates 1-4 of Scene.Find_Closest_Hit (scene.adb:62-69: spheres, Cornell box, rect lights, the reference's brute-force mesh):
 // the starting bound of the BVH search.  The same calls in the same order as k_analytic and closest_hit().
 template <class SP, class LP>
-ART_HD Cand analytic_bound_t(const DevScene& s, SP sph, LP lgt, f3 o, f3 d, float tfar) {
+ART_HD Cand analytic_bound_t(const DevScene& s, SP sph, LP lgt, f3 o, f3 d, f3 rcp, float tfar) {
   Cand best = cand_init(tfar);
   for (int i = 0; i < s.n_spheres; ++i) isect_sphere(o, d, load_sphere(sph, i), (uint32_t)i, best);
-  if (s.has_cornell) isect_cornell(o, d, s, best);
+  if (s.has_cornell) isect_cornell(o, d, rcp, s, best);
   for (int i = 0; i < s.n_lights; ++i)
     if (lgt[i].shape == LIGHT_RECT) isect_quad(o, d, lgt + i, (uint32_t)i, best);
-  isect_bf_mesh(o, d, s, best);
+  isect_bf_mesh(o, d, rcp, s, best);
   return best;
 }
-ART_HD Cand analytic_bound(const DevScene& s, const StageCtx& cx, f3 o, f3 d, float tfar) {
-  if (cx.lds_spheres) return analytic_bound_t(s, cx.lds_spheres, cx.lds_lights, o, d, tfar);      // the kernel's LDS copies (both tables or neither)
-  return analytic_bound_t(s, cx.spheres ? cx.spheres : s.spheres, cx.lights ? cx.lights : s.lights, o, d, tfar);
+// rcp: the ray's reciprocals (ray_rcp), shared with the caller's slab set-up
+ART_HD Cand analytic_bound(const DevScene& s, const StageCtx& cx, f3 o, f3 d, f3 rcp, float tfar) {
+  if (cx.lds_spheres) return analytic_bound_t(s, cx.lds_spheres, cx.lds_lights, o, d, rcp, tfar);      // the kernel's LDS copies (both tables or neither)
+  return analytic_bound_t(s, cx.spheres ? cx.spheres : s.spheres, cx.lights ? cx.lights : s.lights, o, d, rcp, tfar);
 }
 
 ART_HD size_t rec_slot(int mode, int w, bool shadow_ray) { return (mode == REC_BOTH) ? 2 * (size_t)w + (shadow_ray ? 1u : 0u) : (size_t)w; }
@@ -393,20 +394,25 @@ ART_HD TraceRec make_record(const DevScene& s, const DevPaths& qo, size_t hit_in
   TraceRec t;
   const bool word = ((uint32_t)hit_index & kShadowWord) != 0u;
   float* const sh_t_out = cx.hot_layout ? hotf(qo, HF_SHT) : qo.sh_t;
-  if (word && !live) put(sh_t_out, (int)((uint32_t)hit_index & ~kShadowWord), -1.0f);       // (an item without a shadow ray: never read, kept defined)
+  if (word && !live) put_s(sh_t_out, (int)((uint32_t)hit_index & ~kShadowWord), -1.0f);       // (an item without a shadow ray: never read, kept defined)
   t.r0 = Rec4{0.0f, 0.0f, 0.0f, -1.0f}; t.r1 = Rec4{0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, KEY_MISS)}; t.r2 = Rec4{0.0f, 0.0f, 0.0f, -1.0f};
   t.r3 = Rec4{0.0f, __builtin_bit_cast(float, (uint32_t)hit_index), 0.0f, 0.0f};
   ART_PROBE(30);
   if (live) {
     ART_PROBE(31);
-    const Cand best = analytic_bound(s, cx, o, d, tfar);
-    if (word) put(sh_t_out, (int)((uint32_t)hit_index & ~kShadowWord), (best.key != KEY_MISS) ? best.t : -1.0f);
-    else if (cx.hot_layout) put(hotf<DevHit>(qo, HF_HIT), (int)hit_index, DevHit{best.t, best.key, best.u, best.v});
+#ifndef ART_SHARE_RCP
+#define ART_SHARE_RCP 1
+#endif
+    const f3 rcp = ray_rcp(d);                                   // three divisions per ray: the Cornell box, the brute-force mesh's box and the slab set-up below share them
+    const Cand best = analytic_bound(s, cx, o, d, rcp, tfar);
+    if (word) put_s(sh_t_out, (int)((uint32_t)hit_index & ~kShadowWord), (best.key != KEY_MISS) ? best.t : -1.0f);
+    else if (cx.hot_layout) put_s(hotf<DevHit>(qo, HF_HIT), (int)hit_index, DevHit{best.t, best.key, best.u, best.v});
     else if (!(ART_DIAG_SKIP & 8)) qo.hit[hit_index] = DevHit{best.t, best.key, best.u, best.v};
     const bool near_done = (shm >= 0.0f) && (best.key != KEY_MISS) && (best.t <= shm);       // shadow_rule: decided
     if (!near_done && qo.has_bvh) {
       ART_PROBE(32);
-      f3 inv, noi; slab_setup(o, d, inv, noi);
+      f3 inv, noi;
+      if (ART_SHARE_RCP) slab_setup_rcp(o, d, rcp, inv, noi); else slab_setup(o, d, inv, noi);
       const bool far_found = (shm >= 0.0f) && (best.key != KEY_MISS);
       const float bt = far_found ? next_up_pos(shm) : best.t;
       const uint32_t bk = far_found ? KEY_MISS : best.key;
@@ -442,7 +448,11 @@ ART_HD void emit_ray(const DevScene& s, const DevPaths& qo, size_t hit_index, si
       if (!(ART_DIAG_SKIP & 1)) for (int it = 0; it < 4; ++it) {
         const int g = it * cx.stage_count + stage_slot;
         const Rec4 v = stage[(g & 3) * stage_pitch + (g >> 2)];
+#if (ART_NT & 1) && defined(__HIP_DEVICE_COMPILE__)
+        { typedef float f4nt __attribute__((ext_vector_type(4))); __builtin_nontemporal_store(f4nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f4nt*>(&out[g])); }      // experiment: written once, read once by the trace kernel
+#else
         out[g] = v;
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
         if ((g & 3) == 3 && cx.lost != nullptr && __builtin_bit_cast(uint32_t, v.y) != hit0 + (uint32_t)(g >> 2)) atomicAdd(cx.lost, 1ull);
 #endif
@@ -565,7 +575,7 @@ ART_HD void item_classes(const DevScene& s, const DevPaths& qi, const int (&w)[N
 #endif
   for (int k = 0; k < N; ++k) {                                   // step 1: flags and hit keys
     const int wk = on[k] ? w[k] : 0;
-    fl[k] = camera ? (FLAG_ALIVE | FLAG_PREV_SPEC) : at(hotf<const uint32_t>(qi, HF_FLAGS), wk);      // (k_shade_compact only: the record schedule's block)
+    fl[k] = camera ? (FLAG_ALIVE | FLAG_PREV_SPEC) : at(hotf<const uint32_t>(qi, HF_FLAGS), wk);      // (cached: shade_item reads the line again)      // (k_shade_compact only: the record schedule's block)
     key[k] = ld_off(hotf<const uint32_t>(qi, HF_HIT), (uint32_t)wk * 16u + 4u);
   }
   if (!camera) pin_loads(fl);
@@ -636,15 +646,15 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   // pointer loads then drop out of the kernel), -1 = look at the bank
   const bool dense = (dense_mode >= 0) ? (dense_mode != 0) : (qi.fold_dense != 0);
   const bool batch = (dense_mode == 1);                // k_shade_compact: hints exist, the record schedule's blocks exist (DevPaths::hot / cold)
-  const int slot_loaded = batch ? ((camera_mode == 1) ? w : (int)at(hotf<const uint32_t>(qi, HF_SLOT), w)) : item_slot(qi, w);
+  const int slot_loaded = batch ? ((camera_mode == 1) ? w : (int)at_s(hotf<const uint32_t>(qi, HF_SLOT), w)) : item_slot(qi, w);
   const size_t P = (size_t)qi.P;
   const bool camera = (camera_mode >= 0) ? (camera_mode != 0) : (qi.synth0 && qi.slot_id == nullptr);         // bounce 0 of the compacted schedule: raygen stored the hit and nothing else (DevPaths::synth0)
-  uint32_t fl = camera ? (FLAG_ALIVE | FLAG_PREV_SPEC) : at(batch ? hotf<const uint32_t>(qi, HF_FLAGS) : qi.flags, w);
+  uint32_t fl = camera ? (FLAG_ALIVE | FLAG_PREV_SPEC) : at_s(batch ? hotf<const uint32_t>(qi, HF_FLAGS) : qi.flags, w);
   // ---- everything the item holds is read first: ONE batch of independent loads (round 5).  Written as conditional loads the compiler sank
   // each into the branch that uses it and waited for them one by one -- eight memory round trips in a row at the head of every item, at the
   // stage's 80-VGPR cap -- so the loads a hint makes possible are unconditional (an item without a hint reads record 0 / material 0 and
   // ignores them), and on the device an empty asm that names every loaded value pins them all before the first use.
-  DevHit hw = at(batch ? hotf<const DevHit>(qi, HF_HIT) : qi.hit, w);
+  DevHit hw = at_s(batch ? hotf<const DevHit>(qi, HF_HIT) : qi.hit, w);
   // (hint_in may point at a record that says "no hint" (mat < 0): the caller then need not choose between a pointer and nullptr per lane --
   // which forced the record into scratch memory, with a scratch load and an s_waitcnt vmcnt(0) at each of its four uses, round 5)
   const bool hinted = (hint_in != nullptr) && (hint_in->mat >= 0);
@@ -664,8 +674,8 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   const bool may_owe = (bounce > 0) && (f.render_type != PT_STUPID);
   // (hs_t: t of the shadow ray's closest hit, -1 = none: the word sh_t[w] of the record schedule, else from the hit record at [P + w])
   float hs_t = -1.0f, owed_min = 0.0f; f3 owed = mk3(0.0f, 0.0f, 0.0f);
-  auto shadow_t = [&]() { if (batch) return at(hotf<const float>(qi, HF_SHT), w); if (qi.sh_t) return at(qi.sh_t, w); const DevHit h = qi.hit[P + (size_t)w]; return (h.key != KEY_MISS) ? h.t : -1.0f; };
-  if (may_owe || (batch && !camera)) { hs_t = shadow_t(); owed_min = at(batch ? hotf<const float>(qi, HF_SHMIN) : qi.sh_min_t, w); if (!dense) owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
+  auto shadow_t = [&]() { if (batch) return at_s(hotf<const float>(qi, HF_SHT), w); if (qi.sh_t) return at(qi.sh_t, w); const DevHit h = qi.hit[P + (size_t)w]; return (h.key != KEY_MISS) ? h.t : -1.0f; };
+  if (may_owe || (batch && !camera)) { hs_t = shadow_t(); owed_min = at_s(batch ? hotf<const float>(qi, HF_SHMIN) : qi.sh_min_t, w); if (!dense) owed = mk3(qi.cand_r[w], qi.cand_g[w], qi.cand_b[w]); }
   // (the extension ray is kept as six SoA words next to its trace record: reading it back out of the record would pull the whole
   // 128-byte line of the item's two records for 24 useful bytes)
   f3 o, d; float prev_pdf;
@@ -679,9 +689,9 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     } else d = mk3(at(qi.ray_dx, w), at(qi.ray_dy, w), at(qi.ray_dz, w));
   } else {
     if (batch) {
-      o = mk3(at(hotf<const float>(qi, HF_OX), w), at(hotf<const float>(qi, HF_OY), w), at(hotf<const float>(qi, HF_OZ), w));
-      d = mk3(at(hotf<const float>(qi, HF_DX), w), at(hotf<const float>(qi, HF_DY), w), at(hotf<const float>(qi, HF_DZ), w));
-      prev_pdf = at(hotf<const float>(qi, HF_PDF), w);
+      o = mk3(at_s(hotf<const float>(qi, HF_OX), w), at_s(hotf<const float>(qi, HF_OY), w), at_s(hotf<const float>(qi, HF_OZ), w));
+      d = mk3(at_s(hotf<const float>(qi, HF_DX), w), at_s(hotf<const float>(qi, HF_DY), w), at_s(hotf<const float>(qi, HF_DZ), w));
+      prev_pdf = at_s(hotf<const float>(qi, HF_PDF), w);
     } else {
       o = mk3(at(qi.ray_ox, w), at(qi.ray_oy, w), at(qi.ray_oz, w));
       d = mk3(at(qi.ray_dx, w), at(qi.ray_dy, w), at(qi.ray_dz, w));
@@ -839,7 +849,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   if (dense && !(ART_DIAG_SKIP & 16)) {                      // dense stores: consecutive items, consecutive addresses
     const size_t l0 = (size_t)bounce * P;                   // (the level's base is wave-uniform: a scalar add; the item's offset stays 32 bits)
     const int32_t cw = fold_child_word((rec_child == -2 && wo >= 0) ? wo : rec_child, rec_shadowed);
-    if (batch) { put(cold_w(qi, 0, bounce), w, rec_w.x); put(cold_w(qi, 1, bounce), w, rec_w.y); put(cold_w(qi, 2, bounce), w, rec_w.z); put(cold_child(qi, bounce), w, cw); }
+    if (batch) { put_s(cold_w(qi, 0, bounce), w, rec_w.x); put_s(cold_w(qi, 1, bounce), w, rec_w.y); put_s(cold_w(qi, 2, bounce), w, rec_w.z); put_s(cold_child(qi, bounce), w, cw); }
     else { put(qi.w_r + l0, w, rec_w.x); put(qi.w_g + l0, w, rec_w.y); put(qi.w_b + l0, w, rec_w.z); put(qi.child + l0, w, cw); }
   }
   // ---- the output item
@@ -854,16 +864,16 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   ART_PROBE(41);
   const size_t so_i = (size_t)qo.P + (size_t)wo;
   if (batch) {                                           // the record schedule: every word through the output bank's ONE base pointer
-    put(hotf<uint32_t>(qo, HF_SLOT), wo, (uint32_t)slot);
-    put(hotf<uint32_t>(qo, HF_FLAGS), wo, fl);
-    put(hotf<float>(qo, HF_PDF), wo, new_pdf);
+    put_s(hotf<uint32_t>(qo, HF_SLOT), wo, (uint32_t)slot);
+    put_s(hotf<uint32_t>(qo, HF_FLAGS), wo, fl);
+    put_s(hotf<float>(qo, HF_PDF), wo, new_pdf);
     if (shadow) {
-      put(hotf<float>(qo, HF_SHMIN), wo, sh_min);
-      put(cold_e(qi, 0, bounce + 1), wo, cand.x); put(cold_e(qi, 1, bounce + 1), wo, cand.y); put(cold_e(qi, 2, bounce + 1), wo, cand.z);
+      put_s(hotf<float>(qo, HF_SHMIN), wo, sh_min);
+      put_s(cold_e(qi, 0, bounce + 1), wo, cand.x); put_s(cold_e(qi, 1, bounce + 1), wo, cand.y); put_s(cold_e(qi, 2, bounce + 1), wo, cand.z);
     }
     if (alive && !(ART_DIAG_SKIP & 4)) {
-      put(hotf<float>(qo, HF_OX), wo, no.x); put(hotf<float>(qo, HF_OY), wo, no.y); put(hotf<float>(qo, HF_OZ), wo, no.z);
-      put(hotf<float>(qo, HF_DX), wo, nd.x); put(hotf<float>(qo, HF_DY), wo, nd.y); put(hotf<float>(qo, HF_DZ), wo, nd.z);
+      put_s(hotf<float>(qo, HF_OX), wo, no.x); put_s(hotf<float>(qo, HF_OY), wo, no.y); put_s(hotf<float>(qo, HF_OZ), wo, no.z);
+      put_s(hotf<float>(qo, HF_DX), wo, nd.x); put_s(hotf<float>(qo, HF_DY), wo, nd.y); put_s(hotf<float>(qo, HF_DZ), wo, nd.z);
     }
   } else {
   if (qo.slot_id != nullptr) put(const_cast<uint32_t*>(qo.slot_id), wo, (uint32_t)slot);      // compacted banks: the output item's slot
