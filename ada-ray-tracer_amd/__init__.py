@@ -83,6 +83,16 @@ class ArtStats(C.Structure):
                 ("node_phase_iters", C.c_uint64), ("leaf_phase_iters", C.c_uint64), ("wave_iters", C.c_uint64), ("lost_paths", C.c_uint64)]
 
 
+class ArtStageStats(C.Structure):
+    _fields_ = [("shade_ms", C.c_double), ("raygen_ms", C.c_double), ("fold_ms", C.c_double), ("shade_launches", C.c_uint64), ("batches", C.c_uint64),
+                ("items_in", C.c_uint64 * 16), ("items_out", C.c_uint64 * 16)]
+
+
+class ArtReduceInfo(C.Structure):
+    _fields_ = [("devices", C.c_int32), ("rccl_ranks", C.c_int32), ("path", C.c_int32), ("reduces", C.c_int32),
+                ("reduce_ms", C.c_double), ("device_pass_ms", C.c_double * 8)]
+
+
 class ArtHit(C.Structure):
     _fields_ = [("t", C.c_float), ("is_hit", C.c_int32), ("prim_type", C.c_int32), ("prim_index", C.c_int32),
                 ("mat_id", C.c_int32), ("mat", C.c_int32), ("normal", C.c_float * 3), ("u", C.c_float), ("v", C.c_float)]
@@ -99,9 +109,9 @@ class HitCpp(C.Structure):
 
 
 EXPORTED_SYMBOLS = [
-    "art_init", "art_init_devices", "art_device_count", "art_reduce", "art_set_stream", "art_upload_scene", "art_resize", "art_set_shard", "art_render_pass",
+    "art_init", "art_init_devices", "art_device_count", "art_reduce", "art_get_reduce_info", "art_set_stream", "art_upload_scene", "art_resize", "art_set_shard", "art_render_pass",
     "art_debug_hit_pass", "art_bind_accum", "art_accum_device", "art_download", "art_synchronize", "art_trace_rays",
-    "art_export_bvh", "art_get_stats", "art_set_option", "art_last_error", "art_shutdown",
+    "art_export_bvh", "art_get_stats", "art_get_stage_stats", "art_set_option", "art_last_error", "art_shutdown",
     "gcore_init_and_clear", "gcore_destroy", "gcore_add_mesh_3f", "gcore_instance_meshes", "gcore_commit_scene",
     "gcore_closest_hit", "gcore_closest_hit_n", "gcore_set_two_level", "gcore_set_single_ray_on_gpu",
 ]
@@ -140,6 +150,8 @@ def load_library():
     L.art_trace_rays.argtypes = [f32p, f32p, f32p, C.c_int64, C.POINTER(ArtHit), C.c_int32, C.POINTER(ArtStats)]
     L.art_export_bvh.argtypes = [f32p, C.c_int64, f32p, C.c_int64, C.POINTER(ArtBvhInfo)]
     L.art_get_stats.argtypes = [C.POINTER(ArtStats)]
+    L.art_get_reduce_info.argtypes = [C.POINTER(ArtReduceInfo)]
+    L.art_get_stage_stats.argtypes = [C.POINTER(ArtStageStats)]
     L.art_set_option.argtypes = [C.c_char_p, C.c_int64]
     L.gcore_add_mesh_3f.argtypes = [f32p, C.c_int, i32p, C.c_int]
     L.gcore_add_mesh_3f.restype = C.c_int
@@ -297,6 +309,18 @@ class Backend:
 
     def synchronize(self):
         _check(self.lib.art_synchronize())
+
+    def stage_stats(self):
+        """the wavefront stages around the trace kernel: GPU ms per kind of kernel, items read / kept per bounce (device 0, cumulative)"""
+        st = ArtStageStats()
+        _check(self.lib.art_get_stage_stats(C.byref(st)))
+        return st
+
+    def reduce_info(self):
+        """what the multi-device path did: ranks of the RCCL communicator, GPU time of the reduces, GPU time of every device's passes"""
+        ri = ArtReduceInfo()
+        _check(self.lib.art_get_reduce_info(C.byref(ri)))
+        return ri
 
     def trace_rays(self, origins, dirs, tfar=None, kernel=TRACE_COOP, want_stats=False):
         o = np.ascontiguousarray(origins, np.float32); d = np.ascontiguousarray(dirs, np.float32)

@@ -32,6 +32,13 @@ Ctx* g_cur = &g_devs[0];
 std::mutex g_mu;
 static ncclComm_t g_comms[kMaxDevices];
 static bool g_comms_ready = false;     // distinct GPUs: the framebuffer reduce goes through RCCL
+// events around every reduce on device 0's stream (art_get_reduce_info: the reduce's GPU time is part of the evidence of a multi-GPU run)
+static std::vector<hipEvent_t> g_reduce_events;
+static double g_reduce_ms = 0.0; static int g_reduces = 0, g_reduce_path = 0;
+static void reset_reduce_info() {
+  for (hipEvent_t e : g_reduce_events) (void)hipEventDestroy(e);
+  g_reduce_events.clear(); g_reduce_ms = 0.0; g_reduces = 0; g_reduce_path = 0;
+}
 static bool g_same_gpu = false;        // rehearsal: several contexts on ONE physical GPU, the reduce is a local sum (no collective possible)
 static const bool g_debug_live = getenv("ART_DEBUG_LIVE") != nullptr;   // development aid: work-set sizes per stage on stderr (syncs the stream); read once
 static thread_local std::string t_err;
@@ -183,6 +190,7 @@ int resize(int w, int h) {
   if (w <= 0 || h <= 0 || (int64_t)w * h > (1ll << 30)) return fail("art_resize: bad size");
   Dev0Guard guard;
   for (int k = 0; k < g_ndev; ++k) { if (use_dev(k) || resize_one(w, h)) return 1; }
+  if (g_devs[0].device_ready && !use_dev(0)) reset_reduce_info();
   return 0;
 }
 static int resize_one(int w, int h) {
@@ -195,6 +203,8 @@ static int resize_one(int w, int h) {
   HIP_TRY(hipMemsetAsync(acc, 0, n * 12, c.stream));
   c.spp = 0;
   c.stats = ArtStats();
+  c.stage = ArtStageStats();
+  if (c.d_items) HIP_TRY(hipMemsetAsync(c.d_items, 0, 32 * sizeof(unsigned long long), c.stream));
   c.camera_rays = 0;
   HIP_TRY(hipMemsetAsync(c.d_counters, 0, 16 * sizeof(unsigned long long), c.stream));
   return build_shard();
@@ -315,6 +325,21 @@ static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
 // one trace launch, bracketed by HIP events on the launch stream.  records != nullptr: the bank's rays are already trace records in item
 // order (DevPaths::rec, written by the stage that emitted them): no k_analytic pass, the queue is the record array itself.
 struct RecordQueue { int fixed; const int* items; int mul; };
+// event pairs around groups of launches on the launch stream: ev_begin(kind) ... ev_end()
+static int ev_begin(int kind) {
+  Ctx& c = g_ctx;
+  if (c.ev_pool.size() < c.ev_used + 2) {
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    c.ev_pool.push_back(e0); c.ev_pool.push_back(e1);
+  }
+  if (c.ev_kind.size() < c.ev_pool.size() / 2) c.ev_kind.resize(c.ev_pool.size() / 2);
+  c.ev_kind[c.ev_used / 2] = (uint8_t)kind;
+  HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used], c.stream));
+  return 0;
+}
+static int ev_end() { Ctx& c = g_ctx; HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used + 1], c.stream)); c.ev_used += 2; return 0; }
+
 static int trace(const DevPaths& q, int n_rays, bool timed = true, const int* item_count = nullptr, const RecordQueue* records = nullptr) {
   Ctx& c = g_ctx;
   const bool coop = (c.trace_kernel == TRACE_COOP);
@@ -329,18 +354,13 @@ static int trace(const DevPaths& q, int n_rays, bool timed = true, const int* it
   if (coop) {
     HIP_TRY(hipMemsetAsync(c.d_cursor, 0, kCursorInts * sizeof(int), c.stream));
   }
-  if (timed && c.ev_pool.size() < c.ev_used + 2) {
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    c.ev_pool.push_back(e0); c.ev_pool.push_back(e1);
-  }
   if (coop && !records) launch_analytic(c.stream, c.scene, a, c.count_tests);   // outside the trace-kernel event pair
-  if (timed) HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used], c.stream));
+  if (timed && ev_begin(0)) return 1;
   // a workgroup keeps 4 waves x (64 / width) rays in flight: a handful of rays (the legacy per-ray seam) gets a handful of workgroups
   const int rays_per_block = 4 * (64 / std::max(1, c.scene.node_width));
   const int grid = (int)std::min<int64_t>(coop_grid(), ((int64_t)n_rays + rays_per_block - 1) / rays_per_block);
   launch_trace(c.stream, c.d_scene, a, c.trace_kernel, c.count_tests, std::max(1, grid));
-  if (timed) { HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used + 1], c.stream)); c.ev_used += 2; }
+  if (timed && ev_end()) return 1;
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -351,9 +371,18 @@ static int collect_timing() {
   for (size_t i = 0; i + 1 < c.ev_used; i += 2) {
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, c.ev_pool[i], c.ev_pool[i + 1]));
-    c.stats.trace_ms += ms; c.stats.trace_launches += 1;
+    const int kind = (i / 2 < c.ev_kind.size()) ? c.ev_kind[i / 2] : 0;
+    if (kind == 0) { c.stats.trace_ms += ms; c.stats.trace_launches += 1; }
+    else if (kind == 1) { c.stage.shade_ms += ms; c.stage.shade_launches += 1; }
+    else if (kind == 2) c.stage.raygen_ms += ms;
+    else c.stage.fold_ms += ms;
   }
   c.ev_used = 0;
+  if (c.d_items) {
+    unsigned long long it[32];
+    HIP_TRY(hipMemcpy(it, c.d_items, sizeof it, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 16; ++k) { c.stage.items_in[k] = it[k]; c.stage.items_out[k] = it[16 + k]; }
+  }
   unsigned long long cnt[16];
   HIP_TRY(hipMemcpy(cnt, c.d_counters, sizeof cnt, hipMemcpyDeviceToHost));
   c.stats.node_phase_iters = cnt[8]; c.stats.leaf_phase_iters = cnt[9]; c.stats.wave_iters = cnt[10];
@@ -464,7 +493,10 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
           bank[0].rec_mode = REC_EXT;
           DevPaths q = bank[0];                            // identity layout for raygen
           q.slot_id = nullptr;
+          if (!c.d_items) { HIP_TRY(hipMalloc(&c.d_items, 32 * sizeof(unsigned long long))); HIP_TRY(hipMemsetAsync(c.d_items, 0, 32 * sizeof(unsigned long long), c.stream)); }
+          if (ev_begin(2)) return 1;
           launch_raygen(c.stream, F, c.scene, q);
+          if (ev_end()) return 1;
           launch_bump(c.stream, c.d_counters, rays_b, (unsigned long long)q.P);
           { const RecordQueue rq = {q.P, nullptr, 1}; if (trace(q, q.P, true, nullptr, &rq)) return 1; }
           for (int b = 0; b < p->max_depth; ++b) {
@@ -474,8 +506,10 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
             bank[out].rec_mode = (p->render_type == ART_PT_STUPID) ? REC_EXT : (last ? REC_SHADOW : REC_BOTH);
             int* const n_in = c.d_live + 32 * b; int* const n_out = c.d_live + 32 * (b + 1);      // per level: the fold walks them again
             HIP_TRY(hipMemsetAsync(n_out, 0, 2 * sizeof(int), c.stream));         // n_out[1]: the items this stage defers to its heavy-material kernel
+            if (ev_begin(1)) return 1;
             launch_shade_compact(c.stream, F, c.scene, qi, bank[out], b, b == 0 ? nullptr : n_in, n_out,
                                  const_cast<uint32_t*>(bank[out].slot_id), c.d_counters + 15, c.d_counters, rays_b, c.shade_split ? heavy : nullptr, n_out + 1);
+            if (ev_end()) return 1;
             if (g_debug_live) {
               int n = -1; unsigned long long r0 = 0;
               (void)hipStreamSynchronize(c.stream); (void)hipMemcpy(&n, n_out, 4, hipMemcpyDeviceToHost); (void)hipMemcpy(&r0, c.d_counters, 8, hipMemcpyDeviceToHost);
@@ -487,10 +521,14 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
             }
           }
           const int last = p->max_depth & 1;              // the bank the last stage wrote
+          if (ev_begin(3)) return 1;
           launch_resolve_last(c.stream, bank[last], c.d_live + 32 * p->max_depth, p->max_depth - 1);
           if (bank[last].fold_dense) launch_fold_levels(c.stream, F, bank[last], p->max_depth, c.d_live);
           else launch_fold(c.stream, F, bank[last]);
           launch_accumulate(c.stream, F, q, sn, accum_ptr());
+          if (ev_end()) return 1;
+          launch_acc_items(c.stream, c.d_live, p->max_depth, q.P, c.d_items);
+          c.stage.batches += 1;
         } else {                                          // one-ray-per-lane cross-check kernel: the plain schedule over all slots, in place
           DevPaths q = bank[0];
           q.slot_id = nullptr;
@@ -534,7 +572,14 @@ static int synchronize_one() {
     (void)hipEventDestroy(c.pass_events[i]); (void)hipEventDestroy(c.pass_events[i + 1]);
   }
   c.pass_events.clear();
-  return collect_timing();
+  const uint64_t lost_before = c.stats.lost_paths;
+  if (collect_timing()) return 1;
+  // a lost path is a wrong picture, not a statistic -- a stage that found a path without an output item, a ray its bank has no
+  // record for, a material its instantiation was not compiled for, or a staged trace record that did not name the hit slot its position
+  // implies (art_shade.h emit_ray) fails the call that waits for the render
+  if (c.stats.lost_paths != lost_before)
+    return fail("render self-check: " + std::to_string(c.stats.lost_paths - lost_before) + " path(s) lost by the wavefront stages (ArtStats::lost_paths); the image is not valid");
+  return 0;
 }
 
 // every pixel has one owner, so the other devices hold exact zeros there and the sum over devices is exact: ONE
@@ -548,6 +593,12 @@ static int reduce_accum(const float** out) {
   const size_t count = (size_t)c0.width * c0.height * 3;
   Dev0Guard guard;
   if (use_dev(0) || ensure(c0.b_reduced, count * 4)) return 1;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
+  g_reduce_events.push_back(ev0); g_reduce_events.push_back(ev1);
+  HIP_TRY(hipEventRecord(ev0, c0.stream));
+  g_reduces += 1; g_reduce_path = g_comms_ready ? 1 : 2;
+  struct Stop { hipEvent_t e; hipStream_t s; ~Stop() { (void)hipEventRecord(e, s); } } stop{ev1, c0.stream};       // recorded on every way out
   if (g_comms_ready) {
     if (ncclGroupStart() != ncclSuccess) return fail("ncclGroupStart failed");
     for (int k = 0; k < g_ndev; ++k) {
@@ -715,6 +766,7 @@ int trace_rays(const float* origins, const float* dirs, const float* tfar, int64
 }
 
 void shutdown() {
+  if (g_devs[0].device_ready && !use_dev(0)) reset_reduce_info();
   if (g_comms_ready) { for (int k = 0; k < g_ndev; ++k) (void)ncclCommDestroy(g_comms[k]); g_comms_ready = false; }
   g_same_gpu = false;
   for (int k = g_ndev - 1; k >= 0; --k) {
@@ -731,6 +783,7 @@ void shutdown() {
     if (c.d_scene) (void)hipFree(c.d_scene);
     if (c.d_counters) (void)hipFree(c.d_counters);
     if (c.d_live) (void)hipFree(c.d_live);
+    if (c.d_items) (void)hipFree(c.d_items);
     for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : c.pass_events) (void)hipEventDestroy(e);
     c.b_reduced.release();
@@ -893,6 +946,37 @@ int fetch_host_bvh(std::vector<float>& nodes, std::vector<float>& tris, int& wid
 }
 }  // namespace art
 extern "C" {
+
+int art_get_reduce_info(ArtReduceInfo* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!out) return fail("null ArtReduceInfo");
+  if (synchronize()) return 1;
+  std::memset(out, 0, sizeof *out);
+  out->devices = g_ndev;
+  if (g_comms_ready) { int n = 0; if (ncclCommCount(g_comms[0], &n) != ncclSuccess) return fail("ncclCommCount failed"); out->rccl_ranks = n; }
+  {
+    Dev0Guard guard;
+    if (use_dev(0)) return 1;
+    for (size_t i = 0; i + 1 < g_reduce_events.size(); i += 2) {
+      float ms = 0.0f;
+      HIP_TRY(hipEventElapsedTime(&ms, g_reduce_events[i], g_reduce_events[i + 1]));
+      g_reduce_ms += ms;
+      (void)hipEventDestroy(g_reduce_events[i]); (void)hipEventDestroy(g_reduce_events[i + 1]);
+    }
+    g_reduce_events.clear();
+  }
+  out->path = g_reduce_path; out->reduces = g_reduces; out->reduce_ms = g_reduce_ms;
+  for (int k = 0; k < g_ndev && k < 8; ++k) out->device_pass_ms[k] = g_devs[k].stats.pass_ms;
+  return 0;
+}
+
+int art_get_stage_stats(ArtStageStats* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!out) return fail("null ArtStageStats");
+  if (synchronize()) return 1;
+  *out = g_devs[0].stage;
+  return 0;
+}
 
 int art_get_stats(ArtStats* out) {
   std::lock_guard<std::mutex> lk(g_mu);

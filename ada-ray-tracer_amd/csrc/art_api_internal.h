@@ -54,6 +54,9 @@ struct Ctx {
   bool shade_split = false;    // k_shade_compact as one instantiation per register class (light materials / deferred heavy ones); false: the round-4 kernel with every material (A/B)
   // timing
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+  std::vector<uint8_t> ev_kind;                // per event pair: 0 trace kernel, 1 shade stage, 2 raygen, 3 fold group (art_get_stage_stats)
+  ArtStageStats stage = ArtStageStats();
+  unsigned long long* d_items = nullptr;       // cumulative items_in[16] | items_out[16] (k_acc_items at the end of every batch)
   std::vector<hipEvent_t> pass_events;
   ArtStats stats = ArtStats();
 };

@@ -48,6 +48,8 @@ constexpr int kTraceRecBytes = 64;
 
 void launch_raygen(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q);
 void launch_bump(hipStream_t st, unsigned long long* a, unsigned long long* b, unsigned long long n);    // *a += n; if (b) *b += n
+// end of a batch: items[b] += input items of bounce b, items[16 + b] += the items it kept (live[32 (b + 1)]); bounce 0 reads the P camera paths
+void launch_acc_items(hipStream_t st, const int* live, int depth, int P, unsigned long long* items);
 void launch_shade(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Q, int bounce);
 void launch_finish(hipStream_t st, const DevFrame& F, const DevPaths& Q, int last_level);
 // compacted work sets (k_shade_compact): shade the items of Qi, write the survivors densely to Qo (+ their slot ids); n_in nullptr: all Qi.P items

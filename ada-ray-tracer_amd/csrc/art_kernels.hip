@@ -274,6 +274,8 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         }
         // the chunk's records (16 x 64 B = one load per lane, per 16 records) on their way into the cache before the first group asks for its own
         // (the value is only "used" after the refill's own loads below, so that nothing waits for it alone)
+        // (round 5: fetching the records with non-temporal loads -- they are read once -- made the launch 2 % (C4) to 9 % (C5) SLOWER,
+        // profiles/r5_shade/ab11_trace_nt_loads.txt: the prefetch below relies on the lines staying in the cache until the refill reads them)
         for (int c16 = 0; c16 < A.chunk; c16 += 16) pf_keep += reinterpret_cast<const float*>(A.rec)[((size_t)(chunk_pos + c16) * 4 + lane) * 4];
       }
       const int avail = chunk_end - chunk_pos;
@@ -1037,6 +1039,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(set_waves(S
 }
 
 __global__ void k_bump(unsigned long long* a, unsigned long long* b, unsigned long long n) { *a += n; if (b) *b += n; }
+__global__ void k_acc_items(const int* live, int depth, int P, unsigned long long* items) {
+  unsigned long long in = (unsigned long long)P;
+  for (int b = 0; b < depth && b < 16; ++b) { const unsigned long long out = (unsigned long long)live[32 * (b + 1)]; items[b] += in; items[16 + b] += out; in = out; }
+}
 
 // the shadow tests still owed after the last trace, over the last work set; then the fold over all slots
 __global__ __launch_bounds__(256) void k_resolve_last(const DevPaths Q, const int* __restrict__ n_ptr, int last_level) {
@@ -1178,6 +1184,7 @@ void launch_shade_compact(hipStream_t st, const DevFrame& F, const DevScene& S, 
   hipLaunchKernelGGL(k_probe_on, dim3(1), dim3(1), 0, st, 0);
 #endif
 }
+void launch_acc_items(hipStream_t st, const int* live, int depth, int P, unsigned long long* items) { hipLaunchKernelGGL(k_acc_items, dim3(1), dim3(1), 0, st, live, depth, P, items); }
 void launch_bump(hipStream_t st, unsigned long long* a, unsigned long long* b, unsigned long long n) { hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, st, a, b, n); }
 void launch_resolve_last(hipStream_t st, const DevPaths& Q, const int* n, int last_level) {
   hipLaunchKernelGGL(k_resolve_last, dim3(blocks_for(Q.P)), dim3(256), 0, st, Q, n, last_level);

@@ -43,7 +43,16 @@ import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 GATHER_CEILING_GBPS = 8000.0   # MI355X_MICROARCH.md "Indexed rows": random rows out of the Infinity Cache, 8.6 TB/s (38 MB table) .. 7.4-7.9 (151 MB)
-PROFILE_TAG = "r4_final"
+PROFILE_TAG = "r5_final"
+
+# Algorithmic bytes of the wavefront stages per work item (the layout of csrc/art_scene.h HotField).  in: the
+# item's hit record 16 + flags, shadow word, shadow epsilon, previous pdf, slot 20 + extension ray 24 (bounce 0: the hit record alone, the
+# rest is recomputed) + the 64-byte shading record of the triangle it hit; fold record 16 per input item.  out, per kept item: two 64-byte
+# trace records, hit record 16, shadow word 4, ray 24, flags / pdf / epsilon / slot 16, explicit colour 12.
+STAGE_IN_B, STAGE_IN_B0, STAGE_GATHER_B, STAGE_FOLDREC_B, STAGE_OUT_B = 60.0, 16.0, 64.0, 16.0, 200.0
+FOLD_B = 56.0            # k_fold_level per item of a level: w 12 + child 4 + e 12 + the level below 12 + its child word 4, writes 12
+RAYGEN_B = 80.0          # per camera path: trace record 64 + hit record 16
+ACCUM_B = 12.0           # k_accumulate reads the per-sample radiance
 
 
 def build_scene(art, args):
@@ -238,6 +247,9 @@ def main():
 
     sync()
     s0 = be.stats()
+    g0 = be.stage_stats()
+    r0 = be.reduce_info() if in_library else None
+    reduce_ms_torch = None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if args.host_buffers:
@@ -247,18 +259,25 @@ def main():
             spp = be.render_pass_device(prm, spp)
     if use_dist:
         be.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         dist.reduce(accum_t, dst=0, op=dist.ReduceOp.SUM)
+        e1.record()
         torch.cuda.synchronize()
+        reduce_ms_torch = float(e0.elapsed_time(e1))
     elif in_library:
         be.reduce()                       # the RCCL reduce of the float3 framebuffer to device 0, inside the timed region
     be.synchronize()
     elapsed = time.perf_counter() - t0
     s1 = be.stats()
+    g1 = be.stage_stats()
+    r1 = be.reduce_info() if in_library else None
     rays = s1.rays - s0.rays
     samples = s1.samples - s0.samples
     trace_ms = s1.trace_ms - s0.trace_ms
     launches = s1.trace_launches - s0.trace_launches
     if use_dist:
+        elapsed_local = elapsed
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -266,9 +285,21 @@ def main():
         dist.all_reduce(rs, op=dist.ReduceOp.SUM)
         total_rays, total_samples = float(rs[0].item()), float(rs[1].item())
         rays_dev0 = rays
+        # every rank's own wall time of the timed steps, and the ranks the collective really ran on (the line must not be taken on trust)
+        per_rank = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(per_rank, torch.tensor([elapsed_local], dtype=torch.float64, device="cuda"))
+        multi = {"mode": "one process per GPU (torch.distributed)", "backend": dist.get_backend(), "rccl_ranks": int(dist.get_world_size()),
+                 "reduce_ms": round(reduce_ms_torch, 3), "reduce_note": "torch.cuda events around dist.reduce on rank 0 (one reduce per run, inside the timed region)",
+                 "per_device_ms_per_step": [round(float(t.item()) * 1e3 / max(1, args.steps), 3) for t in per_rank]}
     else:
         total_rays, total_samples = float(rays), float(samples)
         rays_dev0 = rays / n_gpus if in_library else rays          # stats(): trace_ms is device 0's, rays the whole job's
+        multi = None
+        if in_library:
+            multi = {"mode": "one process (art_init_devices)", "backend": "rccl" if r1.rccl_ranks > 0 else "local adds (contexts on one GPU)",
+                     "rccl_ranks": int(r1.rccl_ranks), "devices": int(r1.devices), "reduces": int(r1.reduces - r0.reduces),
+                     "reduce_ms": round(r1.reduce_ms - r0.reduce_ms, 3), "reduce_note": "HIP events around the grouped ncclReduce on device 0's stream (inside the timed region)",
+                     "per_device_ms_per_step": [round((r1.device_pass_ms[k] - r0.device_pass_ms[k]) / max(1, args.steps), 3) for k in range(int(r1.devices))]}
 
     if rank == 0:
         # ---- roofline of the dominant kernel (trace): algorithmic bytes / HIP-event time, device 0's launches
@@ -328,6 +359,33 @@ def main():
                         "whole_over_trace_only": round((trace_ms * 1e-3) / elapsed, 4) if (elapsed > 0 and not in_library) else None,
                         "avg_launch_ms": round(trace_ms / max(1, launches), 4), "launches": int(launches),
                         "trace_Mrays_per_s": round(rays_dev0 / (trace_ms * 1e-3) / 1e6, 2) if trace_ms > 0 else None}
+        # ---- the stages around the trace kernel and the whole-job roofline (device 0 / this rank; cumulative counters of the timed steps)
+        stages = None
+        whole = None
+        if args.kernel == "coop" and g1.batches > g0.batches:
+            nb = g1.batches - g0.batches
+            ins = [g1.items_in[k] - g0.items_in[k] for k in range(16)]; outs = [g1.items_out[k] - g0.items_out[k] for k in range(16)]
+            depth = max(k + 1 for k in range(16) if ins[k] > 0)
+            shade_b = sum(ins[k] * ((STAGE_IN_B0 if k == 0 else STAGE_IN_B) + STAGE_GATHER_B + STAGE_FOLDREC_B) + outs[k] * STAGE_OUT_B for k in range(depth))
+            fold_b = sum(ins[k] * FOLD_B for k in range(depth)) + ins[0] * ACCUM_B
+            raygen_b = ins[0] * RAYGEN_B
+            shade_ms, fold_ms, raygen_ms = g1.shade_ms - g0.shade_ms, g1.fold_ms - g0.fold_ms, g1.raygen_ms - g0.raygen_ms
+            def leg(b, ms):
+                return {"ms_per_batch": round(ms / nb, 3), "algorithmic_GB_per_batch": round(b / nb / 1e9, 3), "achieved_GBps": round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                        "frac_of_hbm_peak": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ms > 0 else None}
+            stages = {"batches": int(nb), "items_in_per_bounce": [int(v // nb) for v in ins[:depth]], "items_kept_per_bounce": [int(v // nb) for v in outs[:depth]],
+                      "bytes_per_item": {"in": STAGE_IN_B, "in_bounce0": STAGE_IN_B0, "shading_record_gather": STAGE_GATHER_B, "fold_record": STAGE_FOLDREC_B, "out_per_kept_item": STAGE_OUT_B},
+                      "shade": leg(shade_b, shade_ms), "fold_accumulate": leg(fold_b, fold_ms), "raygen": leg(raygen_b, raygen_ms),
+                      "note": "GPU ms: HIP events on the launch stream around every launch of the kind; bytes: algorithmic (what the layout makes a stage read and write), "
+                              "not counters -- profiles/%s holds the counter passes (FETCH_SIZE x the factor calibrated per access shape, profiles/r5_calib)" % PROFILE_TAG}
+            if roofline is not None and elapsed > 0:
+                trace_b = rays_dev0 * roofline["bytes_per_ray"]
+                total_b = trace_b + shade_b + fold_b + raygen_b
+                whole = {"algorithmic_GB_per_step": round(total_b / max(1, args.steps) / 1e9, 2), "achieved_GBps": round(total_b / elapsed / 1e9, 1),
+                         "frac": round(total_b / elapsed / 1e9 / HBM_PEAK_GBPS, 4), "peak": HBM_PEAK_GBPS,
+                         "shares_of_gpu_time": {"trace": round(trace_ms * 1e-3 / elapsed, 4), "shade": round(shade_ms * 1e-3 / elapsed, 4),
+                                                "fold_accumulate": round(fold_ms * 1e-3 / elapsed, 4), "raygen": round(raygen_ms * 1e-3 / elapsed, 4)},
+                         "note": "every kernel's algorithmic bytes of the timed steps / the driver-visible wall time / HBM peak"}
         cpu = None
         if not args.no_cpu and n_gpus == 1:          # timed on rank 0 at N = 1 only
             cpu = cpu_baseline(art, sd, args, be)
@@ -350,7 +408,7 @@ def main():
                        "scene_upload_s": round(t_upload, 3),
                        # what a caller waits for: scene upload incl. the BVH build (outside the timed region) + the 256-spp render at the measured rate
                        "end_to_end_s": round(t_upload + render_256_s, 3), "render_256spp_s": round(render_256_s, 3), "fingerprint": workload_fingerprint(args, W, H, info, args.opt)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "whole_job_roofline": whole, "stages": stages, "multi_gpu": multi, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if use_dist:

@@ -138,6 +138,20 @@ int  art_init(int device_ordinal);                       /* -1: keep the current
 int  art_init_devices(int32_t n, const int32_t* ordinals);
 int32_t art_device_count(void);
 int  art_reduce(void);                                   /* enqueue the framebuffer reduce now (no-op with one device) */
+/* What the multi-device path really did (round 5: a bench line has to show how many ranks RCCL saw, not be taken on trust).
+ * Filled after art_synchronize: rccl_ranks = ncclCommCount of the communicator the reduces ran on (0: no communicator -- one device
+ * without ART_FORCE_RCCL, or n contexts on one GPU, whose sum is a chain of local adds); reduce_ms = GPU time of the reduces on device
+ * 0's stream (HIP events around the grouped ncclReduce / the adds), cumulative since art_resize; device_pass_ms[k] = GPU time of
+ * device k's render passes (HIP events on its stream), cumulative. */
+typedef struct ArtReduceInfo {
+  int32_t devices;               /* contexts of this process (art_init_devices n) */
+  int32_t rccl_ranks;            /* ranks of the RCCL communicator, 0 = none */
+  int32_t path;                  /* 0 nothing to reduce, 1 grouped ncclReduce, 2 local adds (contexts on one GPU) */
+  int32_t reduces;               /* reduces enqueued since art_resize */
+  double  reduce_ms;             /* cumulative */
+  double  device_pass_ms[8];     /* per device, cumulative */
+} ArtReduceInfo;
+int  art_get_reduce_info(ArtReduceInfo* out);
 int  art_set_stream(void* hip_stream);                   /* hipStream_t; NULL = default stream */
 int  art_upload_scene(const ArtSceneDesc* scene);        /* Scene.Init: flatten + BVH build + copy to HBM */
 int  art_resize(int32_t width, int32_t height);          /* Resize_Viewport (ray_tracer.adb:297-320): zero accum, spp := 0 */
@@ -165,6 +179,16 @@ int  art_trace_rays(const float* origins, const float* dirs, const float* tfar, 
 
 int  art_export_bvh(float* nodes, int64_t node_floats_cap, float* tris, int64_t tri_floats_cap, ArtBvhInfo* info);
 int  art_get_stats(ArtStats* out);
+/* The wavefront stages around the trace kernel (device 0, cumulative since art_resize; cooperative schedule): GPU time per kind of
+ * kernel (HIP events on the launch stream, like ArtStats::trace_ms) and the work items every bounce read and kept -- what bench.py's
+ * `stages` object and its whole-job roofline are made of.  items_in[b] / items_out[b]: input items of bounce b (b = 0: the camera paths)
+ * and the items it wrote for bounce b + 1. */
+typedef struct ArtStageStats {
+  double   shade_ms, raygen_ms, fold_ms;    /* k_shade_compact (all instantiations) | k_raygen | k_resolve_last + k_fold_level + k_accumulate */
+  uint64_t shade_launches, batches;
+  uint64_t items_in[16], items_out[16];
+} ArtStageStats;
+int  art_get_stage_stats(ArtStageStats* out);
 /* Tuning / test options (defaults in brackets):  "trace_kernel" [0] 0 cooperative, 1 one ray per lane;  "batch_paths" [128M];
  * "blocks_per_cu" [occupancy];  "count_tests" [0];  "node_min" [4];  "refill_min" [2];  "ray_chunk" [48];  "queue_segments" [8];  "shadow_anyhit" [1];
  * "lds_stack_cap" [0 = automatic];  BVH build (take effect at the next art_upload_scene): "bvh_width" [4] lanes per ray = children

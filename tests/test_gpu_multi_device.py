@@ -70,20 +70,28 @@ art = ge.load_package()
 from ada_ray_tracer_amd import scenes
 sd = scenes.synthetic_scene(2000, 3)
 p = art.Backend.pass_params(art.PT_MIS, True, 8, 1, seed=9)
-out = []
+out = []; info = []
 for force in ("0", "1"):
     os.environ["ART_FORCE_RCCL"] = force
     be = art.Backend(devices=[0])
     be.upload_scene(sd); be.resize(64, 48)
     accum, screen, spp = be.render_pass(p, 0, True, True)
     be.reduce(); be.synchronize()
+    ri = be.reduce_info()
+    info.append({"devices": ri.devices, "rccl_ranks": ri.rccl_ranks, "path": ri.path, "reduces_at_least_one": ri.reduces >= 1,
+                 "reduce_ms_positive": ri.reduce_ms > 0.0, "device0_pass_ms_positive": ri.device_pass_ms[0] > 0.0})
     out.append((accum.copy(), screen.copy()))
     be.shutdown()
-print(json.dumps({"same": bool(np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)) and np.array_equal(out[0][1], out[1][1])), "nonzero": bool(out[1][0].any())}))
+print(json.dumps({"same": bool(np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)) and np.array_equal(out[0][1], out[1][1])), "nonzero": bool(out[1][0].any()), "info": info}))
 '''
     r = subprocess.run([sys.executable, "-c", script, art.ROOT], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    assert json.loads(r.stdout.strip().splitlines()[-1]) == {"same": True, "nonzero": True}
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["same"] and got["nonzero"]
+    # art_get_reduce_info: without the communicator nothing is reduced (one device); with it the reduce ran on a 1-rank RCCL communicator,
+    # took GPU time, and the device's passes were timed -- the fields bench.py --gpus N puts on its line (multi_gpu)
+    assert got["info"][0] == {"devices": 1, "rccl_ranks": 0, "path": 0, "reduces_at_least_one": False, "reduce_ms_positive": False, "device0_pass_ms_positive": True}
+    assert got["info"][1] == {"devices": 1, "rccl_ranks": 1, "path": 1, "reduces_at_least_one": True, "reduce_ms_positive": True, "device0_pass_ms_positive": True}
 
 
 def test_bench_under_torchrun_with_one_rank(art):
@@ -96,3 +104,6 @@ def test_bench_under_torchrun_with_one_rank(art):
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["metric"] == "Mrays/s" and line["value"] > 0 and line["n_gpus"] == 1
+    m = line["multi_gpu"]       # the run shows for itself which collective it used, on how many ranks, and what it cost
+    assert m["backend"] == "nccl" and m["rccl_ranks"] == 1 and m["reduce_ms"] >= 0.0 and len(m["per_device_ms_per_step"]) == 1 and m["per_device_ms_per_step"][0] > 0
+    assert line["stages"]["batches"] >= 1 and line["stages"]["shade"]["ms_per_batch"] > 0
