@@ -7,7 +7,7 @@
 #pragma once
 #include "art_scene.h"
 
-// Diagnostic builds only (-DART_LANE_PROBE, profiles/r4_probe.sh): ART_PROBE(k) adds, for every wave passing the point, its number of
+// Diagnostic builds only (-DART_LANE_PROBE; build line and reader: profiles/lane_probe.py): ART_PROBE(k) adds, for every wave passing the point, its number of
 // enabled lanes to g_lane_probe[2k] and 1 to g_lane_probe[2k + 1] -- where a stage loses its lanes (round 4: k_shade_compact ran at 31 of
 // 64 lanes per VALU instruction).  Expands to nothing in the product build.
 #if defined(ART_TIME_PROBE) && !defined(ART_LANE_PROBE)

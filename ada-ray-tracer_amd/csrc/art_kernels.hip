@@ -698,13 +698,14 @@ __global__ __launch_bounds__(256) void k_raygen(const DevFrame F, const DevScene
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool staged = (Q.rec != nullptr) && Q.has_bvh;
   if (staged) { cx.stage = s_stage[wave]; cx.stage_pitch = kPitch; cx.stage_item = lane; }
+  cx.hot_layout = (Q.hot != nullptr);                    // record schedule: the hit record goes out through the bank's block, as a streaming store
   if (slot < Q.P) raygen_slot(F, S, Q, slot, cx);
   if (staged) {
     wave_lds_sync();
     const int first = slot - lane;
     const int n_pieces = 4 * max(0, min(64, Q.P - first));
     Rec4* out = Q.rec + 4 * (size_t)first;
-    for (int pc = lane; pc < n_pieces; pc += 64) out[pc] = s_stage[wave][(pc & 3) * kPitch + (pc >> 2)];
+    for (int pc = lane; pc < n_pieces; pc += 64) put_s(out, pc, s_stage[wave][(pc & 3) * kPitch + (pc >> 2)]);      // (read once, by the trace kernel: non-temporal)
   }
 }
 
@@ -731,8 +732,12 @@ __global__ __launch_bounds__(256) void k_shade(const DevFrame F, const DevScene 
 //      (four binary64 pow) for three lanes on the back wall (profiles/r4_shade/lane_probe_*.txt).
 // The survivors of a wave's round are consecutive output items: their trace records are one contiguous piece of the output bank, the
 // extension rays first, then the shadow rays (REC_BOTH).  The wave builds the records of one kind (make_record: analytic primitives
-// intersected = the starting bound, slab set-up), stages them in LDS and copies them out 16 bytes per lane to consecutive addresses --
-// at a point every lane of the wave reaches, outside all per-item branches.
+// intersected = the starting bound, slab set-up), stages them in LDS and copies them out 16 bytes per lane to consecutive addresses.
+// In the shipped configuration (ART_SHADE_DEFER = 0) that copy-out sits inside shade_item's emit_ray: every kept item of a wave is a
+// surface item and takes the surface branch together, which rests on the compiler keeping ONE call site for it; it is therefore checked
+// at run time -- every record copied must name the hit slot its position implies, else the stage counts a lost path, and a lost path
+// fails art_synchronize.  ART_SHADE_DEFER = 1 builds and copies the records after shade_item at a point every lane of the
+// wave reaches (30 more VGPRs: slower).
 // ------------------------------------------------------------------------------------------------
 // items per workgroup = 256 x kShadePerThread, one global atomic per workgroup.  Rounds 1-2 used 16 per thread (a single hot word serves
 // ~88 atomics / us); measured in round 3 with the fused stage: 4 per thread is faster at every size -- a thread's items one after the other

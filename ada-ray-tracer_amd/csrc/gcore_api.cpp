@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <atomic>
 #include <shared_mutex>
 #include <string>
 #include <vector>
@@ -67,10 +68,13 @@ struct GState {
   TwoLevel two;
   // the committed flattened tree on the host (binary32 node packets + triangle records, as art_export_bvh returns them): what a
   // single-ray gcore_closest_hit walks.  (Two-level scenes walk two.host, which the build left on the host anyway.)
+  // the flattened tree as host arrays, for the single-ray host walk.  Fetched on the FIRST single-ray call after a commit (callers
+  // that only use gcore_closest_hit_n or the art_* seam never pay the device -> host copy of the tree, nor its host memory)
   std::vector<float> h_nodes, h_tris; int h_width = 4, h_ntris = 0;
 } g;
 // single-ray queries hold it shared, commit / destroy exclusively (the reference has no such guard: it commits before it renders)
 std::shared_mutex g_scene_rw;
+std::atomic<bool> g_h_ready{false};      // GState::h_nodes / h_tris hold the committed tree
 
 template <typename T> bool to_device(void** p, const std::vector<T>& v) {
   if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -103,7 +107,7 @@ void gcore_destroy(void) {
   std::unique_lock<std::shared_mutex> wr(g_scene_rw);
   std::lock_guard<std::mutex> lk(art::g_mu);
   g.two.release();
-  g = GState();
+  g = GState(); g_h_ready = false;
 }
 
 // -1 automatic (two-level from 16 instances on), 0 always flatten, 1 always two-level; takes effect at the next gcore_commit_scene
@@ -156,7 +160,7 @@ void gcore_commit_scene(void) {
   std::unique_lock<std::shared_mutex> wr(g_scene_rw);
   std::lock_guard<std::mutex> lk(art::g_mu);
   g.committed = false;
-  g.tri_inst.clear(); g.tri_prim.clear(); g.wverts.clear(); g.widx.clear(); g.h_nodes.clear(); g.h_tris.clear(); g.h_ntris = 0;
+  g.tri_inst.clear(); g.tri_prim.clear(); g.wverts.clear(); g.widx.clear(); g.h_nodes.clear(); g.h_tris.clear(); g.h_ntris = 0; g_h_ready = false;
   g.two.release(); g.two.on = false;
   const bool two_level = (g_force_two_level == 1) || (g_force_two_level < 0 && (int)g.insts.size() >= kTwoLevelMinInstances);
   if (two_level) {                       // embree_connect.cpp:147-184: one tree per mesh, instances on top
@@ -195,7 +199,7 @@ void gcore_commit_scene(void) {
   sd.n_lights = 1; sd.lights = &light; sd.n_materials = 1; sd.materials = &mat; sd.n_meshes = 1; sd.meshes = &mesh;
   sd.cam_matrix[0] = sd.cam_matrix[5] = sd.cam_matrix[10] = sd.cam_matrix[15] = 1.0f;
   if (art::upload_scene(&sd)) { std::printf("[c_gcore]: %s\n", art_last_error()); return; }
-  if (art::fetch_host_bvh(g.h_nodes, g.h_tris, g.h_width, g.h_ntris)) { std::printf("[c_gcore]: %s\n", art_last_error()); return; }
+  g.h_nodes.clear(); g.h_tris.clear(); g_h_ready = false;
   g.committed = true;
 }
 
@@ -348,6 +352,14 @@ void run_batch(Req* const* reqs, size_t n) {
 void gcore_set_single_ray_on_gpu(int on) { std::unique_lock<std::shared_mutex> wr(g_scene_rw); g_force_gpu_single = on; }
 
 bool gcore_closest_hit(const float a_rayPos[3], const float a_rayDir[3], float t_near, float t_far, HitCpp* pHit) {
+  if (!g_force_gpu_single && !g_h_ready.load(std::memory_order_acquire)) {      // first single-ray call since the commit: fetch the tree, once, under the writers' lock
+    std::unique_lock<std::shared_mutex> wr(g_scene_rw);
+    if (g.committed && !g.two.on && !g_h_ready.load(std::memory_order_relaxed)) {
+      std::lock_guard<std::mutex> lk(art::g_mu);
+      if (art::fetch_host_bvh(g.h_nodes, g.h_tris, g.h_width, g.h_ntris)) { std::printf("[c_gcore]: %s\n", art_last_error()); return false; }
+    }
+    g_h_ready.store(true, std::memory_order_release);
+  }
   {
     std::shared_lock<std::shared_mutex> rd(g_scene_rw);
     if (!g_force_gpu_single) return g_cpu_has_fma ? host_walk_fma(a_rayPos, a_rayDir, t_near, t_far, pHit) : host_walk_generic(a_rayPos, a_rayDir, t_near, t_far, pHit);

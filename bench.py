@@ -21,8 +21,9 @@ Extra objects on the line:
                   trace-kernel time (HIP events around every launch, on the launch stream); algorithmic bytes per ray =
                   node_bytes x node visits + 48 x triangle tests + 64, the visits and tests counted on this very workload by
                   the counting variant of the kernel (equal to the oracle's walk of the exported tree); peak = 8 TB/s HBM3E.
-                  "traffic" = bytes that actually left L2 per second (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE passes,
-                  profiles/), only when the committed profile was taken on this source, scene and options; else null.
+                  "traffic" = bytes that actually left L2 per second (rocprofv3 FETCH_SIZE + WRITE_SIZE passes, FETCH_SIZE
+                  times the factor calibrated on the kernel's access shape -- x1 for the trace kernel's 64-byte gathers, profiles/r5_calib),
+                  only when the committed profile was taken on this source, scene and options; else null.
   "cpu_baseline"  the CPU oracle (kind "port": the reference is Ada and cannot be built or shipped) on a bounded sample of
                   the same workload, timed on this host; for --scene c2 also "mode_a", the reference-faithful organisation
                   (brute-force mesh, Threads_Num = 28 whole-frame tasks).
@@ -333,7 +334,8 @@ def main():
             #   fabric_frac = bytes that left L2 (traffic) / the guide's ceiling for random multi-line gathers out of the Infinity Cache
             #                 (8.6 TB/s for a 38 MB table, 7.4-7.9 for 151 MB; the 89 MB working set of C4 is priced at 8.0)
             issue = round(prof["valu_issue_frac"], 4) if prof and "valu_issue_frac" in prof else None
-            fabric = round(prof["traffic_GBps_fetch_x2"] / GATHER_CEILING_GBPS, 4) if prof else None
+            traffic = prof.get("traffic_GBps_calibrated", prof.get("traffic_GBps_raw")) if prof else None      # FETCH_SIZE x the factor calibrated on the kernel's own access shape (x1: profiles/r5_calib)
+            fabric = round(traffic / GATHER_CEILING_GBPS, 4) if prof else None
             over = achieved > HBM_PEAK_GBPS      # only the 8-wide option: its 256-byte binary32 nodes are mostly served by L2, so the
             cands = [("hbm", 0.0 if over else achieved / HBM_PEAK_GBPS)] + ([("issue", issue)] if issue is not None else []) + ([("fabric", fabric)] if fabric is not None else [])
             bound = max(cands, key=lambda kv: kv[1])[0] if prof else "hbm"
@@ -343,7 +345,8 @@ def main():
                         "device": ("device 0 of %d (one process, art_init_devices); counters summed over the devices" % n_gpus) if in_library else None,
                         "frac": None if over else round(achieved / HBM_PEAK_GBPS, 4),
                         "frac_note": "algorithmic bytes exceed the HBM peak (cache hits): not a roofline fraction" if over else None,
-                        "traffic": round(prof["traffic_GBps_fetch_x2"], 1) if prof else None,
+                        "traffic": round(traffic, 1) if prof else None,
+                        "traffic_note": "FETCH_SIZE x 1.0 + WRITE_SIZE per launch / launch time: random 64-byte node packets and triangle records are counted exactly (profiles/r5_calib/calibration; rounds 1-4 doubled FETCH_SIZE on a calibration of 128-byte gathers the kernel no longer does)" if prof else None,
                         "traffic_source": ("profiles/%s/pmc_summary.json (same source %s, scene, options)" % (PROFILE_TAG, fp["source"])) if prof else None,
                         "kernel": "k_trace_coop" if args.kernel == "coop" else "k_trace_simple",
                         "bound_evidence": "frac = algorithmic bytes against the HBM peak (the contract's roofline).  What limits the kernel itself is VALU issue: "

@@ -16,8 +16,11 @@
  *
  * Error convention: art_* return 0 on success, non-zero on failure, text via art_last_error();
  * nothing in this library calls exit() (embree_connect.cpp:28-49 does).  gcore_* keep the reference's
- * return types (0 / false on failure).  The library has NO CPU fallback: without a usable HIP device
- * every call that needs one fails with a message.
+ * return types (0 / false on failure).  Rendering and batched queries have NO CPU fallback: without a usable HIP device
+ * every call that needs one fails with a message.  One documented host path exists on the legacy seam: a SINGLE-ray
+ * gcore_closest_hit is answered on the calling thread by a walk of the committed tree (the product's own walker, the GPU kernels'
+ * boxes and triangle arithmetic: gcore_set_single_ray_on_gpu below; SURVEY 8(b) -- a kernel launch per ray is what that call pattern
+ * cannot afford).  The tree itself is always built and committed on the GPU box; nothing routes through the test oracle.
  *
  * Threading: art_* are single-caller (Render_Pass is only called from the environment task,
  * test.adb:50); gcore_closest_hit may be called concurrently (it is in the reference, from up to 28
@@ -130,7 +133,9 @@ typedef struct ArtBvhInfo { int32_t n_nodes, n_tris, max_stack, node_width; doub
 
 int  art_init(int device_ordinal);                       /* -1: keep the current HIP device */
 /* One process, n GPUs of the node (the Ada host calls Render_Pass from one task: ray_tracer.adb:240-293, test.adb:50).  ordinals ==
- * NULL: devices 0..n-1.  Scene and BVH are replicated, device k owns the 32x32 pixel tiles (bx, by) with (bx + 3 by) mod n == k, and the float3
+ * NULL: devices 0..n-1.  Scene and BVH are replicated, device k owns the 32x32 pixel tiles (bx, by) with (bx + skew by) mod n == k
+ * (skew = 3, or 5 when 3 divides n, or 7 when 15 divides n: tiles dealt along diagonals, csrc/art_host_scene.cpp build_pixmap -- an
+ * integrator that needs the map should not recompute it from this sentence but take the rule from there), and the float3
  * framebuffers are added into device 0 by ONE RCCL reduce over xGMI whenever the image is asked for (art_render_pass with host
  * pointers, art_download, art_reduce).  The image is bit-identical for any n.  Call INSTEAD of art_init; art_set_stream /
  * art_set_shard / art_bind_accum are single-device calls and fail afterwards.  Repeating one ordinal n times rehearses the whole

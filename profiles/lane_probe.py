@@ -15,7 +15,7 @@ NAMES = {0: "shade_item entry", 1: "resolve pending shadow", 2: "alive", 3: "mat
          6: "before light_sample", 7: "before bsdf_eval", 8: "before bsdf_sample", 9: "after bsdf_sample", 10: "light_sample entry", 11: "rect light",
          12: "inside the sphere light", 13: "cone sampling", 14: "frame branch x > y", 15: "frame built", 16: "ray-sphere disc >= 0", 17: "light_sample end",
          20: "bsdf Lambert", 21: "bsdf Mirror", 22: "bsdf Glass", 23: "bsdf Phong", 24: "lobe_to_world", 25: "lobe fix-up", 30: "emit_ray entry", 31: "emit_ray live",
-         32: "emit_ray slab_setup", 33: "emit_ray staged", 40: "output decision", 41: "output item written", 50: "isect_sphere", 51: "isect_sphere disc >= 0",
+         32: "emit_ray slab_setup", 40: "output decision", 41: "output item written", 50: "isect_sphere", 51: "isect_sphere disc >= 0",
          52: "isect_cornell", 53: "isect_cornell hit"}
 
 

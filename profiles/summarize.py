@@ -18,6 +18,20 @@ def newest(pattern):
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# FETCH_SIZE -> bytes, per access shape (round 5, profiles/calib_shapes.hip -> profiles/r5_calib/calib_shapes.json, tables >> 256 MiB with a
+# known byte count):  random 64-byte packets read by 4 lanes x 16 B (the node visit) x0.998,  random 64-byte records read by one lane
+# (triangle test, shading record) x0.998 / x1.001,  coalesced 4-B- and 16-B-per-lane streams x2.000,  stores x1.000 (WRITE_SIZE is exact).
+# Rounds 1-4 doubled FETCH_SIZE for every kernel on the strength of ONE calibration of 128-byte segment gathers (round 1's 8-wide node).
+#   k_trace_coop      its fetches are node packets and triangle records (3968 B per ray on C4 against 64 B of streamed trace record): x1
+#   stream kernels    k_fold_level, k_accumulate, k_resolve_last, k_resolve: x2
+#   k_shade_compact   a mix: the item's own words are streams (x2), the triangle's shading record is a gather (x1).  With the item counts of
+#                     the bench line taken under rocprof (stages.items_in_per_bounce) the streamed part is known: true = raw + streamed / 2;
+#                     without them the factor of the synthetic mix kernel (k_stage_mix<64>: 1.417) is used.
+FETCH_FACTOR_TRACE = 1.0
+FETCH_FACTOR_STREAM = 2.0
+FETCH_FACTOR_STAGE_MIX = 1.417
+STAGE_STREAM_IN_B, STAGE_STREAM_IN_B0 = 60.0, 16.0          # bench.py STAGE_IN_B / STAGE_IN_B0: the streamed words an input item is read with
+
 
 def main(tag, name="c4"):
     """tag: directory under profiles/ (r3_final for the bench.py default workload C4, which bench.py quotes; r3_c3 ...);
@@ -52,6 +66,10 @@ def main(tag, name="c4"):
             o["avg_launch_ms_fetch_pass"] = o["total_ns_fetch"] / n / 1e6
             o["traffic_GBps_raw"] = o["hbm_bytes_per_launch_raw"] / (o["total_ns_fetch"] / n) 
             o["traffic_GBps_fetch_x2"] = o["hbm_bytes_per_launch_fetch_x2"] / (o["total_ns_fetch"] / n)
+            # round 5: the calibrated figure (random 64-byte packets: FETCH_SIZE is exact) -- what bench.py quotes as roofline.traffic
+            o["fetch_factor_calibrated"] = FETCH_FACTOR_TRACE
+            o["hbm_bytes_per_launch_calibrated"] = FETCH_FACTOR_TRACE * fetch_b + write_b
+            o["traffic_GBps_calibrated"] = o["hbm_bytes_per_launch_calibrated"] / (o["total_ns_fetch"] / n)
             if "GRBM_GUI_ACTIVE" in o:
                 o["effective_clock_GHz"] = o["GRBM_GUI_ACTIVE"] / 8.0 / o["total_ns_sq"]
             if "TCC_HIT_sum" in o:
@@ -81,13 +99,32 @@ def main(tag, name="c4"):
                 o["valu_issue_formula"] = "SQ_INSTS_VALU / dispatches / 1024 SIMDs x mean issue ns of the kernel's instruction mix (valu_mix.json x valu_rate2.hip) / launch ns"
     # the other kernels of a step: bytes past L2 and achieved TB/s (the stages are memory-bound; the HBM roofline is theirs)
     others = {}
+    bench_line = None
+    try:
+        bench_line = json.load(open(os.path.join(SRC, "bench_under_rocprof.json")))
+    except Exception:
+        pass
     for k, o in out.items():
         if "k_trace_coop" in k or "FETCH_SIZE" not in o or "dispatches_write" not in o or "art::" not in k or "anonymous" in k or "rocprim" in k or k.replace("void ", "").replace("art::", "").strip() == "":
             continue
         n = o["dispatches_fetch"]
-        fb = 2.0 * o["FETCH_SIZE"] * 1024.0 / n; wb = o["WRITE_SIZE"] * 1024.0 / o["dispatches_write"]; ns = o["total_ns_fetch"] / n
-        e = {"launches": n, "avg_launch_ms": ns / 1e6, "fetch_x2_GB_per_launch": fb / 1e9, "write_GB_per_launch": wb / 1e9, "traffic_TBps": (fb + wb) / ns / 1e3,
-             "frac_of_hbm_peak_8TBps": (fb + wb) / ns / 8000.0}
+        raw = o["FETCH_SIZE"] * 1024.0 / n; wb = o["WRITE_SIZE"] * 1024.0 / o["dispatches_write"]; ns = o["total_ns_fetch"] / n
+        how = "streams: x2"
+        fb = FETCH_FACTOR_STREAM * raw
+        if "k_shade_compact" in k:
+            fb = FETCH_FACTOR_STAGE_MIX * raw; how = "synthetic mix factor 1.417 (k_stage_mix<64>)"
+            st = (bench_line or {}).get("stages")
+            if st:                                                # the streamed words of the launches this kernel name covers, from the item counts
+                ins = st["items_in_per_bounce"]; nb = st["batches"]
+                camera = "true" in k.split("<")[1]
+                launches_per_batch = 1 if camera else max(1, len(ins) - 1)
+                streamed = (ins[0] * STAGE_STREAM_IN_B0) if camera else sum(v * STAGE_STREAM_IN_B for v in ins[1:]) / launches_per_batch
+                fb = raw + 0.5 * min(streamed, 2.0 * raw); how = "raw + streamed words / 2 (item counts of the bench line under rocprof)"
+        elif "k_raygen" in k:
+            fb = raw; how = "no streamed reads: x1"
+        e = {"launches": n, "avg_launch_ms": ns / 1e6, "fetch_raw_GB_per_launch": raw / 1e9, "fetch_GB_per_launch": fb / 1e9, "fetch_factor": fb / raw if raw > 0 else None, "fetch_factor_how": how,
+             "write_GB_per_launch": wb / 1e9, "traffic_TBps": (fb + wb) / ns / 1e3,
+             "frac_of_hbm_peak_8TBps": (fb + wb) / ns / 8000.0, "traffic_TBps_if_fetch_x2": (2.0 * raw + wb) / ns / 1e3}
         if "SQ_INSTS_VALU" in o:
             e["valu_instructions_per_ns_and_simd"] = o["SQ_INSTS_VALU"] / o["dispatches_sq"] / 1024.0 / (o["total_ns_sq"] / o["dispatches_sq"])
         if "TCC_HIT_sum" in o:
