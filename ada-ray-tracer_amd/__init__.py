@@ -60,6 +60,10 @@ class ArtMesh(C.Structure):
                 ("bbmin", C.c_float * 3), ("bbmax", C.c_float * 3)]
 
 
+class ArtInstance(C.Structure):
+    _fields_ = [("mesh", C.c_int32), ("m", C.c_float * 12)]
+
+
 class ArtSceneDesc(C.Structure):
     _fields_ = [("n_spheres", C.c_int32), ("spheres", C.POINTER(ArtSphere)),
                 ("has_cornell", C.c_int32),
@@ -68,7 +72,8 @@ class ArtSceneDesc(C.Structure):
                 ("n_lights", C.c_int32), ("lights", C.POINTER(ArtLight)),
                 ("n_materials", C.c_int32), ("materials", C.POINTER(ArtMaterial)),
                 ("n_meshes", C.c_int32), ("meshes", C.POINTER(ArtMesh)),
-                ("cam_pos", C.c_float * 3), ("cam_matrix", C.c_float * 16)]
+                ("cam_pos", C.c_float * 3), ("cam_matrix", C.c_float * 16),
+                ("n_instances", C.c_int32), ("instances", C.POINTER(ArtInstance))]
 
 
 class ArtPassParams(C.Structure):
@@ -185,7 +190,9 @@ class SceneDesc:
     """Flattened scene held in numpy arrays (keeps them alive) + the ArtSceneDesc view of them."""
 
     def __init__(self, spheres=(), lights=(), materials=(), meshes=(), cornell=None,
-                 cam_pos=(0.0, 2.55, 12.5), cam_matrix=None):
+                 cam_pos=(0.0, 2.55, 12.5), cam_matrix=None, instances=()):
+        """instances: [(mesh index, 12 floats: object -> world 3x4 row-major)] -- then `meshes` are object-space prototypes (ArtSceneDesc::n_instances)"""
+        self._kw = dict(spheres=spheres, lights=lights, materials=materials, cornell=cornell, cam_pos=cam_pos, cam_matrix=cam_matrix)      # (for flattened_copy)
         self.spheres = (ArtSphere * max(1, len(spheres)))()
         for i, (pos, r, mat) in enumerate(spheres):
             self.spheres[i].pos = (C.c_float * 3)(*pos); self.spheres[i].r = r; self.spheres[i].mat = mat
@@ -230,6 +237,10 @@ class SceneDesc:
         d.cam_pos = (C.c_float * 3)(*cam_pos)
         cm = np.eye(4, dtype=np.float32).ravel() if cam_matrix is None else np.asarray(cam_matrix, np.float32).ravel()
         d.cam_matrix = (C.c_float * 16)(*[float(v) for v in cm])
+        self.instances = (ArtInstance * max(1, len(instances)))()
+        for i, (mesh, m) in enumerate(instances):
+            self.instances[i].mesh = int(mesh); self.instances[i].m = (C.c_float * 12)(*[float(v) for v in np.asarray(m, np.float32).ravel()[:12]])
+        d.n_instances = len(instances); d.instances = self.instances
         self.desc = d
 
 

@@ -57,6 +57,14 @@ package Art_Hip is
   end record;
   pragma Convention (C, Art_Mesh);
 
+  type Float12_C is array (0 .. 11) of aliased C_float;
+  pragma Convention (C, Float12_C);
+  type Art_Instance is record          --  embree_connect.cpp:147-184: one instance of a mesh, object -> world 3x4 row-major
+    mesh : int;
+    m    : Float12_C;
+  end record;
+  pragma Convention (C, Art_Instance);
+
   type Art_Scene_Desc is record
     n_spheres   : int;  spheres   : System.Address;
     has_cornell : int;
@@ -68,6 +76,7 @@ package Art_Hip is
     n_meshes    : int;  meshes    : System.Address;
     cam_pos     : Float3_C;
     cam_matrix  : Float16_C;
+    n_instances : int;  instances : System.Address;   --  > 0: meshes are object-space prototypes, the geometry is the instance list
   end record;
   pragma Convention (C, Art_Scene_Desc);
 

@@ -111,8 +111,15 @@ static int upload_scene_arrays(HostScene& hs) {
       upload(c.b_bf_uv, hs.bf_uv) || upload(c.b_bf_idx, hs.bf_idx) || (!hs.gpu_built && upload(c.b_nodes, hs.bvh.nodes)) || (!hs.gpu_built && upload(c.b_qnodes, hs.bvh.qnodes)) ||
       (!hs.gpu_built && upload(c.b_tris, hs.bvh.tris)) || upload(c.b_m_shade, hs.m_shade))
     return 1;
+  if (hs.hdr.n_inst > 0 && (upload(c.b_inst, hs.inst) || upload(c.b_tlas_nodes, hs.two.tlas.nodes) || upload(c.b_tlas_tris, hs.two.tlas.tris) ||
+                            upload(c.b_blas_nodes, hs.two.blas_nodes) || upload(c.b_blas_tris, hs.two.blas_tris)))
+    return 1;
   DevScene& s = c.scene;
   s = hs.hdr;
+  if (hs.hdr.n_inst > 0) {
+    s.inst = (const DevInstance*)c.b_inst.p; s.tlas_nodes = (const float*)c.b_tlas_nodes.p; s.tlas_tris = (const float*)c.b_tlas_tris.p;
+    s.blas_nodes = (const float*)c.b_blas_nodes.p; s.blas_tris = (const float*)c.b_blas_tris.p;
+  }
   s.spheres = (const DevSphere*)c.b_spheres.p; s.sphere_mat = (const int32_t*)c.b_sphere_mat.p;
   s.lights = (const DevLight*)c.b_lights.p; s.materials = (const DevMaterial*)c.b_materials.p;
   s.bf_pos = (const float*)c.b_bf_pos.p; s.bf_nrm = (const float*)c.b_bf_nrm.p; s.bf_uv = (const float*)c.b_bf_uv.p; s.bf_idx = (const int32_t*)c.b_bf_idx.p;
@@ -158,13 +165,13 @@ int upload_scene(const ArtSceneDesc* d) {
     }
     // the trace kernel addresses nodes and triangles with 32-bit byte offsets; the 4-wide entry word keeps bit 31 for the leaf flag
     const uint64_t off_limit = (hs.hdr.node_width == 4) ? (1ull << 31) : (1ull << 32);
-    if ((uint64_t)hs.hdr.n_nodes * node_floats(hs.hdr.node_width) * 4 >= (1ull << 32) || (uint64_t)hs.hdr.n_tris * (hs.hdr.node_width == 4 ? kQTriBytes : kTriBytes) >= off_limit)
-      return fail("mesh too large: the trace kernel addresses nodes and triangles with 32-bit byte offsets (max ~33M triangles at width 4, ~89M at width 8)");
+    if (hs.hdr.n_inst == 0 && ((uint64_t)hs.hdr.n_nodes * node_floats(hs.hdr.node_width) * 4 >= (1ull << 32) || (uint64_t)hs.hdr.n_tris * (hs.hdr.node_width == 4 ? kQTriBytes : kTriBytes) >= off_limit)
+        )  return fail("mesh too large: the trace kernel addresses nodes and triangles with 32-bit byte offsets (max ~33M triangles at width 4, ~89M at width 8)");
     if (hs.hdr.node_width == 4 && hs.hdr.n_nodes > 0 && hs.gpu_built && !c.b_qnodes.p) return fail("internal: GPU build returned no quantised nodes");
     if (dev_stack > kStackEntries) return fail("BVH traversal stack bound " + std::to_string(dev_stack) + " exceeds " + std::to_string(kStackEntries));
     if (upload_scene_arrays(hs)) return 1;
     c.b_qtris.release();
-    if (hs.hdr.node_width == 4 && hs.hdr.n_tris > 0) {       // 64-byte padded copy of the triangle records for the 4-wide kernel
+    if (hs.hdr.node_width == 4 && hs.hdr.n_tris > 0 && hs.hdr.n_inst == 0) {       // 64-byte padded copy of the triangle records for the 4-wide kernel
       if (ensure(c.b_qtris, (size_t)hs.hdr.n_tris * kQTriBytes)) return 1;
       launch_pad_tris(c.stream, (const float*)c.b_tris.p, (float*)c.b_qtris.p, hs.hdr.n_tris);
       HIP_TRY(hipStreamSynchronize(c.stream));
@@ -307,7 +314,7 @@ static int coop_grid() {
 
 static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
   Ctx& c = g_ctx;
-  a.n_rays = n_rays; a.width = c.scene.node_width;
+  a.n_rays = n_rays; a.width = c.scene.node_width; a.instanced = c.scene.n_inst > 0 ? 1 : 0;
   { int e; bool o; stack_plan(c.trace_kernel, e, o); a.stack_entries = e; a.stack_overflow = o ? 1 : 0; }
   a.node_min = c.node_min; a.refill_min = c.refill_min; a.segments = c.queue_segments; a.chunk = c.ray_chunk;
   a.ray_ox = q.ray_ox; a.ray_oy = q.ray_oy; a.ray_oz = q.ray_oz; a.ray_dx = q.ray_dx; a.ray_dy = q.ray_dy; a.ray_dz = q.ray_dz; a.ray_tfar = q.ray_tfar;
@@ -433,6 +440,7 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
   if (check_pass(p)) return 1;
   if (p->render_type == ART_RT_DEBUG || p->render_type == ART_RT_WHITTED) return fail("debug render types go through art_debug_hit_pass");
   if (p->render_type < ART_PT_STUPID || p->render_type > ART_PT_MIS) return fail("unknown render_type");
+  if (c.scene.n_inst > 0 && c.trace_kernel != TRACE_COOP) return fail("an instanced scene renders through the record schedule only (option trace_kernel = 0)");
   const int per = p->aa_on ? 4 : 1;
   if (spp_inout) c.spp = *spp_inout;
   if (p->aa_on && (c.spp % 4) != 0) return fail("with anti-aliasing on, spp must be a multiple of 4 (Generate4RayDirections order)");
@@ -777,7 +785,8 @@ void shutdown() {
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c.b_spheres, &c.b_sphere_mat, &c.b_lights, &c.b_materials, &c.b_bf_pos, &c.b_bf_nrm, &c.b_bf_uv, &c.b_bf_idx,
                       &c.b_nodes, &c.b_qnodes, &c.b_tris, &c.b_qtris, &c.b_m_shade, &c.b_accum, &c.b_screen, &c.b_stage,
-                      &c.b_pixmap, &c.b_paths, &c.b_rays, &c.b_ids, &c.b_queue, &c.b_ovf};
+                      &c.b_pixmap, &c.b_paths, &c.b_rays, &c.b_ids, &c.b_queue, &c.b_ovf,
+                      &c.b_inst, &c.b_tlas_nodes, &c.b_tlas_tris, &c.b_blas_nodes, &c.b_blas_tris};
     for (DevBuf* b : bufs) b->release();
     if (c.d_cursor) (void)hipFree(c.d_cursor);
     if (c.d_scene) (void)hipFree(c.d_scene);
@@ -917,6 +926,7 @@ int art_export_bvh(float* nodes, int64_t node_cap, float* tris, int64_t tri_cap,
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_ctx.scene_ready) return fail("no scene uploaded");
   Bvh8& b = g_ctx.host_scene.bvh;
+  if (g_ctx.scene.n_inst > 0 && (nodes || tris)) return fail("art_export_bvh: an instanced scene has a two-level tree; only its sizes are reported (ArtBvhInfo)");
   if (g_ctx.host_scene.gpu_built && b.nodes.empty() && (nodes || tris)) {     // the GPU-built tree is fetched on first request
     b.nodes.resize((size_t)b.n_nodes * node_floats(b.width)); b.tris.resize((size_t)b.n_tris * kTriFloats);
     HIP_TRY(hipMemcpy(b.nodes.data(), g_ctx.b_nodes.p, b.nodes.size() * 4, hipMemcpyDeviceToHost));

@@ -32,6 +32,7 @@ struct Ctx {
   // frame
   int width = 0, height = 0, spp = 0;
   int rank = 0, nranks = 1, tile = 32, npix_local = 0;
+  DevBuf b_inst, b_tlas_nodes, b_tlas_tris, b_blas_nodes, b_blas_tris;      // instanced scene (DevScene::n_inst > 0)
   DevBuf b_accum, b_screen, b_stage, b_pixmap, b_paths, b_rays, b_ids, b_queue, b_ovf;
   int* d_live = nullptr;                       // item counts per level: d_live[32 k] = items of bounce k's input set (k >= 1); the dense fold walks them again
   DevBuf b_reduced;                            // device 0, multi-device mode: sum of every device's accum (the RCCL reduce target)

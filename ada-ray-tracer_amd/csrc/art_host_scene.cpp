@@ -52,6 +52,58 @@ bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& o
   if (h.has_cornell) for (int i = 0; i < 6; ++i) if (!mat_ok(h.cb_mat[i])) { err = "scene: Cornell box material index out of range"; return false; }
   std::memcpy(h.cam_pos, d.cam_pos, 12); std::memcpy(h.cam_matrix, d.cam_matrix, 64);
 
+  if (d.n_instances < 0 || (d.n_instances > 0 && !d.instances)) { err = "scene: bad instance list"; return false; }
+  if (d.n_instances > 0) {
+    // ---- instanced scene: meshes are object-space prototypes, the geometry is the instance list (embree_connect.cpp:147-184)
+    if (bp.width != 4) { err = "scene: instanced scenes need bvh_width 4"; return false; }
+    std::vector<InstMeshIn> meshes((size_t)d.n_meshes); std::vector<InstIn> insts((size_t)d.n_instances);
+    std::vector<int32_t> shade_base((size_t)d.n_meshes, 0);
+    int32_t max_tris = 0;
+    for (int mi = 0; mi < d.n_meshes; ++mi) {
+      const ArtMesh& m = d.meshes[mi];
+      if (m.mode != ART_MESH_CLOSEST) { err = "scene: an instanced scene takes ART_MESH_CLOSEST meshes only"; return false; }
+      if (m.nverts <= 0 || m.ntris <= 0 || !m.pos || !m.nrm || !m.idx || !m.matid) { err = "scene: empty mesh or null mesh array"; return false; }
+      for (int64_t i = 0; i < 3 * (int64_t)m.ntris; ++i)
+        if (m.idx[i] < 0 || m.idx[i] >= m.nverts) { err = "scene: triangle index out of range"; return false; }
+      for (int64_t i = 0; i < (int64_t)m.nverts; ++i)
+        if (!finite3(m.pos + 3 * i) || !finite3(m.nrm + 3 * i)) { err = "scene: non-finite mesh vertex"; return false; }
+      for (int i = 0; i < m.ntris; ++i) if (!mat_ok(m.matid[i])) { err = "scene: triangle material id out of range"; return false; }
+      meshes[(size_t)mi] = InstMeshIn{m.pos, (size_t)m.nverts, m.idx, (size_t)m.ntris};
+      shade_base[(size_t)mi] = (int32_t)(out.m_shade.size() / kTriShadeFloats);
+      const size_t b0 = out.m_shade.size();
+      out.m_shade.resize(b0 + (size_t)kTriShadeFloats * (size_t)m.ntris, 0.0f);       // object-space vertex normals + material id, per triangle of the mesh
+      for (int i = 0; i < m.ntris; ++i) {
+        float* r = &out.m_shade[b0 + (size_t)kTriShadeFloats * (size_t)i];
+        for (int k = 0; k < 3; ++k) std::memcpy(r + 3 * k, m.nrm + 3 * (size_t)m.idx[3 * (size_t)i + k], 12);
+        std::memcpy(r + 9, &m.matid[i], 4);
+      }
+      max_tris = std::max(max_tris, m.ntris);
+    }
+    for (int i = 0; i < d.n_instances; ++i) {
+      const ArtInstance& in = d.instances[i];
+      if (in.mesh < 0 || in.mesh >= d.n_meshes) { err = "scene: instance of a missing mesh"; return false; }
+      for (int k = 0; k < 12; ++k) if (!std::isfinite(in.m[k])) { err = "scene: non-finite instance matrix"; return false; }
+      insts[(size_t)i].mesh = in.mesh; std::memcpy(insts[(size_t)i].m, in.m, 48);
+    }
+    // boxes of the meshes' trees padded for the object-space walk (art_instanced.h instanced_render_closest)
+    if (!build_two_level_host(meshes, insts, out.two, err, false, 1.0e-4f, 1.0e-5f)) return false;
+    int shift = 0; while ((1 << shift) < max_tris) ++shift;
+    if (shift > 27 || ((uint64_t)d.n_instances << shift) > (1ull << 28)) { err = "scene: instances x triangles per mesh exceed the 28-bit hit index"; return false; }
+    int64_t total = 0;
+    out.inst.resize((size_t)d.n_instances);
+    for (int i = 0; i < d.n_instances; ++i) {
+      const InstRec& R = out.two.inst[(size_t)i];                 // (one-sided builds keep every instance: index = the caller's)
+      DevInstance& D = out.inst[(size_t)i];
+      std::memcpy(D.m, d.instances[i].m, 48); std::memcpy(D.minv, R.minv, 48);
+      D.node_base = R.node_base; D.tri_base = R.tri_base; D.n_tris = R.n_tris; D.shade_base = shade_base[(size_t)R.mesh];
+      total += R.n_tris;
+    }
+    if (total >= (1ll << 31)) { err = "scene: too many instanced triangles"; return false; }
+    h.n_inst = d.n_instances; h.inst_shift = shift; h.n_tris = (int32_t)total; h.n_nodes = out.two.tlas.n_nodes; h.node_width = 4;
+    out.bvh.width = 4; out.bvh.max_stack = std::max(out.two.tlas.max_stack, 8);
+    out.bvh.n_nodes = out.two.tlas.n_nodes + (int32_t)(out.two.blas_nodes.size() / node_floats(4)); out.bvh.n_tris = (int32_t)total;      // (art_export_bvh's info: the two-level tree's sizes)
+    return true;
+  }
   bool have_bf = false, have_closest = false;
   for (int mi = 0; mi < d.n_meshes; ++mi) {
     const ArtMesh& m = d.meshes[mi];
@@ -98,6 +150,27 @@ bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& o
   return true;
 }
 
+bool flatten_instances(const ArtSceneDesc& d, std::vector<float>& pos, std::vector<float>& nrm, std::vector<int32_t>& idx, std::vector<int32_t>& matid, std::string& err) {
+  pos.clear(); nrm.clear(); idx.clear(); matid.clear();
+  std::vector<InstMeshIn> meshes; std::vector<InstIn> insts((size_t)d.n_instances);
+  for (int mi = 0; mi < d.n_meshes; ++mi) meshes.push_back(InstMeshIn{d.meshes[mi].pos, (size_t)d.meshes[mi].nverts, d.meshes[mi].idx, (size_t)d.meshes[mi].ntris});
+  for (int i = 0; i < d.n_instances; ++i) { insts[(size_t)i].mesh = d.instances[i].mesh; std::memcpy(insts[(size_t)i].m, d.instances[i].m, 48); }
+  TwoLevelHost two;
+  if (!build_two_level_host(meshes, insts, two, err, false, 1.0e-4f, 1.0e-5f)) return false;       // (for the inverse matrices: the instanced upload's own)
+  for (int i = 0; i < d.n_instances; ++i) {
+    const ArtMesh& m = d.meshes[d.instances[i].mesh];
+    const float* M = d.instances[i].m; const float* Minv = two.inst[(size_t)i].minv;
+    const int32_t v0 = (int32_t)(pos.size() / 3);
+    for (int v = 0; v < m.nverts; ++v) {
+      const f3 p = xform_point(M, mk3(m.pos[3 * v], m.pos[3 * v + 1], m.pos[3 * v + 2]));
+      const f3 n = instance_normal(Minv, mk3(m.nrm[3 * v], m.nrm[3 * v + 1], m.nrm[3 * v + 2]));
+      pos.insert(pos.end(), {p.x, p.y, p.z}); nrm.insert(nrm.end(), {n.x, n.y, n.z});
+    }
+    for (int t = 0; t < m.ntris; ++t) { for (int k = 0; k < 3; ++k) idx.push_back(v0 + m.idx[3 * t + k]); matid.push_back(m.matid[t]); }
+  }
+  return true;
+}
+
 std::vector<uint32_t> build_pixmap(int W, int H, int rank, int nranks, int T) {
   std::vector<uint32_t> pm;
   pm.reserve((size_t)W * H / (size_t)(nranks > 0 ? nranks : 1) + 1024);
@@ -124,6 +197,10 @@ void bind_host_pointers(HostScene& hs) {
   h.bf_pos = hs.bf_pos.data(); h.bf_nrm = hs.bf_nrm.data(); h.bf_uv = hs.bf_uv.data(); h.bf_idx = hs.bf_idx.data();
   h.nodes = hs.bvh.nodes.data(); h.tris = hs.bvh.tris.data();
   h.m_shade = hs.m_shade.data();
+  if (h.n_inst > 0) {
+    h.inst = hs.inst.data(); h.tlas_nodes = hs.two.tlas.nodes.data(); h.tlas_tris = hs.two.tlas.tris.data();
+    h.blas_nodes = hs.two.blas_nodes.data(); h.blas_tris = hs.two.blas_tris.data();
+  }
 }
 
 }  // namespace art

@@ -6,6 +6,7 @@
 #include "../../include/art_hip.h"
 #include "art_bvh.h"
 #include "art_scene.h"
+#include "art_instanced_build.h"
 
 namespace art {
 
@@ -23,8 +24,15 @@ struct HostScene {
   std::vector<float> deferred_tri9;   // builder == 1: triangle corners for the GPU build (bvh stays empty until then)
   bool gpu_built = false;             // nodes / tris live only in HBM (art_export_bvh copies them back on demand)
   double bvh_build_ms = 0.0;
+  // instanced scene (ArtSceneDesc::n_instances > 0): m_shade then holds the MESHES' records (object-space normals), one block per mesh
+  TwoLevelHost two; std::vector<DevInstance> inst;
   DevScene hdr;               // scalar part; pointer members are filled by the owner (host or device addresses)
 };
+
+// the explicit flattening of an instanced scene's meshes -- what an instanced render must equal bit for bit: positions, normals (3 floats per
+// vertex), indices, material ids of ONE world-space mesh, triangles in the order (instance, triangle of the mesh)
+bool flatten_instances(const ArtSceneDesc& d, std::vector<float>& pos, std::vector<float>& nrm, std::vector<int32_t>& idx, std::vector<int32_t>& matid, std::string& err);
+
 
 bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& out, std::string& err);
 

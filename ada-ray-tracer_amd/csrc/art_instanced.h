@@ -92,4 +92,70 @@ ART_HD InstHit instanced_closest(const InstScene& T, f3 o, f3 d, float tfar) {
   return best;
 }
 
+// ---- the render loop's search over an instanced scene (round 5).  Same two-level walk, but with the semantics of the FLATTENED scene, bit
+// for bit: a mesh's tree is walked with the ray taken into object space (boxes only -- they are padded for it at build time), and every
+// triangle that survives is tested in WORLD space, its corners transformed by the instance's matrix with the arithmetic the flattening
+// uses (xform_point), by the reference's one-sided Moeller-Trumbore on the untransformed ray.  t, u, v are therefore the flattened
+// scene's; the closest hit is the lexicographic minimum over (t, key) as everywhere, key index = instance << inst_shift | triangle --
+// the order of the flattened triangle list.  `best` comes in as the starting bound (analytic primitives); the shadow rule as in bvh_closest.
+template <bool STATS>
+ART_HD void instanced_render_closest(const DevScene& S, f3 o, f3 d, Cand& best, BvhStats* st, ShadowState& sh) {
+  if (S.n_inst <= 0) return;
+  f3 inv, noi;
+  slab_setup(o, d, inv, noi);
+  constexpr int kTop = kInstTopStack;
+  int32_t stk_ref[kTop]; float stk_t[kTop];
+  int sp = 0;
+  stk_ref[sp] = 0; stk_t[sp] = 0.0f; ++sp;
+  constexpr int W = 4;
+  while (sp > 0) {
+    --sp;
+    const int32_t e = stk_ref[sp];
+    if (stk_t[sp] > best.t) continue;
+    const int32_t ref = e >> 4, cnt = e & 15;
+    if (cnt == 0) {
+      const float* nd = S.tlas_nodes + (size_t)ref * (size_t)node_floats(W);
+      uint32_t key[4]; int32_t ent[4]; float tm[4]; int nh = 0;
+      if (STATS) st->node_visits++;
+      for (int j = 0; j < W; ++j) {
+        const int32_t rj = __builtin_bit_cast(int32_t, nd[4 * j + 3]);
+        if (rj < 0) continue;
+        if (STATS) st->box_tests++;
+        float tmn, tmx;
+        slab_fast(nd, W, j, inv, noi, best.t, tmn, tmx);
+        if (tmn <= tmx) {
+          key[nh] = (__builtin_bit_cast(uint32_t, tmn) & ~7u) | (uint32_t)j;
+          ent[nh] = (rj << 4) | __builtin_bit_cast(int32_t, nd[4 * W + 4 * j + 3]);
+          tm[nh] = tmn; ++nh;
+        }
+      }
+      for (int a = 1; a < nh; ++a) {
+        const uint32_t k = key[a]; const int32_t ee = ent[a]; const float tt = tm[a];
+        int b = a - 1;
+        while (b >= 0 && key[b] > k) { key[b + 1] = key[b]; ent[b + 1] = ent[b]; tm[b + 1] = tm[b]; --b; }
+        key[b + 1] = k; ent[b + 1] = ee; tm[b + 1] = tt;
+      }
+      for (int a = nh - 1; a >= 0 && sp < kTop; --a) { stk_ref[sp] = ent[a]; stk_t[sp] = tm[a]; ++sp; }
+    } else {
+      for (int j = 0; j < cnt; ++j) {
+        const int32_t ii = __builtin_bit_cast(int32_t, S.tlas_tris[(size_t)(ref + j) * kTriFloats + 9]);
+        const DevInstance& R = S.inst[ii];
+        const f3 oo = xform_point(R.minv, o), dd = xform_dir(R.minv, d);
+        const float* const tris = S.blas_tris + (size_t)R.tri_base * kTriFloats;
+        const uint32_t key_base = KEY_TRI | ((uint32_t)ii << S.inst_shift);
+        bvh_walk<STATS>(S.blas_nodes + (size_t)R.node_base * (size_t)node_floats(W), W, oo, dd, best, st, sh, [&](int32_t r0, int32_t c0) {
+          for (int q = 0; q < c0; ++q) {
+            const float* tr = tris + (size_t)(r0 + q) * kTriFloats;
+            const f3 A = xform_point(R.m, ld3(tr)), B = xform_point(R.m, ld3(tr + 3)), C = xform_point(R.m, ld3(tr + 6));
+            float t, u, v;
+            if (tri_raw(o, d, A, B, C, t, u, v) && t > 0.0f && t < 1000000.0f)
+              cand_take(best, t, key_base | (uint32_t)__builtin_bit_cast(int32_t, tr[9]), u, v);
+          }
+        });
+        if (sh.shm >= 0.0f && best.key != KEY_MISS && best.t <= sh.shm) return;      // shadow rule: a near hit ended the ray inside the mesh's tree
+      }
+    }
+  }
+}
+
 }  // namespace art

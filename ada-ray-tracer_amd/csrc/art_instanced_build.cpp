@@ -22,26 +22,29 @@ static bool invert_3x4(const float m[12], float out[12]) {     // world -> objec
   return true;
 }
 
-bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vector<InstIn>& insts, TwoLevelHost& T, std::string& err) {
+bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vector<InstIn>& insts, TwoLevelHost& T, std::string& err,
+                          bool two_sided, float pad_rel, float pad_abs) {
   T = TwoLevelHost();
   BvhBuildParams bp; bp.width = 4;
+  if (pad_rel >= 0.0f) bp.inflate_rel = pad_rel;
+  if (pad_abs >= 0.0f) bp.inflate_abs = pad_abs;
   const size_t nm = meshes.size();
   std::vector<int32_t> node_base(nm, 0), tri_base(nm, 0), ntris(nm, 0);
   std::vector<std::array<float, 6>> mesh_box(nm);
   for (size_t mi = 0; mi < nm; ++mi) {
     const InstMeshIn& m = meshes[mi];
     if (m.n_tris == 0 || m.n_verts == 0) { err = "empty mesh"; return false; }
-    std::vector<float> tri9(18 * m.n_tris);
+    std::vector<float> tri9((two_sided ? 18 : 9) * m.n_tris);
     float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
     for (size_t t = 0; t < m.n_tris; ++t) {
       const float* A = m.verts + 3 * (size_t)m.idx[3 * t]; const float* B = m.verts + 3 * (size_t)m.idx[3 * t + 1]; const float* C = m.verts + 3 * (size_t)m.idx[3 * t + 2];
-      float* f = &tri9[18 * t];
+      float* f = &tri9[(two_sided ? 18 : 9) * t];
       std::memcpy(f, A, 12); std::memcpy(f + 3, B, 12); std::memcpy(f + 6, C, 12);          // record 2t:   front winding
-      std::memcpy(f + 9, A, 12); std::memcpy(f + 12, C, 12); std::memcpy(f + 15, B, 12);     // record 2t+1: back winding
+      if (two_sided) { std::memcpy(f + 9, A, 12); std::memcpy(f + 12, C, 12); std::memcpy(f + 15, B, 12); }     // record 2t+1: back winding
       for (const float* P : {A, B, C}) for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], P[a]); hi[a] = std::max(hi[a], P[a]); }
     }
     Bvh8 b;
-    if (!build_bvh8(tri9.data(), nullptr, (int32_t)(2 * m.n_tris), bp, b, err)) return false;
+    if (!build_bvh8(tri9.data(), nullptr, (int32_t)((two_sided ? 2 : 1) * m.n_tris), bp, b, err)) return false;
     // instanced_closest walks a mesh tree with bvh_closest's private stack of kStackEntries entries and pushes unchecked (like the
     // flattened upload, which art_upload_scene refuses for the same reason)
     if (b.max_stack > kStackEntries) { err = "mesh tree stack bound " + std::to_string(b.max_stack) + " exceeds " + std::to_string(kStackEntries); return false; }
@@ -58,7 +61,10 @@ bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vect
     const InstIn& in = insts[ii];
     if (in.mesh < 0 || (size_t)in.mesh >= nm) { err = "instance of a missing mesh"; return false; }
     InstRec R; std::memset(&R, 0, sizeof R);
-    if (!invert_3x4(in.m, R.minv)) continue;                    // singular matrix: the instance has no volume, nothing can hit it
+    if (!invert_3x4(in.m, R.minv)) {                            // singular matrix: the instance has no volume, nothing can hit it
+      if (!two_sided) { err = "instance " + std::to_string(ii) + ": singular matrix"; return false; }
+      continue;
+    }
     R.node_base = node_base[in.mesh]; R.tri_base = tri_base[in.mesh]; R.n_tris = ntris[in.mesh]; R.mesh = in.mesh;
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     const std::array<float, 6>& mb = mesh_box[in.mesh];

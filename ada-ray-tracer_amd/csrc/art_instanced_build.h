@@ -25,6 +25,11 @@ struct TwoLevelHost {
 };
 
 // one tree per mesh (object space, both windings: record 2t front, 2t+1 back), one tree over the instances' world boxes
-bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vector<InstIn>& insts, TwoLevelHost& out, std::string& err);
+// two_sided = false (the render loop's instanced scenes, art_host_scene.cpp): one record per triangle in the caller's winding, prim = its
+// index in the mesh -- the reference's one-sided test; the meshes' boxes then carry the wider padding `pad_rel` / `pad_abs` (the walk
+// tests them with the ray taken to object space in binary32, while the triangles are tested in world space: no box may cull a
+// triangle that the world-space arithmetic would accept), and a singular instance matrix is an error instead of a dropped instance.
+bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vector<InstIn>& insts, TwoLevelHost& out, std::string& err,
+                          bool two_sided = true, float pad_rel = -1.0f, float pad_abs = -1.0f);
 
 }  // namespace art

@@ -209,9 +209,11 @@ ART_HD bool shadow_rule(ShadowState& sh, Cand& best) {
   return false;
 }
 
-template <bool STATS>
-ART_HD void bvh_closest(const DevScene& s, f3 o, f3 d, Cand& best, BvhStats* st, ShadowState& sh) {
-  if (s.n_tris <= 0) return;
+// The published walk over a tree of binary32 node packets, with the leaf left to the caller: leaf(ref, cnt) tests triangle records
+// [ref, ref + cnt) and updates `best` (bvh_closest: the records ARE the triangles; the instanced render search of art_instanced.h walks a
+// mesh's tree with the object-space ray and tests the triangles in world space).
+template <bool STATS, class Leaf>
+ART_HD void bvh_walk(const float* nodes, int W, f3 o, f3 d, Cand& best, BvhStats* st, ShadowState& sh, Leaf leaf) {
   f3 inv, noi;
   slab_setup(o, d, inv, noi);
   int32_t stk_ref[kStackEntries]; float stk_t[kStackEntries];
@@ -223,8 +225,7 @@ ART_HD void bvh_closest(const DevScene& s, f3 o, f3 d, Cand& best, BvhStats* st,
     if (stk_t[sp] > best.t) continue;
     const int32_t ref = e >> 4, cnt = e & 15;
     if (cnt == 0) {
-      const int W = s.node_width;
-      const float* nd = s.nodes + (size_t)ref * (size_t)node_floats(W);
+      const float* nd = nodes + (size_t)ref * (size_t)node_floats(W);
       uint32_t key[8]; int32_t ent[8]; float tm[8]; int nh = 0;
       if (STATS) st->node_visits++;
       for (int j = 0; j < W; ++j) {
@@ -248,11 +249,21 @@ ART_HD void bvh_closest(const DevScene& s, f3 o, f3 d, Cand& best, BvhStats* st,
       for (int a = nh - 1; a >= 0; --a) { stk_ref[sp] = ent[a]; stk_t[sp] = tm[a]; ++sp; }
     } else {
       if (STATS) { st->leaf_visits++; st->tri_tests += (uint64_t)cnt; }
-      for (int j = 0; j < cnt; ++j) tri_leaf_test(s.tris + (size_t)(ref + j) * kTriFloats, o, d, best);   // the leaf is one unit
+      leaf(ref, cnt);                                                                                      // the leaf is one unit
       if (shadow_rule(sh, best)) return;
     }
   }
 }
+template <bool STATS>
+ART_HD void bvh_closest(const DevScene& s, f3 o, f3 d, Cand& best, BvhStats* st, ShadowState& sh) {
+  if (s.n_tris <= 0) return;
+  bvh_walk<STATS>(s.nodes, s.node_width, o, d, best, st, sh, [&](int32_t ref, int32_t cnt) {
+    for (int j = 0; j < cnt; ++j) tri_leaf_test(s.tris + (size_t)(ref + j) * kTriFloats, o, d, best);
+  });
+}
+
+// (art_instanced.h: the same search over an instanced scene -- DevScene::n_inst > 0; every user of closest_hit includes it)
+template <bool STATS> ART_HD void instanced_render_closest(const DevScene& S, f3 o, f3 d, Cand& best, BvhStats* st, ShadowState& sh);
 
 // Scene.Find_Closest_Hit (scene.adb:56-86) for one ray; tfar clips the search (shadow rays only need
 // hits below maxDist - epsilon2, ray_tracer.adb:119-122; camera/bounce rays pass kInfinity).
@@ -267,7 +278,8 @@ ART_HD Cand closest_hit(const DevScene& s, f3 o, f3 d, float tfar, BvhStats* st,
   isect_bf_mesh(o, d, rcp, s, best);
   ShadowState sh; sh.shm = shm; sh.far = false; sh.rep = best;
   if (shadow_rule(sh, best)) return best;
-  bvh_closest<STATS>(s, o, d, best, st, sh);
+  if (s.n_inst > 0) instanced_render_closest<STATS>(s, o, d, best, st, sh);
+  else bvh_closest<STATS>(s, o, d, best, st, sh);
   return (best.key != KEY_MISS || !sh.far) ? best : sh.rep;
 }
 

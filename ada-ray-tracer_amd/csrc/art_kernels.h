@@ -13,6 +13,7 @@ struct TraceArgs {
   int32_t n_rays;
   int32_t stack_entries;        // per-ray LDS stack depth; >= Bvh8::max_stack unless stack_overflow
   int32_t width;                // node width = lanes per ray in k_trace_coop (8 or 4)
+  int32_t instanced;            // DevScene::n_inst > 0: launch_trace runs k_trace_inst (two-level search, one ray per lane) over the records
   int32_t stack_overflow;       // the LDS stack is smaller than the tree's bound: pushes are checked, rays that do not fit go to ovf_queue
   int32_t segments;             // k_trace_coop: the queue is cut into this many contiguous segments (1, 2, 4, 8); workgroup b starts
                                 // in segment b % segments (its XCD) and moves on to the next segment when that one is drained

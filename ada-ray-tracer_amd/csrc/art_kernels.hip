@@ -511,6 +511,42 @@ __global__ __launch_bounds__(256) void k_trace_overflow(const DevScene* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_trace_inst: the trace kernel of INSTANCED scenes (round 5; DevScene::n_inst > 0): one ray per lane over the trace records of the
+// bank, the two-level search of art_instanced.h (a tree over the instances, one tree per mesh walked with the ray in object space, the
+// triangles tested in world space: the flattened scene's t, u, v).  Same protocol as k_trace_coop / k_trace_overflow: the record carries
+// the starting bound and the shadow rule's state; what ends up in the hit slot is a hit found in the meshes, else the first far hit of a
+// shadow ray, else what the producer stored.  (The cooperative kernel does not cross the instance boundary yet: an instanced scene
+// renders through this kernel, correct and slower -- DESIGN.md section 8.)
+// ------------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_trace_inst(const DevScene* __restrict__ Sp, const TraceArgs A) {
+  const DevScene& S = *Sp;
+  const int n_queue = (A.queue_fixed >= 0) ? A.queue_fixed : (A.queue_items ? *A.queue_items * A.queue_mul : *A.queue_count);
+  BvhStats st = {0, 0, 0, 0};
+  unsigned long long traced = 0;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_queue; k += gridDim.x * blockDim.x) {
+    const float4* r = A.rec + 4 * (size_t)k;
+    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+    if (!(r0.w >= 0.0f)) continue;                            // a ray that does not exist, or one the analytic pass decided
+    const int i = __builtin_bit_cast(int, r3.y);
+    const bool far0 = __builtin_bit_cast(uint32_t, r3.z) != 0u;
+    Cand best; best.t = r0.w; best.key = __builtin_bit_cast(uint32_t, r1.w); best.u = 0.0f; best.v = 0.0f;
+    ShadowState sh; sh.shm = r2.w; sh.far = far0; sh.rep = best;
+    instanced_render_closest<STATS>(S, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), best, &st, sh);
+    if (STATS) traced += 1;
+    const bool word = i < 0;                                   // kShadowWord: the result is one float (DevPaths::sh_t)
+    const uint32_t wi = (uint32_t)i & ~kShadowWord;
+    if (best.key != KEY_MISS && (best.key & ~KEY_INDEX_MASK) == KEY_TRI) { if (word) A.sh_t[wi] = best.t; else A.hit[i] = DevHit{best.t, best.key, best.u, best.v}; }
+    else if (sh.far && !far0) { if (word) A.sh_t[wi] = sh.rep.t; else A.hit[i] = DevHit{sh.rep.t, sh.rep.key, 0.0f, 0.0f}; }
+  }
+  if (STATS) {
+    atomicAdd(&A.stats[0], (unsigned long long)st.box_tests); atomicAdd(&A.stats[1], (unsigned long long)st.tri_tests);
+    atomicAdd(&A.stats[2], (unsigned long long)st.node_visits); atomicAdd(&A.stats[3], (unsigned long long)st.leaf_visits);
+    atomicAdd(&A.stats[4], traced);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_analytic: one ray per lane.  Intersects the analytic primitives and the reference brute-force mesh
 // (scene.adb:62-69 candidates 1-4), stores the result as the starting bound of the BVH search and appends
 // the rays that still need the BVH to the live-ray queue (dead rays and decided shadow rays drop out here).
@@ -1257,6 +1293,12 @@ void launch_trace(hipStream_t st, const DevScene* S, const TraceArgs& A, int ker
     return;
   }
   if (A.n_tris <= 0) return;                       // no BVH mesh: the analytic pass (launch_analytic) is the whole search
+  if (A.instanced) {                               // instanced scene: the two-level kernel (one ray per lane) over the same records
+    const int blocks = std::max(1, std::min(grid_blocks * 4, 65535));
+    if (stats) hipLaunchKernelGGL(k_trace_inst<true>, dim3(blocks), dim3(256), 0, st, S, A);
+    else hipLaunchKernelGGL(k_trace_inst<false>, dim3(blocks), dim3(256), 0, st, S, A);
+    return;
+  }
   const size_t lds = trace_coop_lds_bytes(A.stack_entries, A.width);
   const int variant = (stats ? 4 : 0) | (A.width == 4 ? 2 : 0) | (A.stack_overflow ? 1 : 0);
   switch (variant) {

@@ -99,6 +99,9 @@ ART_HD float length(f3 a) { return sqrtf(dot(a, a)); }
 ART_HD f3 reflect(f3 dir, f3 n) { return normalize(((n * dot(dir, n)) * -2.0f) + dir); }  // vector_math.adb:79-82
 
 // float4x4 (row-major, generic_vector_math.ads:64); m*v adds the translation column (vector_math.adb:137-144)
+// world normal of an object-space vertex normal under an instance whose inverse 3x4 is minv: inverse transpose of the 3x3, normalised
+// (instanced scenes, art_scene.h DevInstance; the flattening of art_host_scene.cpp and the shade stage evaluate this very expression)
+ART_HD f3 instance_normal(const float* minv, f3 n) { return normalize(mk3(minv[0] * n.x + minv[4] * n.y + minv[8] * n.z, minv[1] * n.x + minv[5] * n.y + minv[9] * n.z, minv[2] * n.x + minv[6] * n.y + minv[10] * n.z)); }
 ART_HD f3 xform_point(const float* m, f3 v) {
   return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3],
              m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7],

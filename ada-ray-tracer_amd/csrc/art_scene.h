@@ -59,6 +59,17 @@ constexpr int kTriShadeFloats = 16;  // nA.xyz nB.xyz nC.xyz matId, padded to 64
 constexpr int kMaxLeafTris = 8;
 constexpr int kStackEntries = 160;  // private stack of the one-ray-per-lane traversal; art_upload_scene rejects deeper trees
 
+// One instance of a mesh (round 5: art_upload_scene takes meshes + 3x4 instance transforms, embree_connect.cpp:147-184, and the render loop
+// walks them as a two-level tree without flattening).  key index of a hit = instance << DevScene::inst_shift | triangle of the mesh.
+struct DevInstance {
+  float m[12];                 // object -> world, 3x4 row-major (the first 12 floats of the reference's 16-float block, embree_connect.cpp:169)
+  float minv[12];              // world -> object
+  int32_t node_base;           // first node of the mesh's tree in DevScene::blas_nodes (in nodes)
+  int32_t tri_base;            // first triangle record of the mesh in DevScene::blas_tris (object space, one winding, prim = triangle of the mesh)
+  int32_t n_tris;
+  int32_t shade_base;          // first shading record of the mesh in DevScene::m_shade (object-space vertex normals + material id)
+};
+
 struct DevScene {
   int32_t n_spheres; const DevSphere* spheres; const int32_t* sphere_mat;
   int32_t has_cornell;
@@ -77,6 +88,11 @@ struct DevScene {
   // shading data of the closest-hit mesh, one 64-byte record per triangle (by prim index): the three vertex normals and the material id --
   // ONE line fetch per shaded hit instead of five scattered ones (index triple, three normals, material id)
   const float* m_shade;
+  // instanced closest-hit meshes (n_inst > 0; then nodes / tris above are unused and n_tris is the instances' total): a 4-wide tree over
+  // the instances' world boxes (a leaf holds ONE proxy record whose prim is the instance), one tree per mesh in object space
+  int32_t n_inst, inst_shift;
+  const DevInstance* inst;
+  const float* tlas_nodes; const float* tlas_tris; const float* blas_nodes; const float* blas_tris;
   // camera (scene.ads:27-32)
   float cam_pos[3];
   float cam_matrix[16];

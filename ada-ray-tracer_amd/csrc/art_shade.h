@@ -321,6 +321,11 @@ ART_HD void bsdf_eval(const DevMaterial& m, f3 l, f3 v, f3 n, f3& bxdf, float& p
   bxdf = mk3(0.0f, 0.0f, 0.0f); pdf = 1.0f;                       // light / mirror / glass
 }
 
+// shading record of triangle hit index `idx` (art_scene.h KEY_TRI): its own index, or -- instanced scenes -- the record of the mesh's triangle
+ART_HD size_t shade_record(const DevScene& s, uint32_t idx) {
+  if (s.n_inst > 0) return (size_t)s.inst[idx >> s.inst_shift].shade_base + (size_t)(idx & ((1u << s.inst_shift) - 1u));
+  return (size_t)idx;
+}
 // material of rect light `idx` (the flat light's quad, geometry.adb:132-141)
 ART_HD int32_t light_mat(const DevScene& s, const StageCtx& cx, uint32_t idx) { return cx.lds_lights ? cx.lds_lights[idx].mat : (cx.lights ? cx.lights : s.lights)[idx].mat; }
 
@@ -353,6 +358,11 @@ ART_HD Surface surface_at(const DevScene& s, f3 o, f3 d, float t, uint32_t key, 
     } else if (pre.on) {
       sf.normal = (w * pre.a + v * pre.b) + u * pre.c;
       sf.mat_id = -1;                                                          // the caller has the material index from its hint
+    } else if (s.n_inst > 0) {                                                 // instanced scene: the mesh's record, its normals taken to world space
+      const DevInstance& R = s.inst[idx >> s.inst_shift];
+      const float* r = s.m_shade + (size_t)kTriShadeFloats * ((size_t)R.shade_base + (size_t)(idx & ((1u << s.inst_shift) - 1u)));
+      sf.normal = (w * instance_normal(R.minv, ld3(r)) + v * instance_normal(R.minv, ld3(r + 3))) + u * instance_normal(R.minv, ld3(r + 6));
+      sf.mat_id = __builtin_bit_cast(int32_t, r[9]);
     } else {
       const float* r = s.m_shade + (size_t)kTriShadeFloats * (size_t)idx;      // the triangle's own record: normals of A, B, C and the material id
       sf.normal = (w * ld3(r) + v * ld3(r + 3)) + u * ld3(r + 6);
@@ -544,7 +554,7 @@ ART_HD int32_t item_class(const DevScene& s, const DevPaths& qi, int w, const St
   else if (cls == KEY_CORNELL) mat = s.cb_mat[idx];
   else if (cls == KEY_QUAD) mat = light_mat(s, cx, idx);
   else if (cls == KEY_BFTRI) mat = 2;
-  else mat = __builtin_bit_cast(int32_t, s.m_shade[(size_t)kTriShadeFloats * (size_t)idx + 9]);
+  else mat = __builtin_bit_cast(int32_t, s.m_shade[(size_t)kTriShadeFloats * shade_record(s, idx) + 9]);
   if (mat < 0 || mat >= s.n_materials) return CLS_CHEAP;
   const int32_t type = (cx.materials ? cx.materials : s.materials)[mat].type;
   if (hint) { hint->key = key; hint->mat = mat; }
@@ -590,7 +600,7 @@ ART_HD void item_classes(const DevScene& s, const DevPaths& qi, const int (&w)[N
     surf[k] = on[k] && (fl[k] & FLAG_ALIVE) && key[k] != KEY_MISS;
     const uint32_t c = key[k] & ~KEY_INDEX_MASK, idx = key[k] & KEY_INDEX_MASK;
     tri[k] = surf[k] && c == KEY_TRI; sph[k] = surf[k] && c == KEY_SPHERE;
-    m_tri[k] = __builtin_bit_cast(int32_t, shade0[tri[k] ? (size_t)kTriShadeFloats * (size_t)idx + 9 : (size_t)0]);
+    m_tri[k] = __builtin_bit_cast(int32_t, shade0[tri[k] ? (size_t)kTriShadeFloats * shade_record(s, idx) + 9 : (size_t)0]);
     m_sph[k] = smat0[sph[k] ? idx : 0u];
   }
   pin_loads(m_tri); pin_loads(m_sph);
@@ -666,8 +676,12 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     pre_m = (cx.materials ? cx.materials : s.materials)[hinted ? hint_v.mat : 0];
     const bool tri = hinted && !(ART_DIAG_SKIP & 2) && (hint_v.key & ~KEY_INDEX_MASK) == KEY_TRI;
     if (tri || batch) {
-      const float* r = (s.m_shade ? s.m_shade : (const float*)(const void*)s.materials) + (size_t)kTriShadeFloats * (size_t)(tri ? (hint_v.key & KEY_INDEX_MASK) : 0u);
+      const float* r = (s.m_shade ? s.m_shade : (const float*)(const void*)s.materials) + (size_t)kTriShadeFloats * (tri ? shade_record(s, hint_v.key & KEY_INDEX_MASK) : (size_t)0);
       pre_n.a = ld3(r); pre_n.b = ld3(r + 3); pre_n.c = ld3(r + 6); pre_n.on = tri;
+      if (s.n_inst > 0 && tri) {                                 // instanced scene: the record holds object-space normals
+        const DevInstance& R = s.inst[(hint_v.key & KEY_INDEX_MASK) >> s.inst_shift];
+        pre_n.a = instance_normal(R.minv, pre_n.a); pre_n.b = instance_normal(R.minv, pre_n.b); pre_n.c = instance_normal(R.minv, pre_n.c);
+      }
     }
   }
   // the shadow test the item may owe (its words exist for every item; asked for now, used below if the flag says so)

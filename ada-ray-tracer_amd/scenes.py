@@ -4,7 +4,7 @@ C3 (100k triangles), C4 (1M) and C5 (mixed).  Pure numpy; everything is determin
 import numpy as np
 
 from . import (LIGHT_RECT, LIGHT_SPHERE, MAT_GLASS, MAT_LAMBERT, MAT_LIGHT, MAT_MIRROR, MAT_NULL, MAT_PHONG,
-               MESH_CLOSEST, SceneDesc)
+               MESH_CLOSEST, SceneDesc)      # noqa: F401
 
 F = np.float32
 PYRAMID_VSGF = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "data", "pyramid2.vsgf")
@@ -152,6 +152,44 @@ def structured_scene(n_tris=1000000):
     matid = (1 + (np.arange(idx.shape[0]) % 3)).astype(np.int32)
     mesh = dict(mode=MESH_CLOSEST, pos=pos, nrm=nrm, idx=idx, matid=matid)
     return SceneDesc(spheres=spheres, lights=lights, materials=mats, meshes=[mesh], cornell=CORNELL_BOX, cam_pos=REFERENCE_CAMERA)
+
+
+def instanced_scene(n_instances=64, tris_per_mesh=20000, seed=0xADA5EED0 + 64):
+    """Round 5 (embree_connect.cpp:147-184): Cornell walls + the three sphere lights of synthetic_scene + n_instances
+    instances of TWO prototype meshes of about tris_per_mesh triangles each (a torus and a bumpy grid, object space around the origin),
+    every instance under its own rotation, non-uniform scale and translation.  Rendered through the two-level tree without flattening;
+    tests/host_sim's hs_flatten_instances gives the explicit world-space mesh the picture must equal bit for bit."""
+    mats = cornell_materials()
+    mats[4] = dict(type=MAT_LIGHT, light=0)
+    mats.append(dict(type=MAT_LIGHT, light=1)); mats.append(dict(type=MAT_LIGHT, light=2))
+    lights = [sphere_light(-1.5, 4), sphere_light(0.0, 11), sphere_light(1.5, 12)]
+    spheres = [(l["center"], l["radius"], l["mat"]) for l in lights]
+    nv = max(4, int(round((tris_per_mesh / 5.0) ** 0.5))); nu = int(round(2.5 * nv))
+    tor = torus_mesh(nu, nv, R=0.7, r=0.3, centre=(0.0, 0.0, 0.0))
+    m = max(3, int(round((tris_per_mesh / 2) ** 0.5)))
+    g = np.linspace(-1.0, 1.0, m + 1)
+    X, Z = np.meshgrid(g, g, indexing="ij")
+    Y = 0.15 * np.sin(3.0 * X) * np.cos(2.0 * Z)
+    pos = np.stack([X, Y, Z], -1).reshape(-1, 3).astype(F)
+    dydx = 0.45 * np.cos(3.0 * X) * np.cos(2.0 * Z); dydz = -0.3 * np.sin(3.0 * X) * np.sin(2.0 * Z)
+    nrm = np.stack([-dydx, np.ones_like(X), -dydz], -1).reshape(-1, 3); nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(F)
+    i, j = np.meshgrid(np.arange(m), np.arange(m), indexing="ij")
+    a_ = (i * (m + 1) + j).ravel(); b_ = ((i + 1) * (m + 1) + j).ravel(); c_ = (i * (m + 1) + j + 1).ravel(); d_ = ((i + 1) * (m + 1) + j + 1).ravel()
+    idx = np.stack([np.stack([a_, c_, b_], 1), np.stack([b_, c_, d_], 1)], 1).reshape(-1, 3).astype(np.int32)
+    grid = dict(mode=MESH_CLOSEST, pos=pos, nrm=nrm, idx=idx, matid=(1 + (np.arange(idx.shape[0]) % 3)).astype(np.int32))
+    tor["matid"] = np.where(np.arange(tor["idx"].shape[0]) % 7 == 0, 0, 1 + (np.arange(tor["idx"].shape[0]) % 3)).astype(np.int32)      # some Phong (material 0)
+    rng = np.random.default_rng(seed)
+    insts = []
+    for k in range(n_instances):
+        ax, ay, az = rng.random(3) * 2.0 * np.pi
+        Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+        Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+        Rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]])
+        S = np.diag(0.25 + 0.35 * rng.random(3))
+        M = np.zeros((3, 4)); M[:, :3] = Rz @ Ry @ Rx @ S
+        M[:, 3] = [-2.0 + 4.0 * rng.random(), 0.5 + 3.6 * rng.random(), 0.3 + 4.0 * rng.random()]
+        insts.append((k % 2, M.astype(F).ravel()))
+    return SceneDesc(spheres=spheres, lights=lights, materials=mats, meshes=[tor, grid], cornell=CORNELL_BOX, cam_pos=REFERENCE_CAMERA, instances=insts)
 
 
 def mixed_scene(n_tris=20000, config_id=5, extra_spheres=8):

@@ -67,6 +67,9 @@ def build_scene(art, args):
     if args.scene == "s4":
         sd = scenes.structured_scene(args.tris)
         return sd, "S4 (not a BASELINE config): structured meshes, %d triangles (tessellated torus + regular grid) + 3 sphere lights in the Cornell box" % sd.desc.meshes[0].ntris
+    if args.scene == "i64":
+        sd = scenes.instanced_scene(64, 20000)
+        return sd, "I64 (not a BASELINE config): 64 instances of two ~20000-triangle meshes (1.28 M triangles if flattened) + 3 sphere lights in the Cornell box, rendered through the two-level tree"
     if args.scene == "c1":
         return scenes.eight_sphere_scene(), "C1: Cornell-box-style 8-sphere scene"
     return scenes.reference_scene(), "C2: internal Cornell scene with data/pyramid2.vsgf (Scene.Init by the product's host layer)"
@@ -172,7 +175,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="c4", choices=["c1", "c2", "c3", "c4", "c5", "s4"])
+    ap.add_argument("--scene", default="c4", choices=["c1", "c2", "c3", "c4", "c5", "s4", "i64"])
     ap.add_argument("--tris", type=int, default=1000000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -324,6 +327,8 @@ def main():
             # algorithmic bytes per ray of THIS data layout: a node visit reads the node packet once (64 B quantised at
             # width 4, 256 B binary32 at width 8), a triangle test reads a 48-B record, a ray costs 32 B in + 32 B out
             node_bytes = 64.0 if info.node_width == 4 else 256.0
+            if args.scene == "i64":
+                node_bytes = 128.0                          # the two-level search walks binary32 4-wide packets (k_trace_inst)
             bytes_per_ray = node_bytes * NV + 48.0 * T + 64.0
             achieved = rays_dev0 * bytes_per_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
             fp = workload_fingerprint(args, W, H, info, args.opt)
@@ -348,7 +353,7 @@ def main():
                         "traffic": round(traffic, 1) if prof else None,
                         "traffic_note": "FETCH_SIZE x 1.0 + WRITE_SIZE per launch / launch time: random 64-byte node packets and triangle records are counted exactly (profiles/r5_calib/calibration; rounds 1-4 doubled FETCH_SIZE on a calibration of 128-byte gathers the kernel no longer does)" if prof else None,
                         "traffic_source": ("profiles/%s/pmc_summary.json (same source %s, scene, options)" % (PROFILE_TAG, fp["source"])) if prof else None,
-                        "kernel": "k_trace_coop" if args.kernel == "coop" else "k_trace_simple",
+                        "kernel": "k_trace_inst (two-level search, one ray per lane)" if args.scene == "i64" else "k_trace_coop" if args.kernel == "coop" else "k_trace_simple",
                         "bound_evidence": "frac = algorithmic bytes against the HBM peak (the contract's roofline).  What limits the kernel itself is VALU issue: "
                                           "issue = SQ_INSTS_VALU per launch / 1024 SIMDs x the mean issue time of the kernel's own instruction mix (profiles/valu_mix.py x "
                                           "profiles/valu_rate2.hip) / launch time; fabric_frac = bytes past L2 / 8.0 TB/s gather ceiling; both from profiles/%s/pmc_summary.json "
@@ -390,8 +395,10 @@ def main():
                                                 "fold_accumulate": round(fold_ms * 1e-3 / elapsed, 4), "raygen": round(raygen_ms * 1e-3 / elapsed, 4)},
                          "note": "every kernel's algorithmic bytes of the timed steps / the driver-visible wall time / HBM peak"}
         cpu = None
-        if not args.no_cpu and n_gpus == 1:          # timed on rank 0 at N = 1 only
+        if not args.no_cpu and n_gpus == 1 and args.scene != "i64":          # timed on rank 0 at N = 1 only
             cpu = cpu_baseline(art, sd, args, be)
+        elif args.scene == "i64":
+            cpu = {"value": None, "note": "the oracle has no instancing: tests/test_gpu_instanced.py compares with its render of the flattened scene"}
         elif n_gpus > 1:
             cpu = {"value": None, "note": "the CPU leg is timed at N = 1 only (bench contract); see the N = 1 line"}
         value = total_rays / elapsed / 1e6

@@ -77,6 +77,10 @@ typedef struct ArtMesh {
   float bbmin[3], bbmax[3];   /* used by REFERENCE_BF (geometry.adb:273) */
 } ArtMesh;
 
+/* One instance of a mesh (round 5; the reference: gcore_instance_meshes, embree_connect.cpp:147-184 -- RTC_FORMAT_FLOAT3X4_ROW_MAJOR read from
+ * the first 12 floats of a 16-float block, :169).  m: object -> world. */
+typedef struct ArtInstance { int32_t mesh; float m[12]; } ArtInstance;
+
 typedef struct ArtSceneDesc {
   int32_t n_spheres;   const ArtSphere*   spheres;
   int32_t has_cornell;                              /* scene.ads:75-80 */
@@ -85,9 +89,15 @@ typedef struct ArtSceneDesc {
   float   cb_nrm[6][3];
   int32_t n_lights;    const ArtLight*    lights;   /* the reference has exactly one (scene.adb:45-48) */
   int32_t n_materials; const ArtMaterial* materials;
-  int32_t n_meshes;    const ArtMesh*     meshes;   /* at most one per mode */
+  int32_t n_meshes;    const ArtMesh*     meshes;   /* at most one per mode -- unless n_instances > 0 */
   float   cam_pos[3];                               /* scene.ads:27-32 */
   float   cam_matrix[16];                           /* row-major float4x4 */
+  /* Instanced scenes (n_instances > 0): meshes[] are then object-space prototypes, any number of them, every one ART_MESH_CLOSEST, and
+   * the scene's mesh geometry is instances[]: instance i shows mesh instances[i].mesh under its 3x4.  The render loop walks a tree over
+   * the instances and one tree per mesh (memory O(meshes + instances)); the picture is that of the FLATTENED scene, bit for bit --
+   * corners transformed by m (m[0] x + m[1] y + m[2] z + m[3], evaluated left to right in binary32), vertex normals by the inverse
+   * transpose of its 3x3 and normalised, triangles in the order (instance, triangle of the mesh).  Cooperative trace kernel only. */
+  int32_t n_instances; const ArtInstance* instances;
 } ArtSceneDesc;
 
 /* ---- render control --------------------------------------------------------------------------- */

@@ -134,6 +134,19 @@ extern "C" int hs_render(const ArtSceneDesc* sd, const ArtPassParams* p, int w, 
   return 0;
 }
 
+// the explicit flattening of an instanced scene's meshes (art_host_scene.cpp flatten_instances): what an instanced render must equal.
+// Call with null outputs for the sizes (nv, nt in counts2), then with buffers of 3 nv, 3 nv, 3 nt, nt elements.
+extern "C" int hs_flatten_instances(const ArtSceneDesc* sd, float* pos, float* nrm, int32_t* idx, int32_t* matid, long long* counts2) {
+  std::vector<float> p, n; std::vector<int32_t> ix, mi;
+  if (!flatten_instances(*sd, p, n, ix, mi, g_err)) return 1;
+  counts2[0] = (long long)(p.size() / 3); counts2[1] = (long long)mi.size();
+  if (pos) std::memcpy(pos, p.data(), p.size() * 4);
+  if (nrm) std::memcpy(nrm, n.data(), n.size() * 4);
+  if (idx) std::memcpy(idx, ix.data(), ix.size() * 4);
+  if (matid) std::memcpy(matid, mi.data(), mi.size() * 4);
+  return 0;
+}
+
 // BVH of the scene's CLOSEST mesh in the product's packet layout (what art_export_bvh returns on the GPU box)
 extern "C" int hs_bvh(const ArtSceneDesc* sd, float* nodes, long long node_cap, float* tris, long long tri_cap, int* info3 /* n_nodes, n_tris, max_stack, width */) {
   HostScene hs; BvhBuildParams bp = g_bp;

@@ -32,6 +32,20 @@ def pixmap(art, w, h, rank, nranks, tile=32):
     return out[:n].copy()
 
 
+def flattened_copy(art, sd):
+    """the explicit world-space flattening of an instanced art.SceneDesc (the product's flatten_instances through tests/host_sim): a new
+    SceneDesc with ONE ART_MESH_CLOSEST mesh, triangles in the order (instance, triangle of the mesh), and no instances"""
+    L = lib(art)
+    L.hs_flatten_instances.argtypes = [C.POINTER(art.ArtSceneDesc), art.f32p, art.f32p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_longlong)]
+    cnt = (C.c_longlong * 2)()
+    assert L.hs_flatten_instances(C.byref(sd.desc), None, None, None, None, cnt) == 0, L.hs_last_error()
+    nv, nt = int(cnt[0]), int(cnt[1])
+    pos = np.zeros((nv, 3), np.float32); nrm = np.zeros((nv, 3), np.float32); idx = np.zeros((nt, 3), np.int32); matid = np.zeros(nt, np.int32)
+    i32p = C.POINTER(C.c_int32)
+    assert L.hs_flatten_instances(C.byref(sd.desc), pos.ctypes.data_as(art.f32p), nrm.ctypes.data_as(art.f32p), idx.ctypes.data_as(i32p), matid.ctypes.data_as(i32p), cnt) == 0
+    return art.SceneDesc(meshes=[dict(mode=art.MESH_CLOSEST, pos=pos, nrm=nrm, idx=idx, matid=matid)], **sd._kw)
+
+
 def set_fold_dense(art, on):
     """1: the fold over dense per-level records (the GPU's compacted schedule), 0: the slot-indexed fold stack"""
     lib(art).hs_set_fold_dense(int(on))

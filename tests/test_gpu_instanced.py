@@ -1,0 +1,71 @@
+"""Instanced scenes through the C ABI (round 5; SURVEY 8(f) rank 2, embree_connect.cpp:147-184): art_upload_scene takes meshes + 3x4
+instance transforms, art_render_pass walks the two-level tree (k_trace_inst) without flattening, and the picture is the FLATTENED
+scene's, bit for bit.  The reference: the product's own render of the explicitly flattened mesh (itself oracle-checked at this size
+class by tests/test_gpu_stated_spp.py) AND the oracle on sampled pixels, its mesh search walking the flattened scene's exported tree."""
+import numpy as np
+import pytest
+
+import conv
+import hostsim
+import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("rt", ["PT_MIS", "PT_SHADOW", "PT_STUPID"])
+def test_small_instanced_scene_equals_the_oracle_on_the_flattened_scene(art, backend, rt):
+    """12 instances of two ~300-triangle meshes: the oracle's O(N) scan of the flattened mesh, whole frame, every integrator."""
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.instanced_scene(12, 300)
+    flat = hostsim.flattened_copy(art, sd)
+    p = art.Backend.pass_params(getattr(art, rt), True, 8, 2, seed=21)
+    backend.upload_scene(sd); backend.resize(96, 80)
+    accum, _, spp = backend.render_pass(p, 0)
+    rays = backend.stats().rays
+    ref, _, cnt = orc.render(conv.OracleScene(flat).scene, orc.make_params(96, 80, getattr(orc, rt), True, 8, 2, seed=21))
+    assert spp == 8 and rays == cnt.rays and backend.stats().lost_paths == 0
+    assert np.array_equal(bits(accum), bits(ref))
+
+
+def test_64_instances_of_20k_triangles_at_64_spp(art, backend):
+    """The review's case: 64 instances x ~20 k triangles (1.28 M triangles flattened), 640x360, PT_MIS depth 8, 64 spp.  Instanced render ==
+    render of the flattened upload (whole frame, bits), and == the oracle on 300 sampled pixels (its search walks the flattened tree)."""
+    from ada_ray_tracer_amd import scenes
+    W, H, T = 640, 360, 16
+    sd = scenes.instanced_scene(64, 20000)
+    flat = hostsim.flattened_copy(art, sd)
+    assert flat.desc.meshes[0].ntris > 1200000
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, T, seed=5)
+    backend.upload_scene(sd); backend.resize(W, H)
+    inst, _, spp = backend.render_pass(p, 0)
+    rays_inst = backend.stats().rays
+    assert spp == 64 and backend.stats().lost_paths == 0
+    backend.upload_scene(flat); backend.resize(W, H)
+    ref, _, _ = backend.render_pass(p, 0)
+    assert backend.stats().rays == rays_inst
+    assert np.array_equal(bits(inst), bits(ref))
+    osc = conv.OracleScene(flat)
+    nodes, tris, info = backend.export_bvh()
+    osc.attach_bvh(nodes, tris, info.node_width)
+    rng = np.random.default_rng(64)
+    xs = rng.integers(0, W, 300); ys = rng.integers(0, H, 300)
+    oref, _ = orc.render_pixels(osc.scene, orc.make_params(W, H, orc.PT_MIS, True, 8, T, seed=5), xs, ys)
+    assert np.array_equal(bits(inst[ys, xs]), bits(oref))
+    assert (oref.sum(1) > 0).mean() > 0.3
+
+
+def test_instanced_scene_needs_the_record_schedule(art, backend):
+    """the one-ray-per-lane cross-check kernel walks a single tree: an instanced scene is refused there, with a message"""
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.instanced_scene(4, 100)
+    backend.upload_scene(sd); backend.resize(32, 32)
+    backend.set_option("trace_kernel", art.TRACE_SIMPLE)
+    try:
+        with pytest.raises(art.ArtError, match="instanced"):
+            backend.render_pass(art.Backend.pass_params(art.PT_MIS, True, 4, 1, seed=1), 0)
+    finally:
+        backend.set_option("trace_kernel", art.TRACE_COOP)

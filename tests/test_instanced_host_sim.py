@@ -1,0 +1,43 @@
+"""Instanced scenes (round 5; embree_connect.cpp:147-184): the product's two-level search (a tree over the instances, one tree per mesh walked
+with the ray in object space, triangles tested in world space) must give the picture of the explicitly FLATTENED scene, bit for bit.
+CPU side: the product's device functions compiled for the host (tests/host_sim) against the oracle's render of the flattened scene; the
+-m gpu twin (tests/test_gpu_instanced.py) repeats it through the C ABI."""
+import numpy as np
+import pytest
+
+import conv
+import hostsim
+import orc
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("rt", ["PT_MIS", "PT_SHADOW", "PT_STUPID"])
+def test_instanced_scene_equals_the_oracle_on_the_flattened_scene(art, rt):
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.instanced_scene(12, 300)                       # 12 instances of two ~300-triangle meshes: rotated, non-uniformly scaled, translated
+    flat = hostsim.flattened_copy(art, sd)
+    assert flat.desc.n_instances == 0 and flat.desc.meshes[0].ntris == sum(sd.desc.meshes[sd.desc.instances[i].mesh].ntris for i in range(12))
+    p = art.Backend.pass_params(getattr(art, rt), True, 6, 2, seed=21)
+    acc, rays = hostsim.render(art, sd, p, 56, 44)             # the two-level search
+    osc = conv.OracleScene(flat)
+    ref, _, cnt = orc.render(osc.scene, orc.make_params(56, 44, getattr(orc, rt), True, 6, 2, seed=21))      # the oracle's O(N) scan of the flattened mesh
+    assert rays == cnt.rays
+    assert np.array_equal(bits(acc), bits(ref))
+    acc2, rays2 = hostsim.render(art, flat, p, 56, 44)        # and the product's own render of the flattened mesh
+    assert rays2 == rays and np.array_equal(bits(acc2), bits(ref))
+    assert float(np.abs(acc).sum()) > 0.0
+
+
+def test_instanced_scene_rejects_what_it_cannot_hold(art):
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.instanced_scene(4, 100)
+    sd.instances[1].m = (np.ctypeslib.ctypes.c_float * 12)(*([0.0] * 12))                                   # a singular matrix
+    acc = np.zeros((8, 8, 3), np.float32)
+    import ctypes as C
+    rays = C.c_uint64(0)
+    p = art.Backend.pass_params(art.PT_MIS, True, 2, 1, seed=1)
+    rc = hostsim.lib(art).hs_render(C.byref(sd.desc), C.byref(p), 8, 8, 0, acc.ctypes.data_as(art.f32p), C.byref(rays))
+    assert rc != 0 and b"singular" in hostsim.lib(art).hs_last_error()
