@@ -111,7 +111,7 @@ static int upload_scene_arrays(HostScene& hs) {
       upload(c.b_bf_uv, hs.bf_uv) || upload(c.b_bf_idx, hs.bf_idx) || (!hs.gpu_built && upload(c.b_nodes, hs.bvh.nodes)) || (!hs.gpu_built && upload(c.b_qnodes, hs.bvh.qnodes)) ||
       (!hs.gpu_built && upload(c.b_tris, hs.bvh.tris)) || upload(c.b_m_shade, hs.m_shade))
     return 1;
-  if (hs.hdr.n_inst > 0 && (upload(c.b_inst, hs.inst) || upload(c.b_tlas_nodes, hs.two.tlas.nodes) || upload(c.b_tlas_tris, hs.two.tlas.tris) ||
+  if (hs.hdr.n_inst > 0 && (upload(c.b_inst, hs.inst) || upload(c.b_qnodes, hs.two.qnodes) || upload(c.b_tlas_nodes, hs.two.tlas.nodes) || upload(c.b_tlas_tris, hs.two.tlas.tris) ||
                             upload(c.b_blas_nodes, hs.two.blas_nodes) || upload(c.b_blas_tris, hs.two.blas_tris)))
     return 1;
   DevScene& s = c.scene;
@@ -174,6 +174,11 @@ int upload_scene(const ArtSceneDesc* d) {
     if (hs.hdr.node_width == 4 && hs.hdr.n_tris > 0 && hs.hdr.n_inst == 0) {       // 64-byte padded copy of the triangle records for the 4-wide kernel
       if (ensure(c.b_qtris, (size_t)hs.hdr.n_tris * kQTriBytes)) return 1;
       launch_pad_tris(c.stream, (const float*)c.b_tris.p, (float*)c.b_qtris.p, hs.hdr.n_tris);
+      HIP_TRY(hipStreamSynchronize(c.stream));
+    } else if (hs.hdr.n_inst > 0) {                      // instanced scene: the meshes' object-space records, padded the same way
+      const int nrec = (int)(hs.two.blas_tris.size() / kTriFloats);
+      if (ensure(c.b_qtris, (size_t)nrec * kQTriBytes)) return 1;
+      launch_pad_tris(c.stream, (const float*)c.b_blas_tris.p, (float*)c.b_qtris.p, nrec);
       HIP_TRY(hipStreamSynchronize(c.stream));
     }
     c.bvh_stack_bound = std::max(8, dev_stack);
@@ -314,7 +319,8 @@ static int coop_grid() {
 
 static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
   Ctx& c = g_ctx;
-  a.n_rays = n_rays; a.width = c.scene.node_width; a.instanced = c.scene.n_inst > 0 ? 1 : 0;
+  a.n_rays = n_rays; a.width = c.scene.node_width; a.instanced = c.scene.n_inst > 0 ? (c.inst_coop ? 1 : 2) : 0;
+  a.inst = c.scene.inst; a.inst_shift = c.scene.inst_shift;
   { int e; bool o; stack_plan(c.trace_kernel, e, o); a.stack_entries = e; a.stack_overflow = o ? 1 : 0; }
   a.node_min = c.node_min; a.refill_min = c.refill_min; a.segments = c.queue_segments; a.chunk = c.ray_chunk;
   a.ray_ox = q.ray_ox; a.ray_oy = q.ray_oy; a.ray_oz = q.ray_oz; a.ray_dx = q.ray_dx; a.ray_dy = q.ray_dy; a.ray_dz = q.ray_dz; a.ray_tfar = q.ray_tfar;
@@ -845,7 +851,7 @@ int art_init_devices(int32_t n, const int32_t* ordinals) {
     Ctx& c = g_devs[k];
     c = Ctx();
     c.trace_kernel = opts.trace_kernel; c.batch_paths = opts.batch_paths; c.bvh_params = opts.bvh_params; c.node_min = opts.node_min; c.refill_min = opts.refill_min;
-    c.queue_segments = opts.queue_segments; c.ray_chunk = opts.ray_chunk; c.shadow_anyhit = opts.shadow_anyhit; c.shade_split = opts.shade_split; c.lds_stack_cap = opts.lds_stack_cap;
+    c.queue_segments = opts.queue_segments; c.ray_chunk = opts.ray_chunk; c.shadow_anyhit = opts.shadow_anyhit; c.shade_split = opts.shade_split; c.inst_coop = opts.inst_coop; c.lds_stack_cap = opts.lds_stack_cap;
     c.opt_blocks_per_cu = opts.opt_blocks_per_cu; c.count_tests = opts.count_tests;
     c.device = ord[k]; c.rank = k; c.nranks = n; c.tile = 32;
     if (use_dev(k) || ensure_device()) { shutdown(); return 1; }
@@ -1022,6 +1028,7 @@ static int set_option_one(const std::string& n, int64_t value) {
   else if (n == "count_tests") { g_ctx.count_tests = value != 0; }
   else if (n == "shadow_anyhit") { g_ctx.shadow_anyhit = value != 0; }
   else if (n == "shade_split") { g_ctx.shade_split = value != 0; }
+  else if (n == "inst_coop") { g_ctx.inst_coop = value != 0; }
   else if (n == "ray_chunk") { if (value < 16 || value > 4096 || (value & 15)) return fail("ray_chunk: a multiple of 16, 16..4096"); g_ctx.ray_chunk = (int)value; }
   else if (n == "refill_min") { if (value < 1 || value > 8) return fail("refill_min: 1..8"); g_ctx.refill_min = (int)value; }
   else if (n == "node_min") { if (value < 1 || value > 8) return fail("node_min: 1..8"); g_ctx.node_min = (int)value; }

@@ -52,6 +52,7 @@ struct Ctx {
   int queue_segments = 8;       // the live-ray queue is cut into this many contiguous segments, one per XCD (1 = a single cursor)
   int ray_chunk = 48;            // trace records a wave claims per atomic (and prefetches): 16 -> 48 is worth 1 % on C4, 4 % on C3, 10 % on C5 (the claim stalls the wave)
   bool shadow_anyhit = true;   // shadow rays use the visibility rule instead of a full closest-hit search (same decision)
+  bool inst_coop = true;       // instanced scenes: the cooperative kernel crosses the instance boundary (k_trace_coop<.., INST>); false: k_trace_inst, one ray per lane (A/B, cross-check)
   bool shade_split = false;    // k_shade_compact as one instantiation per register class (light materials / deferred heavy ones); false: the round-4 kernel with every material (A/B)
   // timing
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;

@@ -95,12 +95,12 @@ bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& o
       const InstRec& R = out.two.inst[(size_t)i];                 // (one-sided builds keep every instance: index = the caller's)
       DevInstance& D = out.inst[(size_t)i];
       std::memcpy(D.m, d.instances[i].m, 48); std::memcpy(D.minv, R.minv, 48);
-      D.node_base = R.node_base; D.tri_base = R.tri_base; D.n_tris = R.n_tris; D.shade_base = shade_base[(size_t)R.mesh];
+      D.node_base = R.node_base; D.tri_base = R.tri_base; D.qroot = (uint32_t)out.two.qnode_base[(size_t)R.mesh] * (uint32_t)kQNodeBytes; D.shade_base = shade_base[(size_t)R.mesh];
       total += R.n_tris;
     }
     if (total >= (1ll << 31)) { err = "scene: too many instanced triangles"; return false; }
     h.n_inst = d.n_instances; h.inst_shift = shift; h.n_tris = (int32_t)total; h.n_nodes = out.two.tlas.n_nodes; h.node_width = 4;
-    out.bvh.width = 4; out.bvh.max_stack = std::max(out.two.tlas.max_stack, 8);
+    out.bvh.width = 4; out.bvh.max_stack = std::max(out.two.tlas.max_stack + 1 + out.two.blas_max_stack, 8);      // instance tree + the "leave" marker + a mesh's tree on one stack
     out.bvh.n_nodes = out.two.tlas.n_nodes + (int32_t)(out.two.blas_nodes.size() / node_floats(4)); out.bvh.n_tris = (int32_t)total;      // (art_export_bvh's info: the two-level tree's sizes)
     return true;
   }

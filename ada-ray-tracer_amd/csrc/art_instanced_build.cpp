@@ -5,6 +5,7 @@
 #include <array>
 #include <cmath>
 #include <cstring>
+#include <utility>
 
 namespace art {
 
@@ -31,6 +32,7 @@ bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vect
   const size_t nm = meshes.size();
   std::vector<int32_t> node_base(nm, 0), tri_base(nm, 0), ntris(nm, 0);
   std::vector<std::array<float, 6>> mesh_box(nm);
+  std::vector<std::vector<uint32_t>> mesh_q;             // one-sided builds: every mesh's quantised nodes, relocated below
   for (size_t mi = 0; mi < nm; ++mi) {
     const InstMeshIn& m = meshes[mi];
     if (m.n_tris == 0 || m.n_verts == 0) { err = "empty mesh"; return false; }
@@ -48,6 +50,8 @@ bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vect
     // instanced_closest walks a mesh tree with bvh_closest's private stack of kStackEntries entries and pushes unchecked (like the
     // flattened upload, which art_upload_scene refuses for the same reason)
     if (b.max_stack > kStackEntries) { err = "mesh tree stack bound " + std::to_string(b.max_stack) + " exceeds " + std::to_string(kStackEntries); return false; }
+    if (!two_sided) mesh_q.push_back(b.qnodes);
+    T.blas_max_stack = std::max(T.blas_max_stack, b.max_stack);
     node_base[mi] = (int32_t)(T.blas_nodes.size() / node_floats(4));
     tri_base[mi] = (int32_t)(T.blas_tris.size() / kTriFloats);
     ntris[mi] = b.n_tris;
@@ -90,6 +94,67 @@ bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vect
   BvhBuildParams tp; tp.width = 4; tp.max_leaf = 1;
   if (!build_bvh8(proxy9.data(), proxy_id.data(), (int32_t)proxy_id.size(), tp, T.tlas, err)) return false;
   if (T.tlas.max_stack > kInstTopStack) { err = "instance tree stack bound " + std::to_string(T.tlas.max_stack) + " exceeds " + std::to_string(kInstTopStack); return false; }
+  if (!two_sided) {
+    // ---- the cooperative kernel's form: ONE array of quantised nodes, entry words absolute
+    if (T.tlas.qnodes.empty()) { err = "instance tree has no quantised nodes"; return false; }
+    const size_t words = kQNodeBytes / 4;
+    size_t total_nodes = (size_t)T.tlas.n_nodes;
+    T.qnode_base.assign(nm, 0);
+    for (size_t mi = 0; mi < nm; ++mi) { T.qnode_base[mi] = (int32_t)total_nodes; total_nodes += mesh_q[mi].size() / words; }
+    if (total_nodes * kQNodeBytes >= (1ull << 31) || T.blas_tris.size() / kTriFloats * (size_t)kQTriBytes >= (1ull << 31)) { err = "instanced scene too large for 31-bit node / triangle offsets"; return false; }
+    T.qnodes.assign(total_nodes * words, 0u);
+    std::memcpy(T.qnodes.data(), T.tlas.qnodes.data(), T.tlas.qnodes.size() * 4);
+    for (int32_t n = 0; n < T.tlas.n_nodes; ++n)
+      for (int j = 0; j < 4; ++j) {
+        uint32_t& e = T.qnodes[(size_t)n * words + 4 * (size_t)j + 2];
+        if (e == kQEntryEmpty || !(e & kQEntryLeaf)) continue;                   // inner entries: the instance tree sits at node 0
+        const uint32_t tri = (e & 0x7ffffff0u) / (uint32_t)kQTriBytes;            // (max_leaf = 1: one proxy per leaf)
+        const int32_t inst = __builtin_bit_cast(int32_t, T.tlas.tris[(size_t)tri * kTriFloats + 9]);
+        e = kQEntryLeaf | ((uint32_t)inst << 4) | kQCountInstance;
+      }
+    for (size_t mi = 0; mi < nm; ++mi) {
+      const std::vector<uint32_t>& q = mesh_q[mi];
+      uint32_t* dst = &T.qnodes[(size_t)T.qnode_base[mi] * words];
+      std::memcpy(dst, q.data(), q.size() * 4);
+      for (size_t n = 0; n < q.size() / words; ++n)
+        for (int j = 0; j < 4; ++j) {
+          uint32_t& e = dst[n * words + 4 * (size_t)j + 2];
+          if (e == kQEntryEmpty) continue;
+          if (e & kQEntryLeaf) e = kQEntryLeaf | ((e & 0x7ffffff0u) + (uint32_t)tri_base[mi] * (uint32_t)kQTriBytes) | (e & 15u);
+          else e = e + (uint32_t)T.qnode_base[mi] * (uint32_t)kQNodeBytes;
+        }
+    }
+    // The cooperative kernel follows these entry words without a check: a word that led back into a tree already entered would make a
+    // ray walk for ever (a GPU hang, not a wrong pixel).  So the array is walked here once, as the kernel would: every node reached exactly
+    // once, the instance tree's nodes only from the instance tree, a mesh's nodes only from that mesh's root, every leaf inside its
+    // mesh's triangle records, every instance marker naming a valid instance.
+    std::vector<uint8_t> seen(total_nodes, 0);
+    std::vector<std::pair<uint32_t, int32_t>> todo;      // (node, owner: -1 instance tree, else mesh)
+    todo.emplace_back(0u, -1);
+    for (size_t mi = 0; mi < nm; ++mi) todo.emplace_back((uint32_t)T.qnode_base[mi], (int32_t)mi);
+    while (!todo.empty()) {
+      const auto [n, owner] = todo.back(); todo.pop_back();
+      const size_t lo = owner < 0 ? 0 : (size_t)T.qnode_base[(size_t)owner];
+      const size_t hi = owner < 0 ? (size_t)T.tlas.n_nodes : (((size_t)owner + 1 < nm) ? (size_t)T.qnode_base[(size_t)owner + 1] : total_nodes);
+      if (n < lo || n >= hi || seen[n]) { err = "internal: two-level node array is not a forest (node " + std::to_string(n) + ")"; return false; }
+      seen[n] = 1;
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t e = T.qnodes[(size_t)n * words + 4 * (size_t)j + 2];
+        if (e == kQEntryEmpty) continue;
+        if (e & kQEntryLeaf) {
+          const uint32_t cnt = e & 15u, off = e & 0x7ffffff0u;
+          if (owner < 0) { if (cnt != kQCountInstance || (off >> 4) >= T.inst.size()) { err = "internal: bad instance marker in the instance tree"; return false; } }
+          else {
+            const size_t first = off / (size_t)kQTriBytes, base = (size_t)tri_base[(size_t)owner];
+            if (cnt < 1 || cnt > 4 || (off % kQTriBytes) != 0 || first < base || first + cnt > base + (size_t)ntris[(size_t)owner]) { err = "internal: bad leaf in a mesh's tree"; return false; }
+          }
+        } else {
+          if (e % kQNodeBytes) { err = "internal: misaligned node entry"; return false; }
+          todo.emplace_back(e / (uint32_t)kQNodeBytes, owner);
+        }
+      }
+    }
+  }
   return true;
 }
 

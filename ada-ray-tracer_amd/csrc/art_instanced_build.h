@@ -5,6 +5,7 @@
 #include <vector>
 #include "art_bvh.h"
 #include "art_instanced.h"
+#include "art_qnode.h"
 
 namespace art {
 
@@ -16,6 +17,11 @@ struct TwoLevelHost {
   std::vector<int32_t> inst_src;        // inst[k] is the caller's instance inst_src[k]
   Bvh8 tlas;                            // 4-wide tree over one proxy triangle per instance (its corners span the padded world box)
   std::vector<float> blas_nodes, blas_tris;
+  // one-sided (render) builds: the whole two-level tree as ONE array of 64-byte quantised nodes for the cooperative trace kernel
+  // (art_qnode.h): the instance tree first (its leaves rewritten to instance markers, kQEntryInstance), then every mesh's tree with its
+  // entry words made absolute (node offsets + qnode_base[mesh], triangle offsets + the mesh's tri_base).  qnode_base: first node per mesh.
+  std::vector<uint32_t> qnodes; std::vector<int32_t> qnode_base;
+  int32_t blas_max_stack = 0;           // the largest worst-case traversal stack of the meshes' trees
   InstScene view() const {
     InstScene S;
     S.tlas_nodes = tlas.nodes.data(); S.tlas_tris = tlas.tris.data(); S.blas_nodes = blas_nodes.data(); S.blas_tris = blas_tris.data();

@@ -13,7 +13,7 @@ struct TraceArgs {
   int32_t n_rays;
   int32_t stack_entries;        // per-ray LDS stack depth; >= Bvh8::max_stack unless stack_overflow
   int32_t width;                // node width = lanes per ray in k_trace_coop (8 or 4)
-  int32_t instanced;            // DevScene::n_inst > 0: launch_trace runs k_trace_inst (two-level search, one ray per lane) over the records
+  int32_t instanced;            // DevScene::n_inst > 0: 1 = k_trace_coop<.., INST> walks the two-level tree (qnodes = art_instanced_build.cpp's array), 2 = k_trace_inst (one ray per lane; option inst_coop = 0)
   int32_t stack_overflow;       // the LDS stack is smaller than the tree's bound: pushes are checked, rays that do not fit go to ovf_queue
   int32_t segments;             // k_trace_coop: the queue is cut into this many contiguous segments (1, 2, 4, 8); workgroup b starts
                                 // in segment b % segments (its XCD) and moves on to the next segment when that one is drained
@@ -27,6 +27,7 @@ struct TraceArgs {
   // sh_min[i - shadow_begin] = 10*eps.  nullptr: every ray is a closest-hit query.
   const float* sh_min; int32_t shadow_begin;
   DevHit* hit;
+  const DevInstance* inst; int32_t inst_shift;   // instanced scene (k_trace_coop<.., INST>): the instance table; a hit's key index = instance << inst_shift | triangle
   float* sh_t;                  // record schedule: a record whose hit-slot word has kShadowWord set leaves its result as ONE float, sh_t[word & ~kShadowWord] = t of the hit (DevPaths::sh_t)
   const float* nodes; const uint32_t* qnodes; const float* tris; const float* qtris; int32_t n_tris;   // qnodes: 64-byte quantised nodes (width 4, art_qnode.h)   // BVH of the closest-hit mesh (hot-loop operands)
   int32_t chunk;                // trace records a wave claims per atomic on the cursor (a multiple of 16: prefetched 16 records per load)

@@ -207,8 +207,16 @@ __device__ __forceinline__ uint32_t key_masked(mask_t hit, uint32_t tmn_bits, ui
 // entry is { child entry word, bits(tmin) }: the entry word is the node's byte offset (inner child) or 0x80000000 | triangle byte
 // offset | count (leaf), exactly as stored in the node, so a pop needs no decoding.  G = 8 walks the binary32 256-byte nodes; its
 // entry word is (ref << 4) | count.
-template <bool STATS, int G, bool OVF>
+// INST (round 5, G = 4): the quantised node array holds a TWO-LEVEL tree (art_instanced_build.cpp: the instance tree first, then every mesh's
+// tree in object space, entry words absolute).  A leaf entry with count 15 names an instance: the group takes its ray into the mesh's
+// space (inv, noi and the plane selectors are replaced; o and d stay the world ray), pushes a "leave" marker (count 14) and goes on
+// with the mesh's root; popped, the marker restores the world-space inv / noi / selectors from the ray's trace record.  t means the same in
+// both spaces (the direction is not renormalised), so stack entries and the running bound carry over.  A mesh triangle is tested in WORLD
+// space -- its corners through the instance's matrix with xform_point's arithmetic, the reference's Moeller-Trumbore on the world ray --
+// so t, u, v are the flattened scene's, bit for bit; key index = instance << inst_shift | triangle of the mesh.
+template <bool STATS, int G, bool OVF, bool INST = false>
 __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(const DevScene* __restrict__ Sp, const TraceArgs A) {
+  static_assert(!INST || G == 4, "instanced scenes walk the 4-wide quantised nodes");
   extern __shared__ uint2 lds_stack[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int NG = 64 / G;                                   // ray groups per wave
@@ -241,7 +249,8 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
   constexpr uint32_t kSaBias = (ART_EXECM & 8) ? 8u : 0u;      // the stack pointer register holds sb + 8 sp + kSaBias (bit 3: the address of the top entry itself)
   const uint32_t se = sb + kSaBias;                            // its value for an empty stack
   uint32_t sa = se; int ray = 0;
-  int rec_i = 0;                                      // OVF: the ray's record, for k_trace_overflow
+  int rec_i = 0;                                      // OVF / INST: the ray's record (k_trace_overflow; the world-space state to restore on leaving an instance)
+  int cur_inst = -1;                                  // INST: the instance whose mesh the ray is in (-1: the instance tree, world space)
   f3 o = mk3(0, 0, 0), d = o, inv = o, noi = o;
   float best_t = 0.0f; uint32_t best_key = KEY_MISS;
   uint32_t pend = 0;                                  // the popped entry word
@@ -295,7 +304,8 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         best_t = r0.w; best_key = __builtin_bit_cast(uint32_t, r1.w); shm = r2.w;
         sel_near = __builtin_bit_cast(uint32_t, r3.x); sel_far = 0x18070503u - sel_near;      // per byte: near + far = 3, 5, 7, 0x18 (0x0c + 0x0c)
         ray = __builtin_bit_cast(int, r3.y); far_found = __builtin_bit_cast(uint32_t, r3.z) != 0u;
-        if (OVF) rec_i = chunk_pos + my_rank;
+        if (OVF || INST) rec_i = chunk_pos + my_rank;
+        if (INST) cur_inst = -1;
         held_key = KEY_MISS;
         sa = se; pend = 0u;                                       // entry word 0 = root node (both encodings)
       }
@@ -431,7 +441,8 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
     if (want_leaf != 0) {
       const bool wl = lane_of(want_leaf);
       const int cnt = (int)(pend & 15u);
-      const bool tri_lane = wl && (j < cnt);
+      const bool special = INST && wl && (cnt >= (int)kQCountLeaveInstance);        // an instance to enter (15) or its "leave" marker (14): no triangles
+      const bool tri_lane = wl && !special && (j < cnt);
       const uint32_t tbase = (G == 4) ? (pend & 0x7ffffff0u) : (pend >> 4) * (uint32_t)kTriBytes;
       // only the lanes that hold a triangle load (about 12 of 64): the other lanes' result is masked anyway
       float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q1 = q0, q2 = q0;
@@ -442,10 +453,21 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         q2 = *reinterpret_cast<const float4*>(tris_b + toff + 32u);
       }
       float tt, uu, vv;
-      const bool pass = tri_raw(o, d, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x), tt, uu, vv);
+      f3 tA = mk3(q0.x, q0.y, q0.z), tB = mk3(q0.w, q1.x, q1.y), tC = mk3(q1.z, q1.w, q2.x);
+      uint32_t key_hi = KEY_TRI;
+      if (INST) {                                          // the mesh's triangle in world space: the flattening's own arithmetic (xform_point)
+        if (tri_lane) {
+          const char* const ib = reinterpret_cast<const char*>(A.inst) + (size_t)(uint32_t)cur_inst * sizeof(DevInstance);
+          const float4 m0 = *reinterpret_cast<const float4*>(ib), m1 = *reinterpret_cast<const float4*>(ib + 16), m2 = *reinterpret_cast<const float4*>(ib + 32);
+          const float mm[12] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w};
+          tA = xform_point(mm, tA); tB = xform_point(mm, tB); tC = xform_point(mm, tC);
+          key_hi = KEY_TRI | ((uint32_t)cur_inst << A.inst_shift);
+        }
+      }
+      const bool pass = tri_raw(o, d, tA, tB, tC, tt, uu, vv);
       const bool valid = tri_lane && pass && (tt > 0.0f) && (tt < 1000000.0f);
       const uint32_t tb = valid ? __builtin_bit_cast(uint32_t, tt) : 0x7f7fffffu;
-      const uint32_t key = valid ? (KEY_TRI | (uint32_t)__builtin_bit_cast(int, q2.y)) : KEY_MISS;
+      const uint32_t key = valid ? (key_hi | (uint32_t)__builtin_bit_cast(int, q2.y)) : KEY_MISS;
       // lexicographic (t, key) minimum as two 32-bit reductions: smallest t, then smallest key among the lanes holding it
       const uint32_t win_tb = group_min_u32_g<G>(tb);
       const uint32_t win_key = group_min_u32_g<G>(tb == win_tb ? key : 0xffffffffu);
@@ -472,8 +494,44 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
       }
       const bool mine = accept && valid && (key == (uint32_t)win);
       held_key = mine ? key : held_key; held_u = mine ? uu : held_u; held_v = mine ? vv : held_v;
-      pend_valid &= ~want_leaf;
-      if (STATS) { st_tri += tri_lane; st_leaf += (wl && j == 0); st_it_leaf += (lane == 0); }
+      mask_t entered = 0;                                  // groups that go on with a mesh's root: their popped entry stays valid
+      if (INST) {
+        const mask_t sp_mask = ballot64(special);
+        if (sp_mask != 0) {                                // rare next to node steps: a few instances per ray
+          bool enter = special && (cnt == (int)kQCountInstance);
+          if (enter) {
+            const uint32_t ii = (pend >> 4) & 0x07ffffffu;
+            const char* const ib = reinterpret_cast<const char*>(A.inst) + (size_t)ii * sizeof(DevInstance);
+            const float4 w0 = *reinterpret_cast<const float4*>(ib + 48), w1 = *reinterpret_cast<const float4*>(ib + 64), w2 = *reinterpret_cast<const float4*>(ib + 80);
+            const uint4 wi = *reinterpret_cast<const uint4*>(ib + 96);
+            const float mi[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+            const f3 oo = xform_point(mi, o), dd = mk3(mi[0] * d.x + mi[1] * d.y + mi[2] * d.z, mi[4] * d.x + mi[5] * d.y + mi[6] * d.z, mi[8] * d.x + mi[9] * d.y + mi[10] * d.z);
+            const uint32_t top = sa + 8u;
+            if (OVF && top > slimit + kSaBias) {           // the marker does not fit the capped stack: the ray moves to k_trace_overflow
+              if (j == 0) A.ovf_queue[atomicAdd(A.ovf_count, 1)] = rec_i;
+              enter = false;
+            } else {
+              slab_setup(oo, dd, inv, noi);
+              const uint32_t sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+              sel_near = (sx ? 3u : 0u) | ((sy ? 4u : 1u) << 8) | ((sz ? 5u : 2u) << 16) | 0x0c000000u; sel_far = 0x18070503u - sel_near;
+              lds_store(sa + (16u - kSaBias), make_uint2(kQEntryLeaveInstance, 0u));      // under the mesh's tree: popped when that tree is done
+              sa = top;
+              cur_inst = (int)ii;
+              pend = wi.z;                                 // DevInstance::qroot: the mesh's root, an inner entry
+            }
+          } else if (special) {                            // the "leave" marker: back to world space, from the ray's own trace record
+            const char* const rb = reinterpret_cast<const char*>(A.rec) + (size_t)rec_i * (size_t)kTraceRecBytes;
+            const float4 r2 = *reinterpret_cast<const float4*>(rb + 32); const float selw = *reinterpret_cast<const float*>(rb + 48);
+            inv = mk3(r2.x, r2.y, r2.z); noi = mk3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+            sel_near = __builtin_bit_cast(uint32_t, selw); sel_far = 0x18070503u - sel_near;
+            cur_inst = -1;
+          }
+          entered = ballot64(enter);
+          if (OVF) { const mask_t gone = ballot64(special && (cnt == (int)kQCountInstance) && !enter); if (gone != 0) { has_ray &= ~gone; sa = lane_of(gone) ? se : sa; } }
+        }
+      }
+      pend_valid &= ~(want_leaf & ~entered);
+      if (STATS) { st_tri += tri_lane; st_leaf += (wl && !special && j == 0); st_it_leaf += (lane == 0); }
     }
   }
   if (STATS) {
@@ -502,7 +560,8 @@ __global__ __launch_bounds__(256) void k_trace_overflow(const DevScene* __restri
     BvhStats st = {0, 0, 0, 0};
     Cand best; best.t = r0.w; best.key = __builtin_bit_cast(uint32_t, r1.w); best.u = 0.0f; best.v = 0.0f;
     ShadowState sh; sh.shm = r2.w; sh.far = far0; sh.rep = best;
-    bvh_closest<STATS>(S, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), best, &st, sh);
+    if (S.n_inst > 0) instanced_render_closest<STATS>(S, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), best, &st, sh);      // (instanced scene: the two-level search)
+    else bvh_closest<STATS>(S, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), best, &st, sh);
     const bool word = i < 0;                                   // kShadowWord: the result is one float (DevPaths::sh_t)
     const uint32_t wi = (uint32_t)i & ~kShadowWord;
     if (best.key != KEY_MISS && (best.key & ~KEY_INDEX_MASK) == KEY_TRI) { if (word) A.sh_t[wi] = best.t; else A.hit[i] = DevHit{best.t, best.key, best.u, best.v}; }
@@ -1293,13 +1352,22 @@ void launch_trace(hipStream_t st, const DevScene* S, const TraceArgs& A, int ker
     return;
   }
   if (A.n_tris <= 0) return;                       // no BVH mesh: the analytic pass (launch_analytic) is the whole search
-  if (A.instanced) {                               // instanced scene: the two-level kernel (one ray per lane) over the same records
+  if (A.instanced == 2) {                          // instanced scene, option inst_coop = 0: the two-level kernel with one ray per lane over the same records
     const int blocks = std::max(1, std::min(grid_blocks * 4, 65535));
     if (stats) hipLaunchKernelGGL(k_trace_inst<true>, dim3(blocks), dim3(256), 0, st, S, A);
     else hipLaunchKernelGGL(k_trace_inst<false>, dim3(blocks), dim3(256), 0, st, S, A);
     return;
   }
   const size_t lds = trace_coop_lds_bytes(A.stack_entries, A.width);
+  if (A.instanced == 1) {                          // instanced scene: the cooperative kernel crosses the instance boundary itself
+    if (stats) { if (A.stack_overflow) hipLaunchKernelGGL((k_trace_coop<true, 4, true, true>), dim3(grid_blocks), dim3(256), lds, st, S, A); else hipLaunchKernelGGL((k_trace_coop<true, 4, false, true>), dim3(grid_blocks), dim3(256), lds, st, S, A); }
+    else { if (A.stack_overflow) hipLaunchKernelGGL((k_trace_coop<false, 4, true, true>), dim3(grid_blocks), dim3(256), lds, st, S, A); else hipLaunchKernelGGL((k_trace_coop<false, 4, false, true>), dim3(grid_blocks), dim3(256), lds, st, S, A); }
+    if (A.stack_overflow) {
+      if (stats) hipLaunchKernelGGL(k_trace_overflow<true>, dim3(64), dim3(256), 0, st, S, A);
+      else hipLaunchKernelGGL(k_trace_overflow<false>, dim3(64), dim3(256), 0, st, S, A);
+    }
+    return;
+  }
   const int variant = (stats ? 4 : 0) | (A.width == 4 ? 2 : 0) | (A.stack_overflow ? 1 : 0);
   switch (variant) {
     case 0: hipLaunchKernelGGL((k_trace_coop<false, 8, false>), dim3(grid_blocks), dim3(256), lds, st, S, A); break;

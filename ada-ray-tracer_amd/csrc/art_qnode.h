@@ -28,6 +28,10 @@ namespace art {
 
 constexpr int kQNodeBytes = 64;
 constexpr uint32_t kQEntryEmpty = 0x80000000u, kQEntryLeaf = 0x80000000u;
+// instanced scenes (k_trace_coop<.., INST = true>): a leaf entry whose count field is 15 names an INSTANCE (index in bits 4..30) -- the ray
+// enters its mesh's tree there; count 14 is the marker the kernel pushes under that tree: popped, the ray is back in world space
+constexpr uint32_t kQCountInstance = 15u, kQCountLeaveInstance = 14u;
+constexpr uint32_t kQEntryLeaveInstance = kQEntryLeaf | kQCountLeaveInstance;
 constexpr int kTriBytes = kTriFloats * 4;
 constexpr int kQTriBytes = 64;       // the 4-wide kernel reads triangle records padded to 64 bytes: a record never straddles a 128-byte L2 line
 

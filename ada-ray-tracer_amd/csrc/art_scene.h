@@ -66,7 +66,7 @@ struct DevInstance {
   float minv[12];              // world -> object
   int32_t node_base;           // first node of the mesh's tree in DevScene::blas_nodes (in nodes)
   int32_t tri_base;            // first triangle record of the mesh in DevScene::blas_tris (object space, one winding, prim = triangle of the mesh)
-  int32_t n_tris;
+  uint32_t qroot;              // the mesh's root as an entry word of the cooperative kernel's quantised node array (its byte offset there)
   int32_t shade_base;          // first shading record of the mesh in DevScene::m_shade (object-space vertex normals + material id)
 };
 

@@ -17,14 +17,22 @@ def bits(a):
 
 
 @pytest.mark.parametrize("rt", ["PT_MIS", "PT_SHADOW", "PT_STUPID"])
-def test_small_instanced_scene_equals_the_oracle_on_the_flattened_scene(art, backend, rt):
-    """12 instances of two ~300-triangle meshes: the oracle's O(N) scan of the flattened mesh, whole frame, every integrator."""
+@pytest.mark.parametrize("kernel", ["coop", "coop_stack_cap_3", "one_ray_per_lane"])
+def test_small_instanced_scene_equals_the_oracle_on_the_flattened_scene(art, backend, rt, kernel):
+    """12 instances of two ~300-triangle meshes: the oracle's O(N) scan of the flattened mesh, whole frame, every integrator -- through the
+    cooperative kernel crossing the instance boundary (k_trace_coop<.., INST>), the same with its LDS stack capped at 3 entries (rays that
+    do not fit -- the "leave" marker included -- finish in k_trace_overflow's two-level search), and through k_trace_inst (option inst_coop = 0)."""
     from ada_ray_tracer_amd import scenes
     sd = scenes.instanced_scene(12, 300)
     flat = hostsim.flattened_copy(art, sd)
     p = art.Backend.pass_params(getattr(art, rt), True, 8, 2, seed=21)
-    backend.upload_scene(sd); backend.resize(96, 80)
-    accum, _, spp = backend.render_pass(p, 0)
+    backend.set_option("inst_coop", 0 if kernel == "one_ray_per_lane" else 1)
+    backend.set_option("lds_stack_cap", 3 if kernel == "coop_stack_cap_3" else 0)
+    try:
+        backend.upload_scene(sd); backend.resize(96, 80)
+        accum, _, spp = backend.render_pass(p, 0)
+    finally:
+        backend.set_option("inst_coop", 1); backend.set_option("lds_stack_cap", 0)
     rays = backend.stats().rays
     ref, _, cnt = orc.render(conv.OracleScene(flat).scene, orc.make_params(96, 80, getattr(orc, rt), True, 8, 2, seed=21))
     assert spp == 8 and rays == cnt.rays and backend.stats().lost_paths == 0
@@ -44,6 +52,13 @@ def test_64_instances_of_20k_triangles_at_64_spp(art, backend):
     inst, _, spp = backend.render_pass(p, 0)
     rays_inst = backend.stats().rays
     assert spp == 64 and backend.stats().lost_paths == 0
+    backend.set_option("inst_coop", 0)                        # the one-ray-per-lane two-level kernel: the same picture
+    try:
+        backend.resize(W, H)
+        slow, _, _ = backend.render_pass(p, 0)
+    finally:
+        backend.set_option("inst_coop", 1)
+    assert np.array_equal(bits(inst), bits(slow))
     backend.upload_scene(flat); backend.resize(W, H)
     ref, _, _ = backend.render_pass(p, 0)
     assert backend.stats().rays == rays_inst
