@@ -24,7 +24,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLAGS = ("-fno-slp-vectorize -DART_COOP_WAVES_PER_SIMD=8 -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math "
          "-fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero").split()      # = ada-ray-tracer_amd/Makefile
-KERNEL = "_ZN3art12k_trace_coopILb0ELi4ELb0EEEvPKNS_8DevSceneENS_9TraceArgsE"
+KERNEL = "_ZN3art12k_trace_coopILb0ELi4ELb0ELb0EEEvPKNS_8DevSceneENS_9TraceArgsE"      # <STATS = false, G = 4, OVF = false, INST = false>
 
 CLASS = [   # (regex on the mnemonic, key in valu_rate.json)
     (r"v_fma_f32|v_fmac_f32", "fma"), (r"v_mul_f32", "mul"), (r"v_add_f32", "add"), (r"v_sub(rev)?_f32", "sub"),
