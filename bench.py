@@ -327,8 +327,8 @@ def main():
             # algorithmic bytes per ray of THIS data layout: a node visit reads the node packet once (64 B quantised at
             # width 4, 256 B binary32 at width 8), a triangle test reads a 48-B record, a ray costs 32 B in + 32 B out
             node_bytes = 64.0 if info.node_width == 4 else 256.0
-            if args.scene == "i64":
-                node_bytes = 128.0                          # the two-level search walks binary32 4-wide packets (k_trace_inst)
+            if args.scene == "i64" and "inst_coop=0" in args.opt:
+                node_bytes = 128.0                          # option inst_coop = 0: k_trace_inst walks binary32 4-wide packets (the cooperative kernel: 64-byte quantised nodes, as everywhere)
             bytes_per_ray = node_bytes * NV + 48.0 * T + 64.0
             achieved = rays_dev0 * bytes_per_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
             fp = workload_fingerprint(args, W, H, info, args.opt)
@@ -353,7 +353,7 @@ def main():
                         "traffic": round(traffic, 1) if prof else None,
                         "traffic_note": "FETCH_SIZE x 1.0 + WRITE_SIZE per launch / launch time: random 64-byte node packets and triangle records are counted exactly (profiles/r5_calib/calibration; rounds 1-4 doubled FETCH_SIZE on a calibration of 128-byte gathers the kernel no longer does)" if prof else None,
                         "traffic_source": ("profiles/%s/pmc_summary.json (same source %s, scene, options)" % (PROFILE_TAG, fp["source"])) if prof else None,
-                        "kernel": "k_trace_inst (two-level search, one ray per lane)" if args.scene == "i64" else "k_trace_coop" if args.kernel == "coop" else "k_trace_simple",
+                        "kernel": ("k_trace_inst (two-level search, one ray per lane)" if "inst_coop=0" in args.opt else "k_trace_coop<.., INST> (two-level tree)") if args.scene == "i64" else "k_trace_coop" if args.kernel == "coop" else "k_trace_simple",
                         "bound_evidence": "frac = algorithmic bytes against the HBM peak (the contract's roofline).  What limits the kernel itself is VALU issue: "
                                           "issue = SQ_INSTS_VALU per launch / 1024 SIMDs x the mean issue time of the kernel's own instruction mix (profiles/valu_mix.py x "
                                           "profiles/valu_rate2.hip) / launch time; fabric_frac = bytes past L2 / 8.0 TB/s gather ceiling; both from profiles/%s/pmc_summary.json "

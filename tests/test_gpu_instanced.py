@@ -84,3 +84,42 @@ def test_instanced_scene_needs_the_record_schedule(art, backend):
             backend.render_pass(art.Backend.pass_params(art.PT_MIS, True, 4, 1, seed=1), 0)
     finally:
         backend.set_option("trace_kernel", art.TRACE_COOP)
+
+
+def test_ray_queries_and_the_debug_pass_see_the_flattened_scene(art, backend):
+    """art_trace_rays (both trace kernels) and Debug_Ray_Tracing over an instanced scene: the hits of the flattened upload -- t, u, v, the
+    material and the world-space shading normal the same bits; the triangle index is instance << shift | triangle of the mesh there and
+    the position in the flattened list here."""
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.instanced_scene(10, 200)
+    flat = hostsim.flattened_copy(art, sd)
+    rng = np.random.default_rng(3)
+    n = 20000
+    o = np.tile(np.array([0.0, 2.55, 12.5], np.float32), (n, 1)) + rng.normal(0, 0.05, (n, 3)).astype(np.float32)
+    d = rng.normal(0, 1, (n, 3)).astype(np.float32); d[:, 2] = -np.abs(d[:, 2]) - 1.0
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    ntris = [sd.desc.meshes[sd.desc.instances[i].mesh].ntris for i in range(10)]
+    offs = np.concatenate([[0], np.cumsum(ntris)])
+    shift = int(np.ceil(np.log2(max(ntris))))
+    dbg = art.Backend.pass_params(art.RT_DEBUG, False, 8, 1)
+    backend.upload_scene(flat); backend.resize(80, 60)
+    ref = {k: backend.trace_rays(o, d, kernel=k) for k in (art.TRACE_COOP, art.TRACE_SIMPLE)}
+    ref_dbg = backend.debug_hit_pass(dbg)
+    backend.upload_scene(sd); backend.resize(80, 60)
+    got_dbg = backend.debug_hit_pass(dbg)
+    for k in (art.TRACE_COOP, art.TRACE_SIMPLE):
+        got = backend.trace_rays(o, d, kernel=k)
+        tri_hits = 0
+        for i in range(n):
+            a, b = got[i], ref[k][i]
+            assert (a.is_hit, a.prim_type, a.mat_id, a.mat) == (b.is_hit, b.prim_type, b.mat_id, b.mat)
+            if not a.is_hit:
+                continue
+            assert bits([a.t, a.u, a.v] + list(a.normal)).tolist() == bits([b.t, b.u, b.v] + list(b.normal)).tolist()
+            if a.prim_type == 2:
+                tri_hits += 1
+                assert offs[a.prim_index >> shift] + (a.prim_index & ((1 << shift) - 1)) == b.prim_index
+            else:
+                assert a.prim_index == b.prim_index
+        assert tri_hits > n // 20
+    assert np.array_equal(bits(got_dbg[0]), bits(ref_dbg[0])) and np.array_equal(got_dbg[3], ref_dbg[3]) and np.array_equal(got_dbg[4], ref_dbg[4])
