@@ -112,6 +112,7 @@ begin
   desc.n_lights := 1;  desc.lights := lgt'Address;
   desc.n_materials := int (n_mat);  desc.materials := mats (0)'Address;
   desc.n_meshes := 1;  desc.meshes := msh'Address;
+  desc.n_instances := 0;  desc.instances := System.Null_Address;   --  the internal scene has no instances (the Hydra scene's <instance> nodes become Art_Instance records: INTEGRATION.md section 2)
   desc.cam_pos := F3 (a_scn.g_cam.pos);
   for i in 0 .. 3 loop
     for j in 0 .. 3 loop
