@@ -184,6 +184,7 @@ int upload_scene(const ArtSceneDesc* d) {
     c.bvh_stack_bound = std::max(8, dev_stack);
     c.blocks_per_cu = 0;   // re-query occupancy
     c.scene_ready = true;
+    c.auto_phase = 0;                                    // a new scene: the shade stage measures its items-per-thread choice again
   }
   g_devs[0].host_scene = std::move(hs);
   return 0;
@@ -216,6 +217,7 @@ static int resize_one(int w, int h) {
   c.spp = 0;
   c.stats = ArtStats();
   c.stage = ArtStageStats();
+  c.auto_phase = 0;                                      // (the batch size follows the frame: measure again)
   if (c.d_items) HIP_TRY(hipMemsetAsync(c.d_items, 0, 32 * sizeof(unsigned long long), c.stream));
   c.camera_rays = 0;
   HIP_TRY(hipMemsetAsync(c.d_counters, 0, 16 * sizeof(unsigned long long), c.stream));
@@ -497,6 +499,11 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
         for (DevPaths& b : bank) { b.P = pn * sn; b.npix = pn; b.pixmap = (const uint32_t*)c.b_pixmap.p + px0; b.sample_base = (uint32_t)(c.spp + s0); }
         uint4* heavy = nullptr;
         carve(bank, bank[0].P, p->max_depth, c.trace_kernel == TRACE_COOP, &heavy);
+        // items per thread of the shade stage for this batch: the option, the measured choice, or a trial (art_api_internal.h Ctx::opt_shade_per)
+        const bool trial = (c.opt_shade_per == 0 && c.auto_phase < 2 && c.trace_kernel == TRACE_COOP && !c.shade_split);
+        const int shade_per = c.opt_shade_per ? c.opt_shade_per : (c.auto_phase >= 2 ? c.auto_per : (c.auto_phase == 0 ? 4 : 2));
+        double shade_ms_before = 0.0;
+        if (trial) { HIP_TRY(hipStreamSynchronize(c.stream)); if (collect_timing()) return 1; shade_ms_before = c.stage.shade_ms; }
         c.camera_rays += (uint64_t)bank[0].P;
         if (c.trace_kernel == TRACE_COOP) {
           // Compacted work sets: raygen fills bank 0 (one item per slot); stage b shades the items of bank b & 1 and writes the survivors
@@ -522,7 +529,7 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
             HIP_TRY(hipMemsetAsync(n_out, 0, 2 * sizeof(int), c.stream));         // n_out[1]: the items this stage defers to its heavy-material kernel
             if (ev_begin(1)) return 1;
             launch_shade_compact(c.stream, F, c.scene, qi, bank[out], b, b == 0 ? nullptr : n_in, n_out,
-                                 const_cast<uint32_t*>(bank[out].slot_id), c.d_counters + 15, c.d_counters, rays_b, c.shade_split ? heavy : nullptr, n_out + 1);
+                                 const_cast<uint32_t*>(bank[out].slot_id), c.d_counters + 15, c.d_counters, rays_b, c.shade_split ? heavy : nullptr, n_out + 1, shade_per);
             if (ev_end()) return 1;
             if (g_debug_live) {
               int n = -1; unsigned long long r0 = 0;
@@ -543,6 +550,13 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
           if (ev_end()) return 1;
           launch_acc_items(c.stream, c.d_live, p->max_depth, q.P, c.d_items);
           c.stage.batches += 1;
+          if (trial) {                                   // this batch's shade time (same batch size for both trials: consecutive batches of one pass, or of two passes)
+            HIP_TRY(hipStreamSynchronize(c.stream));
+            if (collect_timing()) return 1;
+            const double ms = (c.stage.shade_ms - shade_ms_before) / (double)std::max(1, bank[0].P);
+            c.auto_ms[c.auto_phase] = ms; c.auto_phase += 1;
+            if (c.auto_phase == 2) c.auto_per = (c.auto_ms[1] < c.auto_ms[0]) ? 2 : 4;
+          }
         } else {                                          // one-ray-per-lane cross-check kernel: the plain schedule over all slots, in place
           DevPaths q = bank[0];
           q.slot_id = nullptr;
@@ -851,7 +865,7 @@ int art_init_devices(int32_t n, const int32_t* ordinals) {
     Ctx& c = g_devs[k];
     c = Ctx();
     c.trace_kernel = opts.trace_kernel; c.batch_paths = opts.batch_paths; c.bvh_params = opts.bvh_params; c.node_min = opts.node_min; c.refill_min = opts.refill_min;
-    c.queue_segments = opts.queue_segments; c.ray_chunk = opts.ray_chunk; c.shadow_anyhit = opts.shadow_anyhit; c.shade_split = opts.shade_split; c.inst_coop = opts.inst_coop; c.lds_stack_cap = opts.lds_stack_cap;
+    c.queue_segments = opts.queue_segments; c.ray_chunk = opts.ray_chunk; c.shadow_anyhit = opts.shadow_anyhit; c.shade_split = opts.shade_split; c.inst_coop = opts.inst_coop; c.opt_shade_per = opts.opt_shade_per; c.lds_stack_cap = opts.lds_stack_cap;
     c.opt_blocks_per_cu = opts.opt_blocks_per_cu; c.count_tests = opts.count_tests;
     c.device = ord[k]; c.rank = k; c.nranks = n; c.tile = 32;
     if (use_dev(k) || ensure_device()) { shutdown(); return 1; }
@@ -1029,6 +1043,7 @@ static int set_option_one(const std::string& n, int64_t value) {
   else if (n == "shadow_anyhit") { g_ctx.shadow_anyhit = value != 0; }
   else if (n == "shade_split") { g_ctx.shade_split = value != 0; }
   else if (n == "inst_coop") { g_ctx.inst_coop = value != 0; }
+  else if (n == "shade_per") { if (value != 0 && value != 2 && value != 4) return fail("shade_per: 0 (measured), 2 or 4"); g_ctx.opt_shade_per = (int)value; }
   else if (n == "ray_chunk") { if (value < 16 || value > 4096 || (value & 15)) return fail("ray_chunk: a multiple of 16, 16..4096"); g_ctx.ray_chunk = (int)value; }
   else if (n == "refill_min") { if (value < 1 || value > 8) return fail("refill_min: 1..8"); g_ctx.refill_min = (int)value; }
   else if (n == "node_min") { if (value < 1 || value > 8) return fail("node_min: 1..8"); g_ctx.node_min = (int)value; }

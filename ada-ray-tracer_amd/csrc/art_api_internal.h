@@ -52,6 +52,11 @@ struct Ctx {
   int queue_segments = 8;       // the live-ray queue is cut into this many contiguous segments, one per XCD (1 = a single cursor)
   int ray_chunk = 48;            // trace records a wave claims per atomic (and prefetches): 16 -> 48 is worth 1 % on C4, 4 % on C3, 10 % on C5 (the claim stalls the wave)
   bool shadow_anyhit = true;   // shadow rays use the visibility rule instead of a full closest-hit search (same decision)
+  // Items per thread of k_shade_compact (256 x per items and one global atomic per workgroup): 4 or 2.  Neither wins everywhere (round 5,
+  // profiles/r5_shade/ab12: 2 is 7 % faster on C4 and C3, 10 % slower on C5 and S4), so by default the library MEASURES: the first batch
+  // after a scene upload or a resize runs with 4, the second with 2, HIP events around the shade launches, the faster one is kept.  The
+  // picture does not depend on it (the order of the items of a bank carries no meaning).  Option shade_per: 0 automatic, 2, 4.
+  int opt_shade_per = 0, auto_per = 0, auto_phase = 0; double auto_ms[2] = {0.0, 0.0};
   bool inst_coop = true;       // instanced scenes: the cooperative kernel crosses the instance boundary (k_trace_coop<.., INST>); false: k_trace_inst, one ray per lane (A/B, cross-check)
   bool shade_split = false;    // k_shade_compact as one instantiation per register class (light materials / deferred heavy ones); false: the round-4 kernel with every material (A/B)
   // timing

@@ -58,7 +58,7 @@ void launch_finish(hipStream_t st, const DevFrame& F, const DevPaths& Q, int las
 // rays_a / rays_b: += the rays the stage emits as trace records (Qo.rec != nullptr); rays_b may be nullptr
 void launch_shade_compact(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Qi, const DevPaths& Qo, int bounce,
                           const int* n_in, int* n_out, uint32_t* slot_out, unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b,
-                          uint4* heavy = nullptr, int* n_heavy = nullptr);      // heavy: the queue of deferred items (16 B x Qi.P), n_heavy: its count (zeroed by the caller); nullptr: one kernel for every material
+                          uint4* heavy = nullptr, int* n_heavy = nullptr, int per = 0);      // per: items per thread, 2 or 0 = the default (4)      // heavy: the queue of deferred items (16 B x Qi.P), n_heavy: its count (zeroed by the caller); nullptr: one kernel for every material
 void launch_resolve_last(hipStream_t st, const DevPaths& Q, const int* n, int last_level);
 void launch_fold(hipStream_t st, const DevFrame& F, const DevPaths& Q);
 void launch_fold_levels(hipStream_t st, const DevFrame& F, const DevPaths& Q, int max_depth, const int* counts);     // dense fold records: counts[32 k] = items of level k

@@ -1256,9 +1256,10 @@ __global__ void k_probe_on(int v) { g_lane_probe_on = v; }
 #endif
 void launch_shade_compact(hipStream_t st, const DevFrame& F, const DevScene& S, const DevPaths& Qi, const DevPaths& Qo, int bounce,
                           const int* n_in, int* n_out, uint32_t* slot_out, unsigned long long* lost, unsigned long long* rays_a, unsigned long long* rays_b,
-                          uint4* heavy, int* n_heavy) {
+                          uint4* heavy, int* n_heavy, int per) {
   const bool camera = Qi.synth0 && Qi.slot_id == nullptr;
-  const dim3 grid((Qi.P + 256 * kShadePerThread - 1) / (256 * kShadePerThread));
+  const int per_now = (per == 2 && !(ART_SHADE_SPLIT && heavy != nullptr && n_heavy != nullptr)) ? 2 : kShadePerThread;      // items per thread of this launch (2: the one-kernel form only)
+  const dim3 grid((Qi.P + 256 * per_now - 1) / (256 * per_now));
 #if defined(ART_LANE_PROBE)
   hipLaunchKernelGGL(k_probe_on, dim3(1), dim3(1), 0, st, 1);
 #endif
@@ -1266,8 +1267,13 @@ void launch_shade_compact(hipStream_t st, const DevFrame& F, const DevScene& S, 
   A.heavy = heavy; A.n_heavy_ptr = n_heavy;
   const bool split = ART_SHADE_SPLIT && heavy != nullptr && n_heavy != nullptr;
   if (!split) {
-    if (camera) hipLaunchKernelGGL((k_shade_compact<kShadePerThread, true, SET_ALL>), grid, dim3(256), 0, st, A);
-    else hipLaunchKernelGGL((k_shade_compact<kShadePerThread, false, SET_ALL>), grid, dim3(256), 0, st, A);
+    if (per_now == 2) {
+      if (camera) hipLaunchKernelGGL((k_shade_compact<2, true, SET_ALL>), grid, dim3(256), 0, st, A);
+      else hipLaunchKernelGGL((k_shade_compact<2, false, SET_ALL>), grid, dim3(256), 0, st, A);
+    } else {
+      if (camera) hipLaunchKernelGGL((k_shade_compact<kShadePerThread, true, SET_ALL>), grid, dim3(256), 0, st, A);
+      else hipLaunchKernelGGL((k_shade_compact<kShadePerThread, false, SET_ALL>), grid, dim3(256), 0, st, A);
+    }
   } else {
     // the light classes, then the deferred items of the heavy ones (their count is only known on the device: the grid covers the
     // worst case, workgroups past the queue's end return at once)
