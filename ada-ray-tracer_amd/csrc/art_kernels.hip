@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256) void k_raygen(const DevFrame F, const DevScene
     if ((int)threadIdx.x < S.n_spheres) s_sph[threadIdx.x] = S.spheres[threadIdx.x];
     if ((int)threadIdx.x < S.n_lights) s_lgt[threadIdx.x] = S.lights[threadIdx.x];
     __syncthreads();
-    cx.lds_spheres = (const ART_LDS DevSphere*)(uint32_t)(uintptr_t)s_sph; cx.lds_lights = (const ART_LDS DevLight*)(uint32_t)(uintptr_t)s_lgt;      // (the low 32 bits of a generic LDS address are the LDS address)
+    cx.lds_spheres = as_lds(&s_sph[0]); cx.lds_lights = as_lds(&s_lgt[0]);
   }
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
   // record mode: a wave's 64 records are 4 KB of consecutive bytes; staged through LDS so that every store instruction writes one
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(set_waves(S
   __syncthreads();
   StageCtx tables;
   tables.hot_layout = true;
-  if (tables_in_lds) { tables.lds_spheres = (const ART_LDS DevSphere*)(uint32_t)(uintptr_t)s_sph; tables.lds_lights = (const ART_LDS DevLight*)(uint32_t)(uintptr_t)s_lgt; }
+  if (tables_in_lds) { tables.lds_spheres = as_lds(&s_sph[0]); tables.lds_lights = as_lds(&s_lgt[0]); }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t lanes_below = (1ull << lane) - 1ull;
 #if defined(ART_TIME_PROBE)
@@ -1057,9 +1057,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(set_waves(S
 #if ART_SHADE_KERNARG
     const ShadeKArgs K2 = launder_kargs(K);               // the round's own view of the arguments: nothing loaded before survives in a register
     const DevFrame& F = *(const DevFrame*)&K2->F; const DevScene& S = *(const DevScene*)&K2->S; const DevPaths& Qi = *(const DevPaths*)&K2->Qi; const DevPaths& Qo = *(const DevPaths*)&K2->Qo;
-    uint32_t* const slot_out = K2->slot_out; unsigned long long* const lost = K2->lost;
+    unsigned long long* const lost = K2->lost;            // (the output items' slot words are written by shade_item: Qo's HF_SLOT field IS K->slot_out)
 #else
-    uint32_t* const slot_out = K->slot_out; unsigned long long* const lost = K->lost;
+    unsigned long long* const lost = K->lost;
     const ShadeKernArgs* const K2 = K;
 #endif
     ART_TPROBE(tables.tprobe, 70);    // round bookkeeping (and, after the first round, whatever followed the last probe of the item before)

@@ -30,6 +30,15 @@ struct f3 { float x, y, z; };
 #define ART_LDS
 #endif
 
+// a generic pointer to a __shared__ object as an LDS-qualified one (the low 32 bits of a generic LDS address are the LDS address)
+template <class T> ART_HD const ART_LDS T* as_lds(const T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (const ART_LDS T*)(uint32_t)(uintptr_t)p;
+#else
+  return p;
+#endif
+}
+
 // scalar base + 32-bit byte offset: on the device the address costs no vector instruction and no VGPR pair (a 64-bit pointer per array costs a
 // v_lshl_add_u64 and two registers each).  The caller guarantees that the offset fits 32 bits.  at(base, i) = base[i] through it.
 template <class T> ART_HD T ld_off(const T* base, uint32_t byte_off) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off); }
