@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         best_t = r0.w; best_key = __builtin_bit_cast(uint32_t, r1.w); shm = r2.w;
         sel_near = __builtin_bit_cast(uint32_t, r3.x); sel_far = 0x18070503u - sel_near;      // per byte: near + far = 3, 5, 7, 0x18 (0x0c + 0x0c)
         ray = __builtin_bit_cast(int, r3.y); far_found = __builtin_bit_cast(uint32_t, r3.z) != 0u;
-        if (OVF || INST) rec_i = chunk_pos + my_rank;
+        if (OVF) rec_i = chunk_pos + my_rank;
         if (INST) cur_inst = -1;
         held_key = KEY_MISS;
         sa = se; pend = 0u;                                       // entry word 0 = root node (both encodings)
@@ -336,6 +336,25 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         if (ART_EXECM & 2) pop_masked(v1, ok1, sa, pend, e1.x);
         else { pend = sel(ok1, e1.x, pend); sa = sel(v1, sa - 8u, sa); }
         pend_valid |= ok1;
+      }
+      if (INST) {
+        // A popped "leave" marker is dealt with here, not in the leaf phase: two LDS reads and eight instructions for the groups that hold
+        // one.  Waiting for the next leaf phase cost a pass of the outer loop per instance left: 2.2 x the leaf-phase passes of the
+        // flattened scene at equal node visits; consumed here 1.7 x and +11 % Mrays/s.  (The ENTRY handled here too brought the passes down to
+        // the flattened scene's and was 3 % slower: ~100 instructions and four loads inside the node loop for one or two groups;
+        // it stays in the leaf phase, which serves every waiting group at once.  profiles/r5_instanced.json)
+        const mask_t leaving = has_ray & pend_valid & vcmp(pend == kQEntryLeaveInstance);
+        if (leaving != 0) {
+          if (lane_of(leaving)) {
+            const uint2 s1 = lds_load(sa + (8u - kSaBias)), s0 = lds_load(sa - kSaBias);      // under the marker: world-space inv.xy | inv.z, near-plane selector
+            sa -= 16u;
+            inv = mk3(__builtin_bit_cast(float, s0.x), __builtin_bit_cast(float, s0.y), __builtin_bit_cast(float, s1.x));
+            noi = mk3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+            sel_near = s1.y; sel_far = 0x18070503u - sel_near;
+            cur_inst = -1;
+          }
+          pend_valid &= ~leaving;                          // those groups pop their next entry in the next iteration
+        }
       }
       const mask_t active = has_ray & pend_valid;
       const mask_t is_leaf = (G == 4) ? vcmp((int)pend < 0) : vcmp((pend & 15u) != 0u);
@@ -506,26 +525,24 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
             const uint4 wi = *reinterpret_cast<const uint4*>(ib + 96);
             const float mi[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
             const f3 oo = xform_point(mi, o), dd = mk3(mi[0] * d.x + mi[1] * d.y + mi[2] * d.z, mi[4] * d.x + mi[5] * d.y + mi[6] * d.z, mi[8] * d.x + mi[9] * d.y + mi[10] * d.z);
-            const uint32_t top = sa + 8u;
-            if (OVF && top > slimit + kSaBias) {           // the marker does not fit the capped stack: the ray moves to k_trace_overflow
+            const uint32_t top = sa + 24u;                 // three entries: the world-space inv.xy | inv.z, near-plane selector | the "leave" marker on top
+            if (OVF && top > slimit + kSaBias) {           // they do not fit the capped stack: the ray moves to k_trace_overflow
               if (j == 0) A.ovf_queue[atomicAdd(A.ovf_count, 1)] = rec_i;
               enter = false;
             } else {
+              // what leaving the instance has to restore goes under the marker, on the ray's own LDS stack (re-reading it from the trace
+              // record would put a global-memory round trip into every instance left)
+              lds_store(sa + (16u - kSaBias), make_uint2(__builtin_bit_cast(uint32_t, inv.x), __builtin_bit_cast(uint32_t, inv.y)));
+              lds_store(sa + (24u - kSaBias), make_uint2(__builtin_bit_cast(uint32_t, inv.z), sel_near));
+              lds_store(sa + (32u - kSaBias), make_uint2(kQEntryLeaveInstance, 0u));      // under the mesh's tree: popped when that tree is done
               slab_setup(oo, dd, inv, noi);
               const uint32_t sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
               sel_near = (sx ? 3u : 0u) | ((sy ? 4u : 1u) << 8) | ((sz ? 5u : 2u) << 16) | 0x0c000000u; sel_far = 0x18070503u - sel_near;
-              lds_store(sa + (16u - kSaBias), make_uint2(kQEntryLeaveInstance, 0u));      // under the mesh's tree: popped when that tree is done
               sa = top;
               cur_inst = (int)ii;
               pend = wi.z;                                 // DevInstance::qroot: the mesh's root, an inner entry
             }
-          } else if (special) {                            // the "leave" marker: back to world space, from the ray's own trace record
-            const char* const rb = reinterpret_cast<const char*>(A.rec) + (size_t)rec_i * (size_t)kTraceRecBytes;
-            const float4 r2 = *reinterpret_cast<const float4*>(rb + 32); const float selw = *reinterpret_cast<const float*>(rb + 48);
-            inv = mk3(r2.x, r2.y, r2.z); noi = mk3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
-            sel_near = __builtin_bit_cast(uint32_t, selw); sel_far = 0x18070503u - sel_near;
-            cur_inst = -1;
-          }
+          }                                                // (a "leave" marker never gets here: the inner loop consumes it as it pops it)
           entered = ballot64(enter);
           if (OVF) { const mask_t gone = ballot64(special && (cnt == (int)kQCountInstance) && !enter); if (gone != 0) { has_ray &= ~gone; sa = lane_of(gone) ? se : sa; } }
         }

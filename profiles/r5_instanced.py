@@ -24,9 +24,18 @@ def run(art, be, sd, label, opts=()):
     for _ in range(2):
         spp = be.render_pass_device(prm, spp)
     be.synchronize(); dt = time.perf_counter() - t0; s1 = be.stats()
+    # traversal counters per ray (the counting variant of the same kernel, one untimed 4-spp pass)
+    be.set_option("count_tests", 1)
+    c0 = be.stats(); be.render_pass_device(art.Backend.pass_params(art.PT_MIS, True, 8, 1, seed=1), spp); c1 = be.stats()
+    be.set_option("count_tests", 0)
+    nr = max(1, c1.traced_rays - c0.traced_rays)
+    counters = {"node_visits_per_ray": round((c1.node_visits - c0.node_visits) / nr, 2), "leaf_visits_per_ray": round((c1.leaf_visits - c0.leaf_visits) / nr, 2),
+                "tri_tests_per_ray": round((c1.tri_tests - c0.tri_tests) / nr, 2), "box_tests_per_ray": round((c1.box_tests - c0.box_tests) / nr, 2),
+                "wave_iters_per_kray": round(1000.0 * (c1.wave_iters - c0.wave_iters) / nr, 1), "node_phase_iters_per_kray": round(1000.0 * (c1.node_phase_iters - c0.node_phase_iters) / nr, 1),
+                "leaf_phase_iters_per_kray": round(1000.0 * (c1.leaf_phase_iters - c0.leaf_phase_iters) / nr, 1)}
     for k, v in opts:
         be.set_option(k, 1 if k == "inst_coop" else 0)
-    return {"variant": label, "Mrays_per_s": round((s1.rays - s0.rays) / dt / 1e6, 1), "ms_per_64spp_step": round(dt * 500.0, 1), "trace_ms_per_step": round((s1.trace_ms - s0.trace_ms) / 2, 1),
+    return {"counters": counters, "variant": label, "Mrays_per_s": round((s1.rays - s0.rays) / dt / 1e6, 1), "ms_per_64spp_step": round(dt * 500.0, 1), "trace_ms_per_step": round((s1.trace_ms - s0.trace_ms) / 2, 1),
             "scene_upload_s": round(t_up, 2), "tree_nodes": info.n_nodes, "tree_triangle_records": info.n_tris}
 
 
