@@ -154,11 +154,13 @@ def structured_scene(n_tris=1000000):
     return SceneDesc(spheres=spheres, lights=lights, materials=mats, meshes=[mesh], cornell=CORNELL_BOX, cam_pos=REFERENCE_CAMERA)
 
 
-def instanced_scene(n_instances=64, tris_per_mesh=20000, seed=0xADA5EED0 + 64):
+def instanced_scene(n_instances=64, tris_per_mesh=20000, seed=0xADA5EED0 + 64, transforms=None, all_materials=False):
     """Round 5 (embree_connect.cpp:147-184): Cornell walls + the three sphere lights of synthetic_scene + n_instances
     instances of TWO prototype meshes of about tris_per_mesh triangles each (a torus and a bumpy grid, object space around the origin),
     every instance under its own rotation, non-uniform scale and translation.  Rendered through the two-level tree without flattening;
-    tests/host_sim's hs_flatten_instances gives the explicit world-space mesh the picture must equal bit for bit."""
+    tests/host_sim's hs_flatten_instances gives the explicit world-space mesh the picture must equal bit for bit.
+    transforms: [(mesh index 0 | 1, 3x4 object -> world)] instead of the n_instances seeded ones (the tests' mirrored, sheared, coincident,
+    tiny and huge instances); all_materials: the torus also carries mirror (5) and Phong (8) triangles next to its glass (0) ones."""
     mats = cornell_materials()
     mats[4] = dict(type=MAT_LIGHT, light=0)
     mats.append(dict(type=MAT_LIGHT, light=1)); mats.append(dict(type=MAT_LIGHT, light=2))
@@ -177,7 +179,10 @@ def instanced_scene(n_instances=64, tris_per_mesh=20000, seed=0xADA5EED0 + 64):
     a_ = (i * (m + 1) + j).ravel(); b_ = ((i + 1) * (m + 1) + j).ravel(); c_ = (i * (m + 1) + j + 1).ravel(); d_ = ((i + 1) * (m + 1) + j + 1).ravel()
     idx = np.stack([np.stack([a_, c_, b_], 1), np.stack([b_, c_, d_], 1)], 1).reshape(-1, 3).astype(np.int32)
     grid = dict(mode=MESH_CLOSEST, pos=pos, nrm=nrm, idx=idx, matid=(1 + (np.arange(idx.shape[0]) % 3)).astype(np.int32))
-    tor["matid"] = np.where(np.arange(tor["idx"].shape[0]) % 7 == 0, 0, 1 + (np.arange(tor["idx"].shape[0]) % 3)).astype(np.int32)      # some Phong (material 0)
+    tn = np.arange(tor["idx"].shape[0])
+    tor["matid"] = np.where(tn % 7 == 0, 0, 1 + (tn % 3)).astype(np.int32)      # every seventh triangle glass (material 0)
+    if all_materials:
+        tor["matid"] = np.where(tn % 7 == 3, 5, np.where(tn % 7 == 5, 8, tor["matid"])).astype(np.int32)
     rng = np.random.default_rng(seed)
     insts = []
     for k in range(n_instances):
@@ -189,6 +194,8 @@ def instanced_scene(n_instances=64, tris_per_mesh=20000, seed=0xADA5EED0 + 64):
         M = np.zeros((3, 4)); M[:, :3] = Rz @ Ry @ Rx @ S
         M[:, 3] = [-2.0 + 4.0 * rng.random(), 0.5 + 3.6 * rng.random(), 0.3 + 4.0 * rng.random()]
         insts.append((k % 2, M.astype(F).ravel()))
+    if transforms is not None:
+        insts = [(int(mi), np.asarray(M, F).reshape(3, 4).ravel()) for mi, M in transforms]
     return SceneDesc(spheres=spheres, lights=lights, materials=mats, meshes=[tor, grid], cornell=CORNELL_BOX, cam_pos=REFERENCE_CAMERA, instances=insts)
 
 

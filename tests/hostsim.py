@@ -95,3 +95,24 @@ def set_bvh_param(art, name, value):
     L.hs_set_bvh_param.argtypes = [C.c_char_p, C.c_double]
     L.hs_set_bvh_param.restype = None
     L.hs_set_bvh_param(name.encode(), float(value))
+
+
+def awkward_instances():
+    """Instance transforms the seeded scenes do not contain: the identity, a mirror image (negative determinant: the triangles' winding as
+    seen from outside flips, so does the one-sided test of geometry.adb:231-263 -- in the flattened scene exactly the same way), the SAME
+    transform twice (coincident triangles: equal t, the lower hit index must win in both renderings), a shear, a tiny and a large instance
+    (scale 1e-3 / 2.2, the large one cutting through the walls of the box), and two instances that interpenetrate."""
+    def M(a, t):
+        m = np.zeros((3, 4)); m[:, :3] = np.asarray(a, np.float64); m[:, 3] = t
+        return m
+    I = np.eye(3)
+    rot = np.array([[0.8, 0.0, 0.6], [0.0, 1.0, 0.0], [-0.6, 0.0, 0.8]])
+    return [(0, M(I, (0.0, 1.2, 2.0))),
+            (0, M(np.diag([-1.0, 1.0, 1.0]) * 0.9, (1.3, 2.6, 2.4))),
+            (1, M(rot * 0.8, (-1.0, 2.2, 1.5))),
+            (1, M(rot * 0.8, (-1.0, 2.2, 1.5))),
+            (0, M(np.array([[1.0, 0.6, 0.0], [0.0, 1.0, 0.3], [0.0, 0.0, 1.0]]) * 0.7, (-1.2, 3.6, 3.2))),
+            (0, M(I * 1.0e-3, (0.2, 2.5, 4.0))),
+            (1, M(rot.T * 2.2, (0.0, 0.4, 2.5))),
+            (0, M(rot * 0.6, (0.9, 1.0, 3.3))),
+            (1, M(np.diag([0.5, -0.7, 0.5]), (1.0, 1.1, 3.2)))]

@@ -39,6 +39,44 @@ def test_small_instanced_scene_equals_the_oracle_on_the_flattened_scene(art, bac
     assert np.array_equal(bits(accum), bits(ref))
 
 
+@pytest.mark.parametrize("kernel", ["coop", "coop_stack_cap_3", "one_ray_per_lane"])
+def test_mirrored_sheared_coincident_tiny_and_huge_instances(art, backend, kernel):
+    """hostsim.awkward_instances (a mirror image, one transform twice -- equal t, the lower hit index wins --, a shear, scales 1e-3 and 2.2,
+    interpenetrating instances; glass, mirror and Phong triangles): the oracle's O(N) scan of the flattened mesh, whole frame, and the
+    hit indices of the debug pass against the flattened upload's"""
+    from ada_ray_tracer_amd import scenes
+    tr = hostsim.awkward_instances()
+    sd = scenes.instanced_scene(0, 260, transforms=tr, all_materials=True)
+    flat = hostsim.flattened_copy(art, sd)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=77)
+    backend.set_option("inst_coop", 0 if kernel == "one_ray_per_lane" else 1)
+    backend.set_option("lds_stack_cap", 3 if kernel == "coop_stack_cap_3" else 0)
+    try:
+        backend.upload_scene(sd); backend.resize(128, 96)
+        accum, _, spp = backend.render_pass(p, 0)
+        rays = backend.stats().rays
+        dbg = backend.debug_hit_pass(art.Backend.pass_params(art.RT_DEBUG, False, 8, 1))
+    finally:
+        backend.set_option("inst_coop", 1); backend.set_option("lds_stack_cap", 0)
+    ref, _, cnt = orc.render(conv.OracleScene(flat).scene, orc.make_params(128, 96, orc.PT_MIS, True, 8, 2, seed=77))
+    assert spp == 8 and rays == cnt.rays and backend.stats().lost_paths == 0
+    assert np.array_equal(bits(accum), bits(ref))
+    backend.upload_scene(flat); backend.resize(128, 96)
+    ref_dbg = backend.debug_hit_pass(art.Backend.pass_params(art.RT_DEBUG, False, 8, 1))
+    ntris = [sd.desc.meshes[mi].ntris for mi, _ in tr]
+    offs = np.concatenate([[0], np.cumsum(ntris)])
+    shift = int(np.ceil(np.log2(max(ntris))))
+    prim, mat, ptype = dbg[2], dbg[3], dbg[4]; rprim = ref_dbg[2]
+    assert np.array_equal(bits(dbg[0]), bits(ref_dbg[0])) and np.array_equal(mat, ref_dbg[3]) and np.array_equal(ptype, ref_dbg[4])
+    on_mesh = (ptype == 2)                                     # mesh triangles: instance << shift | triangle of the mesh here, the position in the flattened list there
+    assert np.array_equal(prim[~on_mesh], rprim[~on_mesh]) and on_mesh.sum() > 500
+    inst = prim[on_mesh] >> shift
+    assert np.array_equal(offs[inst] + (prim[on_mesh] & ((1 << shift) - 1)), rprim[on_mesh])
+    hit_insts = set(np.unique(inst).tolist())
+    assert 3 not in hit_insts and 2 in hit_insts              # the coincident pair: always the first of the two
+    assert {0, 1, 4, 6}.issubset(hit_insts)
+
+
 def test_64_instances_of_20k_triangles_at_64_spp(art, backend):
     """The review's case: 64 instances x ~20 k triangles (1.28 M triangles flattened), 640x360, PT_MIS depth 8, 64 spp.  Instanced render ==
     render of the flattened upload (whole frame, bits), and == the oracle on 300 sampled pixels (its search walks the flattened tree)."""

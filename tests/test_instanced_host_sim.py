@@ -31,6 +31,20 @@ def test_instanced_scene_equals_the_oracle_on_the_flattened_scene(art, rt):
     assert float(np.abs(acc).sum()) > 0.0
 
 
+def test_mirrored_sheared_coincident_tiny_and_huge_instances(art):
+    """hostsim.awkward_instances: a mirror image, one transform twice, a shear, scales 1e-3 and 2.2, interpenetrating instances; glass, mirror
+    and Phong triangles on the torus -- still the flattened scene's picture, bit for bit"""
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.instanced_scene(0, 260, transforms=hostsim.awkward_instances(), all_materials=True)
+    flat = hostsim.flattened_copy(art, sd)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=77)
+    acc, rays = hostsim.render(art, sd, p, 64, 48)
+    ref, _, cnt = orc.render(conv.OracleScene(flat).scene, orc.make_params(64, 48, orc.PT_MIS, True, 8, 2, seed=77))
+    assert rays == cnt.rays
+    assert np.array_equal(bits(acc), bits(ref))
+    assert np.isfinite(acc).mean() > 0.99 and (acc > 0).mean() > 0.3      # (the reference's 1 / max(cos, 1e-20) gives a few pixels of 1e16 .. 1e38 on the mirror and glass triangles: the same bits in both)
+
+
 def test_instanced_scene_rejects_what_it_cannot_hold(art):
     from ada_ray_tracer_amd import scenes
     sd = scenes.instanced_scene(4, 100)
