@@ -46,6 +46,18 @@ out["oracle_equal"] = bool(np.array_equal(base[0].view(np.uint32), ref.view(np.u
 for name, v in imgs.items():
     out[name] = bool(np.array_equal(v[0].view(np.uint32), base[0].view(np.uint32)) and np.array_equal(v[1], base[1]) and v[2:5] == base[2:5]
                      and np.array_equal(v[5], base[5]))
+# an instanced scene (the two-level tree replicated per context) through the same path
+isd = scenes.instanced_scene(6, 200)
+iimgs = {}
+for name, devs in (("one", None), ("three_contexts", [0, 0, 0])):
+    be = art.Backend(0) if devs is None else art.Backend(devices=devs)
+    be.upload_scene(isd); be.resize(100, 72)
+    accum, screen, spp = be.render_pass(p, 0, True, True)
+    iimgs[name] = (accum.copy(), screen.copy(), spp, be.stats().rays)
+    be.shutdown()
+out["instanced_three_contexts"] = bool(np.array_equal(iimgs["one"][0].view(np.uint32), iimgs["three_contexts"][0].view(np.uint32))
+                                       and np.array_equal(iimgs["one"][1], iimgs["three_contexts"][1]) and iimgs["one"][2:] == iimgs["three_contexts"][2:]
+                                       and float(np.abs(iimgs["one"][0]).sum()) > 0.0)
 print(json.dumps(out))
 '''
 
@@ -55,7 +67,7 @@ def test_n_contexts_in_one_process_give_the_single_device_image(art):
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out == {"oracle_equal": True, "one": True, "init_devices_1": True, "three_contexts": True, "eight_contexts": True,
-                   "three_contexts_set_shard_refused": True, "eight_contexts_set_shard_refused": True}, out
+                   "three_contexts_set_shard_refused": True, "eight_contexts_set_shard_refused": True, "instanced_three_contexts": True}, out
 
 
 def test_rccl_calls_of_the_n_device_path_run_on_one_device(art):
