@@ -33,6 +33,7 @@ bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vect
   std::vector<int32_t> node_base(nm, 0), tri_base(nm, 0), ntris(nm, 0);
   std::vector<std::array<float, 6>> mesh_box(nm);
   std::vector<std::vector<uint32_t>> mesh_q;             // one-sided builds: every mesh's quantised nodes, relocated below
+  std::vector<std::vector<float>> mesh_pts(nm);          // the vertices a mesh's triangles use (an instance's world box is the box of their images)
   for (size_t mi = 0; mi < nm; ++mi) {
     const InstMeshIn& m = meshes[mi];
     if (m.n_tris == 0 || m.n_verts == 0) { err = "empty mesh"; return false; }
@@ -58,7 +59,16 @@ bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vect
     T.blas_nodes.insert(T.blas_nodes.end(), b.nodes.begin(), b.nodes.end());
     T.blas_tris.insert(T.blas_tris.end(), b.tris.begin(), b.tris.end());
     mesh_box[mi] = {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]};
+    std::vector<uint8_t> used(m.n_verts, 0);
+    for (size_t k = 0; k < 3 * m.n_tris; ++k) used[(size_t)m.idx[k]] = 1;
+    for (size_t v = 0; v < m.n_verts; ++v) if (used[v]) mesh_pts[mi].insert(mesh_pts[mi].end(), m.verts + 3 * v, m.verts + 3 * v + 3);
   }
+  // An instance's world box: the box of its transformed VERTICES (tight: the image of the object box's 8 corners is up to twice as large
+  // for a rotated instance, and every overlap of two instances' boxes is a second mesh tree entered for nothing) while that stays cheap --
+  // 2e8 vertex transforms per build, about half a second; beyond that the corners' box.
+  double transforms = 0.0;
+  for (const InstIn& in : insts) if (in.mesh >= 0 && (size_t)in.mesh < nm) transforms += (double)mesh_pts[(size_t)in.mesh].size() / 3.0;
+  const bool tight = transforms <= 2.0e8;
   // proxies: ONE triangle per instance whose corners span exactly the instance's (padded) world box, prim = instance record index
   std::vector<float> proxy9; std::vector<int32_t> proxy_id;
   for (size_t ii = 0; ii < insts.size(); ++ii) {
@@ -72,16 +82,21 @@ bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vect
     R.node_base = node_base[in.mesh]; R.tri_base = tri_base[in.mesh]; R.n_tris = ntris[in.mesh]; R.mesh = in.mesh;
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     const std::array<float, 6>& mb = mesh_box[in.mesh];
-    for (int corner = 0; corner < 8; ++corner) {
-      const double x = mb[(corner & 1) ? 3 : 0], y = mb[(corner & 2) ? 4 : 1], z = mb[(corner & 4) ? 5 : 2];
+    const std::vector<float>& pts = mesh_pts[(size_t)in.mesh];
+    const double M[12] = {in.m[0], in.m[1], in.m[2], in.m[3], in.m[4], in.m[5], in.m[6], in.m[7], in.m[8], in.m[9], in.m[10], in.m[11]};
+    double mag[3] = {0.0, 0.0, 0.0};                    // the largest sum of |terms| of a coordinate: what the binary32 transform of the kernels rounds against
+    auto take = [&](double x, double y, double z) {
       for (int r = 0; r < 3; ++r) {
-        const double w = (double)in.m[4 * r] * x + (double)in.m[4 * r + 1] * y + (double)in.m[4 * r + 2] * z + (double)in.m[4 * r + 3];
+        const double a = M[4 * r] * x, b = M[4 * r + 1] * y, c = M[4 * r + 2] * z, w = a + b + c + M[4 * r + 3];
         lo[r] = std::min(lo[r], w); hi[r] = std::max(hi[r], w);
+        mag[r] = std::max(mag[r], std::fabs(a) + std::fabs(b) + std::fabs(c) + std::fabs(M[4 * r + 3]));
       }
-    }
+    };
+    if (tight) for (size_t v = 0; v + 2 < pts.size(); v += 3) take(pts[v], pts[v + 1], pts[v + 2]);
+    else for (int corner = 0; corner < 8; ++corner) take(mb[(corner & 1) ? 3 : 0], mb[(corner & 2) ? 4 : 1], mb[(corner & 4) ? 5 : 2]);
     float flo[3], fhi[3];
     for (int r = 0; r < 3; ++r) {        // pad: the ray is taken to object space in binary32, so the world box must not be tight
-      const double pad = 1.0e-4 * (hi[r] - lo[r]) + 1.0e-5 * std::max(std::fabs(lo[r]), std::fabs(hi[r])) + 1.0e-6;
+      const double pad = 1.0e-4 * (hi[r] - lo[r]) + 1.0e-5 * std::max(std::fabs(lo[r]), std::fabs(hi[r])) + 1.0e-6 * mag[r] + 1.0e-6;
       flo[r] = (float)(lo[r] - pad); fhi[r] = (float)(hi[r] + pad);
     }
     const float p[9] = {flo[0], flo[1], flo[2], fhi[0], fhi[1], fhi[2], flo[0], fhi[1], flo[2]};
