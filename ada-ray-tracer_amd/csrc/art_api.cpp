@@ -1050,6 +1050,7 @@ static int set_option_one(const std::string& n, int64_t value) {
   else if (n == "bvh_width") { if (value != 4 && value != 8) return fail("bvh_width: 4 or 8"); g_ctx.bvh_params.width = (int)value; }
   else if (n == "lds_stack_cap") { if (value < 0 || value > kStackEntries) return fail("lds_stack_cap: 0 (automatic) .. 160"); g_ctx.lds_stack_cap = (int)value; }
   else if (n == "bvh_max_leaf") { if (value < 0 || value > kMaxLeafTris) return fail("bvh_max_leaf: 1..8, 0 = defaults"); g_ctx.bvh_params.max_leaf = value ? (int)value : BvhBuildParams().max_leaf; g_ctx.bvh_params.gpu_max_leaf = (int)value; }
+  else if (n == "inst_open") { if (value < 0 || value > 4096) return fail("inst_open: 1 .. 4096 entry points per instance, 0 = chosen from the instances' overlap"); g_ctx.bvh_params.inst_open = (int)value; }
   else if (n == "bvh_spatial_splits") { g_ctx.bvh_params.spatial_alpha = value ? 1.0e-5f : -1.0f; }   // host builder: SBVH reference splitting
   else if (n == "bvh_builder") { if (value < 0 || value > 3) return fail("bvh_builder: 0 host SAH, 1 GPU LBVH, 2 GPU PLOC, 3 GPU SAH"); g_ctx.bvh_params.builder = (int)value; }
   else if (n == "bvh_ploc_radius") { if (value < 1 || value > 64) return fail("bvh_ploc_radius: 1..64"); g_ctx.bvh_params.ploc_radius = (int)value; }

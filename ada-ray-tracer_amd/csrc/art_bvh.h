@@ -29,6 +29,9 @@ struct BvhBuildParams {
                                  // 0: binned SAH on the host (art_bvh.cpp; also used below 2 triangles and for spatial splits); 1 LBVH, 2 PLOC on the GPU (art_lbvh.hip)
   int   collapse = 0;            // BVH2 -> wide: 0 open the child with the largest area until the node is full; 1 cost-optimal (fewest expected wide-node visits)
   int   ploc_radius = 8;         // PLOC: neighbours searched on either side
+  int   inst_open = 0;           // instanced scenes: entry points per instance the instance tree ends at, on average (art_instanced_build.h).  1: whole
+                                 // instances; 0 (default): 1 where the instances' boxes overlap little, up to 64 where they interpenetrate -- the rule and
+                                 // the measurements behind it are in art_instanced_build.cpp
   int   gpu_max_leaf = 0;        // GPU builders: a subtree of at most this many triangles becomes one leaf; 0 = measured optimum
                                  // (1 for width 4, 2 for width 8: their trees have no SAH leaf term, small leaves cull better)
   int   quantise = 1;            // width 4: child boxes snapped outwards to the 8-bit grid of the 64-byte node (art_qnode.h); 0 keeps binary32 boxes

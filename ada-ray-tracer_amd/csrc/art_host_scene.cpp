@@ -86,20 +86,22 @@ bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& o
       insts[(size_t)i].mesh = in.mesh; std::memcpy(insts[(size_t)i].m, in.m, 48);
     }
     // boxes of the meshes' trees padded for the object-space walk (art_instanced.h instanced_render_closest)
-    if (!build_two_level_host(meshes, insts, out.two, err, false, 1.0e-4f, 1.0e-5f)) return false;
+    if (!build_two_level_host(meshes, insts, out.two, err, false, 1.0e-4f, 1.0e-5f, bp.inst_open)) return false;
     int shift = 0; while ((1 << shift) < max_tris) ++shift;
     if (shift > 27 || ((uint64_t)d.n_instances << shift) > (1ull << 28)) { err = "scene: instances x triangles per mesh exceed the 28-bit hit index"; return false; }
     int64_t total = 0;
-    out.inst.resize((size_t)d.n_instances);
-    for (int i = 0; i < d.n_instances; ++i) {
-      const InstRec& R = out.two.inst[(size_t)i];                 // (one-sided builds keep every instance: index = the caller's)
-      DevInstance& D = out.inst[(size_t)i];
-      std::memcpy(D.m, d.instances[i].m, 48); std::memcpy(D.minv, R.minv, 48);
-      D.node_base = R.node_base; D.tri_base = R.tri_base; D.qroot = (uint32_t)out.two.qnode_base[(size_t)R.mesh] * (uint32_t)kQNodeBytes; D.shade_base = shade_base[(size_t)R.mesh];
-      total += R.n_tris;
+    out.inst.assign(out.two.entry.size(), DevInstance{});         // one record per entry point: the instances first (art_scene.h DevInstance)
+    for (size_t e = 0; e < out.two.entry.size(); ++e) {
+      const TwoLevelHost::EntryPoint& E = out.two.entry[e];
+      const InstRec& R = out.two.inst[(size_t)E.inst];            // (one-sided builds keep every instance: index = the caller's)
+      DevInstance& D = out.inst[e];
+      std::memcpy(D.m, d.instances[E.inst].m, 48); std::memcpy(D.minv, R.minv, 48);
+      D.node_base = R.node_base; D.tri_base = R.tri_base; D.shade_base = shade_base[(size_t)R.mesh];
+      D.root_entry = E.root_entry; D.qroot = E.qroot; D.inst = E.inst;
     }
+    for (int i = 0; i < d.n_instances; ++i) total += out.two.inst[(size_t)i].n_tris;
     if (total >= (1ll << 31)) { err = "scene: too many instanced triangles"; return false; }
-    h.n_inst = d.n_instances; h.inst_shift = shift; h.n_tris = (int32_t)total; h.n_nodes = out.two.tlas.n_nodes; h.node_width = 4;
+    h.n_inst = d.n_instances; h.n_entry = (int32_t)out.two.entry.size(); h.inst_shift = shift; h.n_tris = (int32_t)total; h.n_nodes = out.two.tlas.n_nodes; h.node_width = 4;
     out.bvh.width = 4; out.bvh.max_stack = std::max(out.two.tlas.max_stack + 3 + out.two.blas_max_stack, 8);      // instance tree + the "leave" marker over two entries of saved world-space state + a mesh's tree, on one stack
     out.bvh.n_nodes = out.two.tlas.n_nodes + (int32_t)(out.two.blas_nodes.size() / node_floats(4)); out.bvh.n_tris = (int32_t)total;      // (art_export_bvh's info: the two-level tree's sizes)
     return true;

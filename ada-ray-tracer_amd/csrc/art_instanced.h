@@ -138,12 +138,12 @@ ART_HD void instanced_render_closest(const DevScene& S, f3 o, f3 d, Cand& best, 
       for (int a = nh - 1; a >= 0 && sp < kTop; --a) { stk_ref[sp] = ent[a]; stk_t[sp] = tm[a]; ++sp; }
     } else {
       for (int j = 0; j < cnt; ++j) {
-        const int32_t ii = __builtin_bit_cast(int32_t, S.tlas_tris[(size_t)(ref + j) * kTriFloats + 9]);
-        const DevInstance& R = S.inst[ii];
+        const int32_t ee = __builtin_bit_cast(int32_t, S.tlas_tris[(size_t)(ref + j) * kTriFloats + 9]);      // the proxy names an ENTRY POINT (art_scene.h DevInstance)
+        const DevInstance& R = S.inst[ee];
         const f3 oo = xform_point(R.minv, o), dd = xform_dir(R.minv, d);
         const float* const tris = S.blas_tris + (size_t)R.tri_base * kTriFloats;
-        const uint32_t key_base = KEY_TRI | ((uint32_t)ii << S.inst_shift);
-        bvh_walk<STATS>(S.blas_nodes + (size_t)R.node_base * (size_t)node_floats(W), W, oo, dd, best, st, sh, [&](int32_t r0, int32_t c0) {
+        const uint32_t key_base = KEY_TRI | ((uint32_t)R.inst << S.inst_shift);
+        bvh_walk<STATS>(S.blas_nodes + (size_t)R.node_base * (size_t)node_floats(W), W, oo, dd, best, st, sh, R.root_entry, [&](int32_t r0, int32_t c0) {
           for (int q = 0; q < c0; ++q) {
             const float* tr = tris + (size_t)(r0 + q) * kTriFloats;
             const f3 A = xform_point(R.m, ld3(tr)), B = xform_point(R.m, ld3(tr + 3)), C = xform_point(R.m, ld3(tr + 6));

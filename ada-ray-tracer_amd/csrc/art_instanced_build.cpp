@@ -24,7 +24,7 @@ static bool invert_3x4(const float m[12], float out[12]) {     // world -> objec
 }
 
 bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vector<InstIn>& insts, TwoLevelHost& T, std::string& err,
-                          bool two_sided, float pad_rel, float pad_abs) {
+                          bool two_sided, float pad_rel, float pad_abs, int open_factor) {
   T = TwoLevelHost();
   BvhBuildParams bp; bp.width = 4;
   if (pad_rel >= 0.0f) bp.inflate_rel = pad_rel;
@@ -34,6 +34,7 @@ bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vect
   std::vector<std::array<float, 6>> mesh_box(nm);
   std::vector<std::vector<uint32_t>> mesh_q;             // one-sided builds: every mesh's quantised nodes, relocated below
   std::vector<std::vector<float>> mesh_pts(nm);          // the vertices a mesh's triangles use (an instance's world box is the box of their images)
+  std::vector<const float*> inst_m;                      // the kept instances' matrices (the caller's arrays)
   for (size_t mi = 0; mi < nm; ++mi) {
     const InstMeshIn& m = meshes[mi];
     if (m.n_tris == 0 || m.n_verts == 0) { err = "empty mesh"; return false; }
@@ -69,8 +70,30 @@ bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vect
   double transforms = 0.0;
   for (const InstIn& in : insts) if (in.mesh >= 0 && (size_t)in.mesh < nm) transforms += (double)mesh_pts[(size_t)in.mesh].size() / 3.0;
   const bool tight = transforms <= 2.0e8;
-  // proxies: ONE triangle per instance whose corners span exactly the instance's (padded) world box, prim = instance record index
-  std::vector<float> proxy9; std::vector<int32_t> proxy_id;
+  // ---- instances, and the entry points the instance tree will end at (art_scene.h DevInstance).  One per instance to begin with: the
+  // mesh's root under the box of the whole instance.  One-sided builds with open_factor > 1 then OPEN entry points, largest world box
+  // first, into the children of their node -- each child under the tight world box of ITS triangles -- until there are open_factor x
+  // instances of them (or nothing is left to open, or the transform budget is spent).
+  struct Open { double area; int32_t inst, entry; float lo[3], hi[3]; };
+  std::vector<Open> heap, closed;
+  auto world_box = [&](const float m[12], auto&& each_point, Open& o) {     // box of the transformed points, padded (see below)
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    double mag[3] = {0.0, 0.0, 0.0};                    // the largest sum of |terms| of a coordinate: what the binary32 transform of the kernels rounds against
+    const double M[12] = {m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9], m[10], m[11]};
+    each_point([&](double x, double y, double z) {
+      for (int r = 0; r < 3; ++r) {
+        const double a = M[4 * r] * x, b = M[4 * r + 1] * y, c = M[4 * r + 2] * z, w = a + b + c + M[4 * r + 3];
+        lo[r] = std::min(lo[r], w); hi[r] = std::max(hi[r], w);
+        mag[r] = std::max(mag[r], std::fabs(a) + std::fabs(b) + std::fabs(c) + std::fabs(M[4 * r + 3]));
+      }
+    });
+    for (int r = 0; r < 3; ++r) {        // pad: the ray is taken to object space in binary32, so the world box must not be tight
+      const double pad = 1.0e-4 * (hi[r] - lo[r]) + 1.0e-5 * std::max(std::fabs(lo[r]), std::fabs(hi[r])) + 1.0e-6 * mag[r] + 1.0e-6;
+      o.lo[r] = (float)(lo[r] - pad); o.hi[r] = (float)(hi[r] + pad);
+    }
+    const double ex = (double)o.hi[0] - o.lo[0], ey = (double)o.hi[1] - o.lo[1], ez = (double)o.hi[2] - o.lo[2];
+    o.area = ex * ey + ey * ez + ez * ex;
+  };
   for (size_t ii = 0; ii < insts.size(); ++ii) {
     const InstIn& in = insts[ii];
     if (in.mesh < 0 || (size_t)in.mesh >= nm) { err = "instance of a missing mesh"; return false; }
@@ -80,32 +103,84 @@ bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vect
       continue;
     }
     R.node_base = node_base[in.mesh]; R.tri_base = tri_base[in.mesh]; R.n_tris = ntris[in.mesh]; R.mesh = in.mesh;
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     const std::array<float, 6>& mb = mesh_box[in.mesh];
     const std::vector<float>& pts = mesh_pts[(size_t)in.mesh];
-    const double M[12] = {in.m[0], in.m[1], in.m[2], in.m[3], in.m[4], in.m[5], in.m[6], in.m[7], in.m[8], in.m[9], in.m[10], in.m[11]};
-    double mag[3] = {0.0, 0.0, 0.0};                    // the largest sum of |terms| of a coordinate: what the binary32 transform of the kernels rounds against
-    auto take = [&](double x, double y, double z) {
-      for (int r = 0; r < 3; ++r) {
-        const double a = M[4 * r] * x, b = M[4 * r + 1] * y, c = M[4 * r + 2] * z, w = a + b + c + M[4 * r + 3];
-        lo[r] = std::min(lo[r], w); hi[r] = std::max(hi[r], w);
-        mag[r] = std::max(mag[r], std::fabs(a) + std::fabs(b) + std::fabs(c) + std::fabs(M[4 * r + 3]));
-      }
-    };
-    if (tight) for (size_t v = 0; v + 2 < pts.size(); v += 3) take(pts[v], pts[v + 1], pts[v + 2]);
-    else for (int corner = 0; corner < 8; ++corner) take(mb[(corner & 1) ? 3 : 0], mb[(corner & 2) ? 4 : 1], mb[(corner & 4) ? 5 : 2]);
-    float flo[3], fhi[3];
-    for (int r = 0; r < 3; ++r) {        // pad: the ray is taken to object space in binary32, so the world box must not be tight
-      const double pad = 1.0e-4 * (hi[r] - lo[r]) + 1.0e-5 * std::max(std::fabs(lo[r]), std::fabs(hi[r])) + 1.0e-6 * mag[r] + 1.0e-6;
-      flo[r] = (float)(lo[r] - pad); fhi[r] = (float)(hi[r] + pad);
-    }
-    const float p[9] = {flo[0], flo[1], flo[2], fhi[0], fhi[1], fhi[2], flo[0], fhi[1], flo[2]};
-    proxy9.insert(proxy9.end(), p, p + 9);
-    proxy_id.push_back((int32_t)T.inst.size());
+    Open o; o.inst = (int32_t)T.inst.size(); o.entry = 0;
+    world_box(in.m, [&](auto&& take) {
+      if (tight) for (size_t v = 0; v + 2 < pts.size(); v += 3) take(pts[v], pts[v + 1], pts[v + 2]);
+      else for (int corner = 0; corner < 8; ++corner) take(mb[(corner & 1) ? 3 : 0], mb[(corner & 2) ? 4 : 1], mb[(corner & 4) ? 5 : 2]);
+    }, o);
+    heap.push_back(o);
     T.inst.push_back(R);
     T.inst_src.push_back((int32_t)ii);
+    inst_m.push_back(in.m);
   }
   if (T.inst.empty()) { err = "no valid instances"; return false; }
+  if (!two_sided && open_factor == 0) {
+    // automatic: rho = the instances' box areas over the area of the box around all of them = how many instance boxes a random line
+    // through the scene crosses.  Opening pays where instances interpenetrate (a ray inside three or four boxes at once cannot use the
+    // hit it found in one mesh to skip the others before it has entered them) and costs where they do not (a ray enters the same
+    // instance two or three times).  Measured (profiles/r5_instanced.json): I64, rho = 1.7: 3478 Mrays/s at whole instances, 3182 / 2961
+    // at 4 / 64 entry points per instance; its 64 instances pulled into one cluster, rho = 13.6: 2915 at whole instances, 3419 / 3960.
+    double sum = 0.0; float ulo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, uhi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (const Open& o : heap) { sum += o.area; for (int r = 0; r < 3; ++r) { ulo[r] = std::min(ulo[r], o.lo[r]); uhi[r] = std::max(uhi[r], o.hi[r]); } }
+    const double ex = (double)uhi[0] - ulo[0], ey = (double)uhi[1] - ulo[1], ez = (double)uhi[2] - ulo[2];
+    const double rho = sum / std::max(ex * ey + ey * ez + ez * ex, 1.0e-30);
+    open_factor = (rho > 4.0) ? (int)std::min(64.0, 4.0 * rho) : 1;
+  }
+  T.open_factor = std::max(1, open_factor);
+  if (!two_sided && open_factor > 1 && tight) {
+    auto by_area = [](const Open& a, const Open& b) { return a.area < b.area || (a.area == b.area && (a.inst > b.inst || (a.inst == b.inst && a.entry > b.entry))); };
+    std::make_heap(heap.begin(), heap.end(), by_area);
+    const size_t target = std::min<size_t>((size_t)open_factor * T.inst.size(), (size_t)1 << 26);
+    std::vector<int32_t> walk;
+    while (!heap.empty() && heap.size() + closed.size() < target) {
+      std::pop_heap(heap.begin(), heap.end(), by_area);
+      const Open o = heap.back(); heap.pop_back();
+      const InstRec& R = T.inst[(size_t)o.inst];
+      if ((o.entry & 15) != 0 || transforms > 2.0e8) { closed.push_back(o); continue; }      // a leaf, or the budget is spent: stays as it is
+      const float* nd = &T.blas_nodes[((size_t)R.node_base + (size_t)(o.entry >> 4)) * (size_t)node_floats(4)];
+      for (int j = 0; j < 4; ++j) {
+        const int32_t rj = __builtin_bit_cast(int32_t, nd[4 * j + 3]);
+        if (rj < 0) continue;
+        Open c; c.inst = o.inst; c.entry = (rj << 4) | __builtin_bit_cast(int32_t, nd[16 + 4 * j + 3]);
+        world_box(inst_m[(size_t)o.inst], [&](auto&& take) {       // the corners of every triangle below the child
+          walk.assign(1, c.entry);
+          while (!walk.empty()) {
+            const int32_t e = walk.back(); walk.pop_back();
+            if (e & 15) {
+              for (int q = 0; q < (e & 15); ++q) {
+                const float* tr = &T.blas_tris[((size_t)R.tri_base + (size_t)(e >> 4) + (size_t)q) * kTriFloats];
+                take(tr[0], tr[1], tr[2]); take(tr[3], tr[4], tr[5]); take(tr[6], tr[7], tr[8]);
+                transforms += 3.0;
+              }
+            } else {
+              const float* n2 = &T.blas_nodes[((size_t)R.node_base + (size_t)(e >> 4)) * (size_t)node_floats(4)];
+              for (int k = 0; k < 4; ++k) {
+                const int32_t rk = __builtin_bit_cast(int32_t, n2[4 * k + 3]);
+                if (rk >= 0) walk.push_back((rk << 4) | __builtin_bit_cast(int32_t, n2[16 + 4 * k + 3]));
+              }
+            }
+          }
+        }, c);
+        heap.push_back(c); std::push_heap(heap.begin(), heap.end(), by_area);
+      }
+    }
+  }
+  closed.insert(closed.end(), heap.begin(), heap.end());
+  std::stable_sort(closed.begin(), closed.end(), [](const Open& a, const Open& b) { return a.inst < b.inst || (a.inst == b.inst && a.entry < b.entry); });
+  // entry point numbering: instance i's first one is entry i, the others follow behind the instances
+  T.entry.assign(T.inst.size(), TwoLevelHost::EntryPoint{-1, 0, 0u});
+  std::vector<float> proxy9; std::vector<int32_t> proxy_id;
+  for (const Open& o : closed) {
+    int32_t id = o.inst;
+    if (T.entry[(size_t)o.inst].inst >= 0) { id = (int32_t)T.entry.size(); T.entry.push_back(TwoLevelHost::EntryPoint{-1, 0, 0u}); }
+    T.entry[(size_t)id] = TwoLevelHost::EntryPoint{o.inst, o.entry, 0u};
+    // proxy: ONE triangle whose corners span exactly the entry point's (padded) world box, prim = the entry point
+    const float p[9] = {o.lo[0], o.lo[1], o.lo[2], o.hi[0], o.hi[1], o.hi[2], o.lo[0], o.hi[1], o.lo[2]};
+    proxy9.insert(proxy9.end(), p, p + 9);
+    proxy_id.push_back(id);
+  }
   BvhBuildParams tp; tp.width = 4; tp.max_leaf = 1;
   if (!build_bvh8(proxy9.data(), proxy_id.data(), (int32_t)proxy_id.size(), tp, T.tlas, err)) return false;
   if (T.tlas.max_stack > kInstTopStack) { err = "instance tree stack bound " + std::to_string(T.tlas.max_stack) + " exceeds " + std::to_string(kInstTopStack); return false; }
@@ -119,6 +194,14 @@ bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vect
     if (total_nodes * kQNodeBytes >= (1ull << 31) || T.blas_tris.size() / kTriFloats * (size_t)kQTriBytes >= (1ull << 31)) { err = "instanced scene too large for 31-bit node / triangle offsets"; return false; }
     T.qnodes.assign(total_nodes * words, 0u);
     std::memcpy(T.qnodes.data(), T.tlas.qnodes.data(), T.tlas.qnodes.size() * 4);
+    for (TwoLevelHost::EntryPoint& E : T.entry) {         // where an entry point enters, as the kernel's entry word (checked: it is followed blindly)
+      const InstRec& R = T.inst[(size_t)E.inst];
+      const size_t ref = (size_t)(E.root_entry >> 4), cnt = (size_t)(E.root_entry & 15);
+      const size_t mesh_nodes = mesh_q[(size_t)R.mesh].size() / words;
+      if (cnt ? (cnt > 4 || ref + cnt > (size_t)ntris[(size_t)R.mesh]) : (ref >= mesh_nodes)) { err = "internal: entry point outside its mesh's tree"; return false; }
+      E.qroot = cnt ? (kQEntryLeaf | (uint32_t)(((size_t)R.tri_base + ref) * (size_t)kQTriBytes) | (uint32_t)cnt)
+                    : (uint32_t)(((size_t)T.qnode_base[(size_t)R.mesh] + ref) * (size_t)kQNodeBytes);
+    }
     for (int32_t n = 0; n < T.tlas.n_nodes; ++n)
       for (int j = 0; j < 4; ++j) {
         uint32_t& e = T.qnodes[(size_t)n * words + 4 * (size_t)j + 2];
@@ -158,7 +241,7 @@ bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vect
         if (e == kQEntryEmpty) continue;
         if (e & kQEntryLeaf) {
           const uint32_t cnt = e & 15u, off = e & 0x7ffffff0u;
-          if (owner < 0) { if (cnt != kQCountInstance || (off >> 4) >= T.inst.size()) { err = "internal: bad instance marker in the instance tree"; return false; } }
+          if (owner < 0) { if (cnt != kQCountInstance || (off >> 4) >= T.entry.size()) { err = "internal: bad instance marker in the instance tree"; return false; } }
           else {
             const size_t first = off / (size_t)kQTriBytes, base = (size_t)tri_base[(size_t)owner];
             if (cnt < 1 || cnt > 4 || (off % kQTriBytes) != 0 || first < base || first + cnt > base + (size_t)ntris[(size_t)owner]) { err = "internal: bad leaf in a mesh's tree"; return false; }

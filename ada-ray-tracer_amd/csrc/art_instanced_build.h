@@ -21,6 +21,11 @@ struct TwoLevelHost {
   // (art_qnode.h): the instance tree first (its leaves rewritten to instance markers, kQEntryInstance), then every mesh's tree with its
   // entry words made absolute (node offsets + qnode_base[mesh], triangle offsets + the mesh's tri_base).  qnode_base: first node per mesh.
   std::vector<uint32_t> qnodes; std::vector<int32_t> qnode_base;
+  // what the instance tree's leaves name (art_scene.h DevInstance): entry[i], i < inst.size(), is instance i's first (or only) entry point,
+  // further ones follow.  root_entry: (node << 4) | 0 or (first record << 4) | count inside the mesh's tree; qroot: the cooperative kernel's word.
+  struct EntryPoint { int32_t inst; int32_t root_entry; uint32_t qroot; };
+  std::vector<EntryPoint> entry;
+  int32_t open_factor = 1;              // entry points per instance asked of the build (the automatic choice, if that was left to it)
   int32_t blas_max_stack = 0;           // the largest worst-case traversal stack of the meshes' trees
   InstScene view() const {
     InstScene S;
@@ -35,7 +40,9 @@ struct TwoLevelHost {
 // index in the mesh -- the reference's one-sided test; the meshes' boxes then carry the wider padding `pad_rel` / `pad_abs` (the walk
 // tests them with the ray taken to object space in binary32, while the triangles are tested in world space: no box may cull a
 // triangle that the world-space arithmetic would accept), and a singular instance matrix is an error instead of a dropped instance.
+// open_factor > 1 (one-sided builds): the instance tree ends at about open_factor entry points per instance -- subtrees of the meshes'
+// trees under the tight world boxes of their own triangles -- instead of at whole instances.  0: chosen from how much the instances' boxes overlap.
 bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vector<InstIn>& insts, TwoLevelHost& out, std::string& err,
-                          bool two_sided = true, float pad_rel = -1.0f, float pad_abs = -1.0f);
+                          bool two_sided = true, float pad_rel = -1.0f, float pad_abs = -1.0f, int open_factor = 1);
 
 }  // namespace art

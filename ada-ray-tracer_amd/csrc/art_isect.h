@@ -213,12 +213,12 @@ ART_HD bool shadow_rule(ShadowState& sh, Cand& best) {
 // [ref, ref + cnt) and updates `best` (bvh_closest: the records ARE the triangles; the instanced render search of art_instanced.h walks a
 // mesh's tree with the object-space ray and tests the triangles in world space).
 template <bool STATS, class Leaf>
-ART_HD void bvh_walk(const float* nodes, int W, f3 o, f3 d, Cand& best, BvhStats* st, ShadowState& sh, Leaf leaf) {
+ART_HD void bvh_walk(const float* nodes, int W, f3 o, f3 d, Cand& best, BvhStats* st, ShadowState& sh, int32_t root, Leaf leaf) {
   f3 inv, noi;
   slab_setup(o, d, inv, noi);
   int32_t stk_ref[kStackEntries]; float stk_t[kStackEntries];
   int sp = 0;
-  stk_ref[sp] = 0; stk_t[sp] = 0.0f; ++sp;        // entry = (ref << 4) | count
+  stk_ref[sp] = root; stk_t[sp] = 0.0f; ++sp;     // entry = (ref << 4) | count; root: 0 = node 0, or where an instance's entry point starts (a subtree, even a leaf)
   while (sp > 0) {
     --sp;
     const int32_t e = stk_ref[sp];
@@ -257,7 +257,7 @@ ART_HD void bvh_walk(const float* nodes, int W, f3 o, f3 d, Cand& best, BvhStats
 template <bool STATS>
 ART_HD void bvh_closest(const DevScene& s, f3 o, f3 d, Cand& best, BvhStats* st, ShadowState& sh) {
   if (s.n_tris <= 0) return;
-  bvh_walk<STATS>(s.nodes, s.node_width, o, d, best, st, sh, [&](int32_t ref, int32_t cnt) {
+  bvh_walk<STATS>(s.nodes, s.node_width, o, d, best, st, sh, 0, [&](int32_t ref, int32_t cnt) {
     for (int j = 0; j < cnt; ++j) tri_leaf_test(s.tris + (size_t)(ref + j) * kTriFloats, o, d, best);
   });
 }

@@ -208,7 +208,7 @@ __device__ __forceinline__ uint32_t key_masked(mask_t hit, uint32_t tmn_bits, ui
 // offset | count (leaf), exactly as stored in the node, so a pop needs no decoding.  G = 8 walks the binary32 256-byte nodes; its
 // entry word is (ref << 4) | count.
 // INST (round 5, G = 4): the quantised node array holds a TWO-LEVEL tree (art_instanced_build.cpp: the instance tree first, then every mesh's
-// tree in object space, entry words absolute).  A leaf entry with count 15 names an instance: the group takes its ray into the mesh's
+// tree in object space, entry words absolute).  A leaf entry with count 15 names an entry point of an instance (a whole instance, or a subtree of its mesh: art_scene.h DevInstance): the group takes its ray into the mesh's
 // space (inv, noi and the plane selectors are replaced; o and d stay the world ray), pushes a "leave" marker (count 14) and goes on
 // with the mesh's root; popped, the marker restores the world-space inv / noi / selectors from the ray's trace record.  t means the same in
 // both spaces (the direction is not renormalised), so stack entries and the running bound carry over.  A mesh triangle is tested in WORLD
@@ -519,10 +519,10 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
         if (sp_mask != 0) {                                // rare next to node steps: a few instances per ray
           bool enter = special && (cnt == (int)kQCountInstance);
           if (enter) {
-            const uint32_t ii = (pend >> 4) & 0x07ffffffu;
+            const uint32_t ii = (pend >> 4) & 0x07ffffffu;       // an ENTRY POINT of an instance (art_scene.h DevInstance)
             const char* const ib = reinterpret_cast<const char*>(A.inst) + (size_t)ii * sizeof(DevInstance);
             const float4 w0 = *reinterpret_cast<const float4*>(ib + 48), w1 = *reinterpret_cast<const float4*>(ib + 64), w2 = *reinterpret_cast<const float4*>(ib + 80);
-            const uint4 wi = *reinterpret_cast<const uint4*>(ib + 96);
+            const uint2 wi = *reinterpret_cast<const uint2*>(ib + 112);      // DevInstance::qroot, inst
             const float mi[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
             const f3 oo = xform_point(mi, o), dd = mk3(mi[0] * d.x + mi[1] * d.y + mi[2] * d.z, mi[4] * d.x + mi[5] * d.y + mi[6] * d.z, mi[8] * d.x + mi[9] * d.y + mi[10] * d.z);
             const uint32_t top = sa + 24u;                 // three entries: the world-space inv.xy | inv.z, near-plane selector | the "leave" marker on top
@@ -539,8 +539,8 @@ __global__ __launch_bounds__(256, ART_COOP_WAVES_PER_SIMD) void k_trace_coop(con
               const uint32_t sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
               sel_near = (sx ? 3u : 0u) | ((sy ? 4u : 1u) << 8) | ((sz ? 5u : 2u) << 16) | 0x0c000000u; sel_far = 0x18070503u - sel_near;
               sa = top;
-              cur_inst = (int)ii;
-              pend = wi.z;                                 // DevInstance::qroot: the mesh's root, an inner entry
+              cur_inst = (int)wi.y;                        // the entry point's instance: what a hit's key and the triangles' matrix go by
+              pend = wi.x;                                 // DevInstance::qroot: where this entry point enters the mesh's tree (an inner entry, or a leaf: the next pop's business either way)
             }
           }                                                // (a "leave" marker never gets here: the inner loop consumes it as it pops it)
           entered = ballot64(enter);

@@ -61,14 +61,25 @@ constexpr int kStackEntries = 160;  // private stack of the one-ray-per-lane tra
 
 // One instance of a mesh (round 5: art_upload_scene takes meshes + 3x4 instance transforms, embree_connect.cpp:147-184, and the render loop
 // walks them as a two-level tree without flattening).  key index of a hit = instance << DevScene::inst_shift | triangle of the mesh.
+//
+// ENTRY POINTS.  The instance tree does not have to end at whole instances: an instance may be "opened" at build time (art_instanced_build.cpp),
+// its mesh's tree entered at several subtrees instead of at the root, each with the tight world box of ITS triangles -- a torus or a
+// rotated plate overlaps far fewer neighbours that way, and every overlap is a mesh tree entered for nothing.  The table therefore holds
+// DevScene::n_entry >= n_inst records: record i < n_inst is instance i (and its first entry point), the records behind are further
+// entry points (copies of their instance's record but for the two root words).  The searches index the table by ENTRY (what an instance
+// tree leaf names), shading by INSTANCE (what a hit's key names: `inst`).
 struct DevInstance {
   float m[12];                 // object -> world, 3x4 row-major (the first 12 floats of the reference's 16-float block, embree_connect.cpp:169)
   float minv[12];              // world -> object
   int32_t node_base;           // first node of the mesh's tree in DevScene::blas_nodes (in nodes)
   int32_t tri_base;            // first triangle record of the mesh in DevScene::blas_tris (object space, one winding, prim = triangle of the mesh)
-  uint32_t qroot;              // the mesh's root as an entry word of the cooperative kernel's quantised node array (its byte offset there)
   int32_t shade_base;          // first shading record of the mesh in DevScene::m_shade (object-space vertex normals + material id)
+  int32_t root_entry;          // where this entry point enters the mesh's tree: (node << 4) or (first record << 4) | count, relative to node_base / tri_base (0: the root)
+  uint32_t qroot;              // the same as an entry word of the cooperative kernel's quantised node array (absolute: node byte offset, or leaf flag | record byte offset | count)
+  int32_t inst;                // the instance this entry point belongs to (= its own index for the first n_inst records)
+  int32_t pad_[2];
 };
+static_assert(sizeof(DevInstance) == 128, "k_trace_coop reads the instance table by byte offsets");
 
 struct DevScene {
   int32_t n_spheres; const DevSphere* spheres; const int32_t* sphere_mat;
@@ -90,8 +101,8 @@ struct DevScene {
   const float* m_shade;
   // instanced closest-hit meshes (n_inst > 0; then nodes / tris above are unused and n_tris is the instances' total): a 4-wide tree over
   // the instances' world boxes (a leaf holds ONE proxy record whose prim is the instance), one tree per mesh in object space
-  int32_t n_inst, inst_shift;
-  const DevInstance* inst;
+  int32_t n_inst, inst_shift, n_entry;
+  const DevInstance* inst;     // n_entry records (see DevInstance)
   const float* tlas_nodes; const float* tlas_tris; const float* blas_nodes; const float* blas_tris;
   // camera (scene.ads:27-32)
   float cam_pos[3];

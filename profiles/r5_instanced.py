@@ -34,7 +34,7 @@ def run(art, be, sd, label, opts=()):
                 "wave_iters_per_kray": round(1000.0 * (c1.wave_iters - c0.wave_iters) / nr, 1), "node_phase_iters_per_kray": round(1000.0 * (c1.node_phase_iters - c0.node_phase_iters) / nr, 1),
                 "leaf_phase_iters_per_kray": round(1000.0 * (c1.leaf_phase_iters - c0.leaf_phase_iters) / nr, 1)}
     for k, v in opts:
-        be.set_option(k, 1 if k == "inst_coop" else 0)
+        be.set_option(k, 1 if k == "inst_coop" else 0 if k == "inst_open" else 0)
     return {"counters": counters, "variant": label, "Mrays_per_s": round((s1.rays - s0.rays) / dt / 1e6, 1), "ms_per_64spp_step": round(dt * 500.0, 1), "trace_ms_per_step": round((s1.trace_ms - s0.trace_ms) / 2, 1),
             "scene_upload_s": round(t_up, 2), "tree_nodes": info.n_nodes, "tree_triangle_records": info.n_tris}
 
@@ -46,9 +46,24 @@ def main():
     sd = scenes.instanced_scene(64, 20000)
     flat = hostsim.flattened_copy(art, sd)
     be = art.Backend(0)
-    out = [run(art, be, sd, "instanced, cooperative kernel (k_trace_coop<.., INST>)"),
-           run(art, be, sd, "instanced, one ray per lane (k_trace_inst)", [("inst_coop", 0)]),
-           run(art, be, flat, "flattened upload: one tree over 1.28 M world-space triangles")]
+    out = [run(art, be, sd, "instanced, cooperative kernel (k_trace_coop<.., INST>), inst_open = 0 (default: chosen by the build -- whole instances here)")]
+    for k in (1, 2, 4, 8, 16, 64):         # entry points per instance the instance tree ends at (art_instanced_build.h)
+        out.append(run(art, be, sd, "instanced, cooperative kernel, inst_open = %d" % k, [("inst_open", k)]))
+    out += [run(art, be, sd, "instanced, one ray per lane (k_trace_inst)", [("inst_coop", 0)]),
+            run(art, be, flat, "flattened upload: one tree over 1.28 M world-space triangles")]
+    # the same 64 instances pulled together into one interpenetrating cluster (translations shrunk to a quarter around the centre of the box,
+    # scales x 1.5): the boxes of whole instances nearly coincide -- the case opening instances is for
+    import numpy as np
+    c = np.array([0.0, 2.3, 2.3])
+    tr = []
+    for i in range(64):
+        M = np.array(list(sd.instances[i].m), np.float64).reshape(3, 4)
+        M[:, 3] = c + 0.25 * (M[:, 3] - c); M[:, :3] *= 1.5
+        tr.append((int(sd.instances[i].mesh), M))
+    sd2 = scenes.instanced_scene(64, 20000, transforms=tr)
+    for k in (0, 1, 4, 16, 64):
+        out.append(run(art, be, sd2, "CLUSTER of the 64 instances, cooperative kernel, inst_open = %d" % k, [("inst_open", k)]))
+    out.append(run(art, be, hostsim.flattened_copy(art, sd2), "CLUSTER, flattened upload"))
     print(json.dumps({"workload": "I64, 1920x1080, PT_MIS depth 8, 2x2 AA, 64 spp per step, 2 timed steps", "results": out}, indent=1))
     be.shutdown()
 

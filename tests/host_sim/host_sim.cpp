@@ -29,6 +29,7 @@ extern "C" void hs_set_bvh_param(const char* name, double v) {
   else if (n == "tri_cost") g_bp.tri_cost = (float)v;
   else if (n == "sah_bins") g_bp.sah_bins = (int)v;
   else if (n == "collapse") g_bp.collapse = (int)v;
+  else if (n == "inst_open") g_bp.inst_open = (int)v;
 
 }
 

@@ -39,11 +39,13 @@ def test_small_instanced_scene_equals_the_oracle_on_the_flattened_scene(art, bac
     assert np.array_equal(bits(accum), bits(ref))
 
 
+@pytest.mark.parametrize("inst_open", [0, 1, 8, 1000])
 @pytest.mark.parametrize("kernel", ["coop", "coop_stack_cap_3", "one_ray_per_lane"])
-def test_mirrored_sheared_coincident_tiny_and_huge_instances(art, backend, kernel):
+def test_mirrored_sheared_coincident_tiny_and_huge_instances(art, backend, kernel, inst_open):
     """hostsim.awkward_instances (a mirror image, one transform twice -- equal t, the lower hit index wins --, a shear, scales 1e-3 and 2.2,
     interpenetrating instances; glass, mirror and Phong triangles): the oracle's O(N) scan of the flattened mesh, whole frame, and the
-    hit indices of the debug pass against the flattened upload's"""
+    hit indices of the debug pass against the flattened upload's.  inst_open: the instance tree ends at whole instances (1; 0, the default, chooses: 1 here), at about 8
+    subtrees per instance (the default), at every leaf of the meshes' trees (1000 asked for: an entry point may then BE a leaf)."""
     from ada_ray_tracer_amd import scenes
     tr = hostsim.awkward_instances()
     sd = scenes.instanced_scene(0, 260, transforms=tr, all_materials=True)
@@ -51,13 +53,14 @@ def test_mirrored_sheared_coincident_tiny_and_huge_instances(art, backend, kerne
     p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=77)
     backend.set_option("inst_coop", 0 if kernel == "one_ray_per_lane" else 1)
     backend.set_option("lds_stack_cap", 3 if kernel == "coop_stack_cap_3" else 0)
+    backend.set_option("inst_open", inst_open)
     try:
         backend.upload_scene(sd); backend.resize(128, 96)
         accum, _, spp = backend.render_pass(p, 0)
         rays = backend.stats().rays
         dbg = backend.debug_hit_pass(art.Backend.pass_params(art.RT_DEBUG, False, 8, 1))
     finally:
-        backend.set_option("inst_coop", 1); backend.set_option("lds_stack_cap", 0)
+        backend.set_option("inst_coop", 1); backend.set_option("lds_stack_cap", 0); backend.set_option("inst_open", 0)
     ref, _, cnt = orc.render(conv.OracleScene(flat).scene, orc.make_params(128, 96, orc.PT_MIS, True, 8, 2, seed=77))
     assert spp == 8 and rays == cnt.rays and backend.stats().lost_paths == 0
     assert np.array_equal(bits(accum), bits(ref))

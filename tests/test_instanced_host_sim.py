@@ -31,14 +31,20 @@ def test_instanced_scene_equals_the_oracle_on_the_flattened_scene(art, rt):
     assert float(np.abs(acc).sum()) > 0.0
 
 
-def test_mirrored_sheared_coincident_tiny_and_huge_instances(art):
+@pytest.mark.parametrize("inst_open", [0, 1, 8, 1000])
+def test_mirrored_sheared_coincident_tiny_and_huge_instances(art, inst_open):
     """hostsim.awkward_instances: a mirror image, one transform twice, a shear, scales 1e-3 and 2.2, interpenetrating instances; glass, mirror
-    and Phong triangles on the torus -- still the flattened scene's picture, bit for bit"""
+    and Phong triangles on the torus -- still the flattened scene's picture, bit for bit.  inst_open: the instance tree ends at whole
+    instances (1; 0, the default, chooses: 1 here), at about 8 subtrees per instance, at every LEAF of the meshes' trees (1000 per instance asked for)."""
     from ada_ray_tracer_amd import scenes
     sd = scenes.instanced_scene(0, 260, transforms=hostsim.awkward_instances(), all_materials=True)
     flat = hostsim.flattened_copy(art, sd)
     p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=77)
-    acc, rays = hostsim.render(art, sd, p, 64, 48)
+    hostsim.set_bvh_param(art, "inst_open", inst_open)
+    try:
+        acc, rays = hostsim.render(art, sd, p, 64, 48)
+    finally:
+        hostsim.set_bvh_param(art, "inst_open", 0)
     ref, _, cnt = orc.render(conv.OracleScene(flat).scene, orc.make_params(64, 48, orc.PT_MIS, True, 8, 2, seed=77))
     assert rays == cnt.rays
     assert np.array_equal(bits(acc), bits(ref))
