@@ -103,7 +103,7 @@ bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& o
     if (total >= (1ll << 31)) { err = "scene: too many instanced triangles"; return false; }
     h.n_inst = d.n_instances; h.n_entry = (int32_t)out.two.entry.size(); h.inst_shift = shift; h.n_tris = (int32_t)total; h.n_nodes = out.two.tlas.n_nodes; h.node_width = 4;
     out.bvh.width = 4; out.bvh.max_stack = std::max(out.two.tlas.max_stack + 3 + out.two.blas_max_stack, 8);      // instance tree + the "leave" marker over two entries of saved world-space state + a mesh's tree, on one stack
-    out.bvh.n_nodes = out.two.tlas.n_nodes + (int32_t)(out.two.blas_nodes.size() / node_floats(4)); out.bvh.n_tris = (int32_t)total;      // (art_export_bvh's info: the two-level tree's sizes)
+    out.bvh.n_nodes = out.two.tlas.n_nodes + (int32_t)(out.two.blas_nodes.size() / node_floats(4)); out.bvh.n_tris = (int32_t)(out.two.blas_tris.size() / kTriFloats);      // (art_export_bvh's info: the two-level tree's sizes -- its nodes and the meshes' triangle records)
     return true;
   }
   bool have_bf = false, have_closest = false;
