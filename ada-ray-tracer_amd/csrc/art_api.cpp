@@ -324,7 +324,7 @@ static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
   a.n_rays = n_rays; a.width = c.scene.node_width; a.instanced = c.scene.n_inst > 0 ? (c.inst_coop ? 1 : 2) : 0;
   a.inst = c.scene.inst; a.inst_shift = c.scene.inst_shift;
   { int e; bool o; stack_plan(c.trace_kernel, e, o); a.stack_entries = e; a.stack_overflow = o ? 1 : 0; }
-  a.node_min = c.node_min; a.refill_min = c.refill_min; a.segments = c.queue_segments; a.chunk = c.ray_chunk;
+  a.node_min = c.node_min ? c.node_min : (c.scene.n_inst > 0 ? 2 : 4); a.refill_min = c.refill_min; a.segments = c.queue_segments; a.chunk = c.ray_chunk;
   a.ray_ox = q.ray_ox; a.ray_oy = q.ray_oy; a.ray_oz = q.ray_oz; a.ray_dx = q.ray_dx; a.ray_dy = q.ray_dy; a.ray_dz = q.ray_dz; a.ray_tfar = q.ray_tfar;
   a.hit = q.hit; a.sh_t = q.sh_t;
   a.nodes = c.scene.nodes; a.qnodes = (const uint32_t*)c.b_qnodes.p; a.tris = c.scene.tris; a.qtris = (const float*)c.b_qtris.p; a.n_tris = c.scene.n_tris;
@@ -1046,7 +1046,7 @@ static int set_option_one(const std::string& n, int64_t value) {
   else if (n == "shade_per") { if (value != 0 && value != 2 && value != 4) return fail("shade_per: 0 (measured), 2 or 4"); g_ctx.opt_shade_per = (int)value; }
   else if (n == "ray_chunk") { if (value < 16 || value > 4096 || (value & 15)) return fail("ray_chunk: a multiple of 16, 16..4096"); g_ctx.ray_chunk = (int)value; }
   else if (n == "refill_min") { if (value < 1 || value > 8) return fail("refill_min: 1..8"); g_ctx.refill_min = (int)value; }
-  else if (n == "node_min") { if (value < 1 || value > 8) return fail("node_min: 1..8"); g_ctx.node_min = (int)value; }
+  else if (n == "node_min") { if (value < 0 || value > 8) return fail("node_min: 1..8, 0 = automatic"); g_ctx.node_min = (int)value; }
   else if (n == "bvh_width") { if (value != 4 && value != 8) return fail("bvh_width: 4 or 8"); g_ctx.bvh_params.width = (int)value; }
   else if (n == "lds_stack_cap") { if (value < 0 || value > kStackEntries) return fail("lds_stack_cap: 0 (automatic) .. 160"); g_ctx.lds_stack_cap = (int)value; }
   else if (n == "bvh_max_leaf") { if (value < 0 || value > kMaxLeafTris) return fail("bvh_max_leaf: 1..8, 0 = defaults"); g_ctx.bvh_params.max_leaf = value ? (int)value : BvhBuildParams().max_leaf; g_ctx.bvh_params.gpu_max_leaf = (int)value; }

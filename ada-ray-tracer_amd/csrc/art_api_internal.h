@@ -47,7 +47,8 @@ struct Ctx {
                                       // so a small render takes less): big batches keep late bounces wide (8M -> 32M: +7 %, -> 128M: +1.7 %)
   int opt_blocks_per_cu = 0, blocks_per_cu = 0;
   bool count_tests = false;
-  int node_min = 4;
+  int node_min = 0;              // the trace kernel leaves its node loop when fewer than 8 x node_min lanes still expand nodes.  0: 4 (the optimum on C4, profiles/r2_sensitivity.json);
+                                 // 2 for an instanced scene -- its groups also wait for instance entries, and leaving the loop for them less often is worth 6 % on I64 (profiles/r5_inst_sweep.py)
   int refill_min = 2;            // idle ray groups of a wave take new rays when two of them are idle (1: at once; measured 0.5-1 % slower)
   int queue_segments = 8;       // the live-ray queue is cut into this many contiguous segments, one per XCD (1 = a single cursor)
   int ray_chunk = 48;            // trace records a wave claims per atomic (and prefetches): 16 -> 48 is worth 1 % on C4, 4 % on C3, 10 % on C5 (the claim stalls the wave)

@@ -205,7 +205,7 @@ typedef struct ArtStageStats {
 } ArtStageStats;
 int  art_get_stage_stats(ArtStageStats* out);
 /* Tuning / test options (defaults in brackets):  "trace_kernel" [0] 0 cooperative, 1 one ray per lane;  "batch_paths" [128M];
- * "blocks_per_cu" [occupancy];  "count_tests" [0];  "node_min" [4];  "refill_min" [2];  "ray_chunk" [48];  "queue_segments" [8];  "shadow_anyhit" [1];
+ * "blocks_per_cu" [occupancy];  "count_tests" [0];  "node_min" [0 = 4, instanced scenes 2];  "refill_min" [2];  "ray_chunk" [48];  "queue_segments" [8];  "shadow_anyhit" [1];
  * "lds_stack_cap" [0 = automatic];  BVH build (take effect at the next art_upload_scene): "bvh_width" [4] lanes per ray = children
  * per node, 4 or 8;  "bvh_builder" [3] 3 binned SAH on the GPU (the tree of 0, built in milliseconds), 0 binned SAH on the host, 1 LBVH on the GPU, 2 PLOC on the GPU;  "bvh_ploc_radius" [8];  "bvh_spatial_splits" [0];  "bvh_max_leaf" [width];
  * "bvh_leaf_base_milli", "bvh_node_cost_milli", "bvh_tri_cost_milli".  The wavefront stages: "shade_per" [0 = measured; 2 | 4 items per thread],

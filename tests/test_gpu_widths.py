@@ -154,7 +154,7 @@ def test_node_min_and_refill_gate_cannot_stall_a_wave(art, backend):
                 assert np.array_equal(bits(img), bits(ref)), (width, node_min, refill)
     finally:
         backend.set_option("bvh_width", 4)
-        backend.set_option("node_min", 4)
+        backend.set_option("node_min", 0)
         backend.set_option("refill_min", 2)
 
 
