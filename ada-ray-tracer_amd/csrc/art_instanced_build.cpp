@@ -132,7 +132,8 @@ bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vect
   if (!two_sided && open_factor > 1 && tight) {
     auto by_area = [](const Open& a, const Open& b) { return a.area < b.area || (a.area == b.area && (a.inst > b.inst || (a.inst == b.inst && a.entry > b.entry))); };
     std::make_heap(heap.begin(), heap.end(), by_area);
-    const size_t target = std::min<size_t>((size_t)open_factor * T.inst.size(), (size_t)1 << 26);
+    // (at most 2^20 entry points, or one per instance if those are more: the table is 128 bytes per entry point and the instance tree is built on the host)
+    const size_t target = std::min<size_t>((size_t)open_factor * T.inst.size(), std::max<size_t>(T.inst.size(), (size_t)1 << 20));
     std::vector<int32_t> walk;
     while (!heap.empty() && heap.size() + closed.size() < target) {
       std::pop_heap(heap.begin(), heap.end(), by_area);
