@@ -199,6 +199,19 @@ def instanced_scene(n_instances=64, tris_per_mesh=20000, seed=0xADA5EED0 + 64, t
     return SceneDesc(spheres=spheres, lights=lights, materials=mats, meshes=[tor, grid], cornell=CORNELL_BOX, cam_pos=REFERENCE_CAMERA, instances=insts)
 
 
+def instanced_cluster(n_instances=64, tris_per_mesh=20000, shrink=0.25, grow=1.5):
+    """instanced_scene's instances pulled together into one interpenetrating cluster (translations shrunk towards the centre of the box,
+    scales x grow): the boxes of whole instances nearly coincide -- the case the build opens instances for (art_instanced_build.cpp)."""
+    sd = instanced_scene(n_instances, tris_per_mesh)
+    c = np.array([0.0, 2.3, 2.3])
+    tr = []
+    for i in range(n_instances):
+        M = np.array(list(sd.instances[i].m), np.float64).reshape(3, 4)
+        M[:, 3] = c + shrink * (M[:, 3] - c); M[:, :3] *= grow
+        tr.append((int(sd.instances[i].mesh), M))
+    return instanced_scene(n_instances, tris_per_mesh, transforms=tr)
+
+
 def mixed_scene(n_tris=20000, config_id=5, extra_spheres=8):
     """C5: spheres (Phong, glass, extra glass/diffuse) + emissive sphere light + a triangle mesh inside the Cornell box."""
     mats = cornell_materials()

@@ -53,14 +53,7 @@ def main():
             run(art, be, flat, "flattened upload: one tree over 1.28 M world-space triangles")]
     # the same 64 instances pulled together into one interpenetrating cluster (translations shrunk to a quarter around the centre of the box,
     # scales x 1.5): the boxes of whole instances nearly coincide -- the case opening instances is for
-    import numpy as np
-    c = np.array([0.0, 2.3, 2.3])
-    tr = []
-    for i in range(64):
-        M = np.array(list(sd.instances[i].m), np.float64).reshape(3, 4)
-        M[:, 3] = c + 0.25 * (M[:, 3] - c); M[:, :3] *= 1.5
-        tr.append((int(sd.instances[i].mesh), M))
-    sd2 = scenes.instanced_scene(64, 20000, transforms=tr)
+    sd2 = scenes.instanced_cluster(64, 20000)
     for k in (0, 1, 4, 16, 64):
         out.append(run(art, be, sd2, "CLUSTER of the 64 instances, cooperative kernel, inst_open = %d" % k, [("inst_open", k)]))
     out.append(run(art, be, hostsim.flattened_copy(art, sd2), "CLUSTER, flattened upload"))

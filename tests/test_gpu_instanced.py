@@ -80,6 +80,40 @@ def test_mirrored_sheared_coincident_tiny_and_huge_instances(art, backend, kerne
     assert {0, 1, 4, 6}.issubset(hit_insts)
 
 
+def test_interpenetrating_cluster_is_opened_by_the_build_and_renders_the_flattened_picture(art, backend):
+    """24 instances of two ~2 k-triangle meshes pulled into one cluster: the build's own rule opens them (more instance-tree nodes than with
+    inst_open = 1); the picture is the one of whole instances and of the flattened upload, whole frame, and the oracle's on sampled pixels"""
+    from ada_ray_tracer_amd import scenes
+    W, H = 320, 180
+    sd = scenes.instanced_cluster(24, 2000)
+    flat = hostsim.flattened_copy(art, sd)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=9)
+    backend.upload_scene(sd); backend.resize(W, H)
+    n_auto = backend.bvh_info().n_nodes
+    auto, _, spp = backend.render_pass(p, 0)
+    rays = backend.stats().rays
+    assert spp == 8 and backend.stats().lost_paths == 0
+    backend.set_option("inst_open", 1)
+    try:
+        backend.upload_scene(sd); backend.resize(W, H)
+        n_whole = backend.bvh_info().n_nodes
+        whole, _, _ = backend.render_pass(p, 0)
+    finally:
+        backend.set_option("inst_open", 0)
+    assert n_auto > n_whole + 24                               # the instance tree grew: entry points were added
+    assert np.array_equal(bits(auto), bits(whole))
+    backend.upload_scene(flat); backend.resize(W, H)
+    ref, _, _ = backend.render_pass(p, 0)
+    assert backend.stats().rays == rays and np.array_equal(bits(auto), bits(ref))
+    osc = conv.OracleScene(flat)
+    nodes, tris, info = backend.export_bvh()
+    osc.attach_bvh(nodes, tris, info.node_width)
+    rng = np.random.default_rng(24)
+    xs = rng.integers(0, W, 200); ys = rng.integers(0, H, 200)
+    oref, _ = orc.render_pixels(osc.scene, orc.make_params(W, H, orc.PT_MIS, True, 8, 2, seed=9), xs, ys)
+    assert np.array_equal(bits(auto[ys, xs]), bits(oref))
+
+
 def test_64_instances_of_20k_triangles_at_64_spp(art, backend):
     """The review's case: 64 instances x ~20 k triangles (1.28 M triangles flattened), 640x360, PT_MIS depth 8, 64 spp.  Instanced render ==
     render of the flattened upload (whole frame, bits), and == the oracle on 300 sampled pixels (its search walks the flattened tree)."""
