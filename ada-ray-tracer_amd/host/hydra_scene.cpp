@@ -1,5 +1,6 @@
 // hydra_scene.cpp -- see hydra_scene.hpp.
 #include "hydra_scene.hpp"
+#include <algorithm>
 
 #include <cctype>
 #include <cstdio>
@@ -177,6 +178,44 @@ bool Hydra_Scene::Init(const std::string& a_path, std::string& err) {
   return true;
 }
 
+bool Hydra_Scene::Build_Render_Desc(const Scene& base, std::string& err) {
+  if (meshes.empty() || instances.empty() || materials.empty()) { err = "scene library without meshes, instances or materials"; return false; }
+  r_materials = base.materials;
+  const int32_t first = (int32_t)r_materials.size();
+  for (const HydraMaterial& hm : materials) {
+    ArtMaterial m; std::memset(&m, 0, sizeof m);
+    m.type = ART_MAT_LAMBERT; std::memcpy(m.p, hm.diffuse, 12);
+    r_materials.push_back(m);
+  }
+  r_meshes.assign(meshes.size(), ArtMesh()); r_matids.assign(meshes.size(), {});
+  for (size_t i = 0; i < meshes.size(); ++i) {
+    const Mesh& me = meshes[i];
+    ArtMesh& d = r_meshes[i]; std::memset(&d, 0, sizeof d);
+    if (me.triangles.empty()) { err = "mesh " + std::to_string(i) + " has no triangles"; return false; }
+    const size_t nt = me.triangles.size() / 3;
+    r_matids[i].resize(nt);
+    for (size_t t = 0; t < nt; ++t) {
+      const int32_t id = t < me.material_ids.size() ? me.material_ids[t] : 0;
+      r_matids[i][t] = first + std::min(std::max(id, 0), (int32_t)materials.size() - 1);
+    }
+    d.mode = ART_MESH_CLOSEST;
+    d.nverts = (int32_t)(me.vert_positions.size() / 3); d.ntris = (int32_t)nt;
+    d.pos = me.vert_positions.data(); d.nrm = me.vert_normals.data(); d.uv = nullptr;
+    d.idx = me.triangles.data(); d.matid = r_matids[i].data();
+    std::memcpy(d.bbmin, me.bbox_min, 12); std::memcpy(d.bbmax, me.bbox_max, 12);
+  }
+  r_instances.clear();
+  for (const HydraInstance& in : instances) {
+    ArtInstance a; a.mesh = in.mesh_id; std::memcpy(a.m, in.matrix, 48);
+    r_instances.push_back(a);
+  }
+  r_desc = base.desc;                                          // box, spheres, light, camera of the internal scene
+  r_desc.n_materials = (int32_t)r_materials.size(); r_desc.materials = r_materials.data();
+  r_desc.n_meshes = (int32_t)r_meshes.size(); r_desc.meshes = r_meshes.data();
+  r_desc.n_instances = (int32_t)r_instances.size(); r_desc.instances = r_instances.data();
+  return true;
+}
+
 void Hydra_Scene::Destroy() { gcore_destroy(); }
 
 bool Hydra_Scene::Find_Closest_Hit(const float origin[3], const float direction[3], HitCpp& hit) const {
@@ -194,6 +233,15 @@ extern "C" int art_host_hydra_load(const char* dir, int* counts4 /* meshes, mate
   std::memcpy(first_diffuse3, g_hydra.materials[0].diffuse, 12);
   for (size_t i = 0; i < g_hydra.instances.size() && i < 64; ++i) std::memcpy(matrices + 16 * i, g_hydra.instances[i].matrix, 64);
   return 0;
+}
+// The scene library as a render scene (Hydra_Scene::Build_Render_Desc): the descriptor art_upload_scene takes, valid until the next call.
+// vsgf_path: where the internal scene finds data/pyramid2.vsgf (Scene.Init).  nullptr on failure, message on stderr.
+extern "C" const ArtSceneDesc* art_host_hydra_render_desc(const char* dir, const char* vsgf_path) {
+  static art_host::Scene base; static art_host::Hydra_Scene hy;
+  std::string err;
+  hy = art_host::Hydra_Scene();
+  if (!dir || !vsgf_path || !base.Init(vsgf_path, err) || !hy.Load(dir, err) || !hy.Build_Render_Desc(base, err)) { std::fprintf(stderr, "art_host_hydra_render_desc: %s\n", err.c_str()); return nullptr; }
+  return &hy.r_desc;
 }
 extern "C" int art_host_hydra_init(const char* dir) {
   std::string err;

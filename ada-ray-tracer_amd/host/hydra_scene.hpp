@@ -36,6 +36,17 @@ struct Hydra_Scene {                    // Render_Scene of scene_hydra_embree.ad
   std::vector<int> geom_ids;            // value returned by gcore_add_mesh_3f per mesh
   int num_lights = 0;
 
+  // The library's geometry as a scene for Ray_Tracer.Render_Pass (round 5; art_hip.h ArtSceneDesc::instances): every mesh of geometry_lib an
+  // object-space prototype, every <instance> an ArtInstance (the first 12 floats of its matrix, as rtcSetGeometryTransform reads them,
+  // embree_connect.cpp:169) -- rendered through the two-level tree, nothing flattened.  The reference's own "external_cpp" body stops short
+  // of this (Find_Closest_Hit returns matId -1, lights are only counted, no camera is read: scene_hydra_embree.adb:303-390, :426-446), so
+  // the surroundings are the internal scene's (`base`: box, spheres, light, camera of Scene.Init) and the materials are its table 0..10
+  // followed by ONE Lambert per <material> (the diffuse colour is all Load_Materials reads, :192-225); a triangle takes material
+  // 11 + its VSGF material id, ids past the end of the library the library's last material.
+  std::vector<ArtMaterial> r_materials; std::vector<ArtMesh> r_meshes; std::vector<std::vector<int32_t>> r_matids; std::vector<ArtInstance> r_instances;
+  ArtSceneDesc r_desc;
+  bool Build_Render_Desc(const Scene& base, std::string& err);   // after Load; the descriptor points into this object and into `base`
+
   bool Load(const std::string& a_path, std::string& err);      // parsing + VSGF loading only (no GPU)
   bool Init(const std::string& a_path, std::string& err);      // Load + gcore_init_and_clear / add / instance / commit
   void Destroy();                                              // gcore_destroy (:392-397)

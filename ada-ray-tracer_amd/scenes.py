@@ -260,6 +260,25 @@ class HostSceneDesc:
             self.desc.cam_pos = (C.c_float * 3)(*cam_pos)
 
 
+class HydraSceneDesc:
+    """A Hydra scene library (statex_00001.xml + its VSGF meshes; scene_hydra_embree.adb:303-390) as a render scene, built by the product's
+    host layer (host/hydra_scene.cpp Build_Render_Desc): the library's meshes as prototypes, its <instance>s as ArtInstances, inside the internal
+    scene's box / spheres / light / camera; materials = the internal table + one Lambert per <material>.  Rendered through the two-level tree."""
+
+    def __init__(self, scene_dir, vsgf_path=None):
+        import ctypes as C
+        from . import HOST_LIB_PATH, ArtError, ArtSceneDesc
+        lib = C.CDLL(HOST_LIB_PATH)
+        lib.art_host_hydra_render_desc.restype = C.POINTER(ArtSceneDesc)
+        lib.art_host_hydra_render_desc.argtypes = [C.c_char_p, C.c_char_p]
+        p = lib.art_host_hydra_render_desc(str(scene_dir).encode(), (vsgf_path or PYRAMID_VSGF).encode())
+        if not p:
+            raise ArtError("art_host_hydra_render_desc failed for %s" % scene_dir)
+        self._lib = lib
+        self.desc = ArtSceneDesc()
+        C.memmove(C.byref(self.desc), p, C.sizeof(ArtSceneDesc))      # pointers stay those of the host layer's static objects
+
+
 def reference_scene(cam_pos=None):
     """C2 (and, with eight spheres, C1): Scene.Init through the product's host mirror."""
     return HostSceneDesc(cam_pos=cam_pos)

@@ -84,6 +84,54 @@ def test_instanced_scene_hits_equal_the_oracle_on_the_flattened_mesh(art, backen
     L.art_host_hydra_destroy()
 
 
+def _hydra_render_scene(art):
+    """the fixture library as a render scene (the product's host layer builds the descriptor) + what it must amount to, written down here
+    independently: the internal scene's spheres / light / box / camera, its 11 materials followed by the library's two as Lamberts"""
+    from ada_ray_tracer_amd import scenes
+    import hostsim
+    sd = scenes.HydraSceneDesc(SCENE_DIR)
+    assert sd.desc.n_instances == 3 and sd.desc.n_meshes == 1 and sd.desc.n_materials == 13 and sd.desc.meshes[0].ntris == 8
+    for k in range(3):
+        assert np.array_equal(np.array(list(sd.desc.instances[k].m), F), MATS[k][:3].ravel())
+    assert [sd.desc.meshes[0].matid[t] for t in range(8)] == [12] * 8      # VSGF material id 2 in a library of two: its last material
+    area = float(F(4.0) * F(np.pi) * F(0.5) * F(0.5))
+    sd._kw = dict(spheres=[((-1.5, 1.0, 1.5), 1.0, 8), ((1.4, 1.0, 3.0), 1.0, 0), ((0.0, 4.5, 1.0), 0.5, 4)],
+                  lights=[dict(shape=art.LIGHT_SPHERE, mat=4, center=(0.0, 4.5, 1.0), radius=0.5, intensity=(10.0, 10.0, 10.0), surfaceArea=area)],
+                  materials=scenes.cornell_materials() + [dict(type=art.MAT_LAMBERT, p=(0.5, 0.25, 0.125)), dict(type=art.MAT_LAMBERT, p=(0.25, 0.5, 0.0))],
+                  cornell=scenes.CORNELL_BOX, cam_pos=scenes.REFERENCE_CAMERA, cam_matrix=None)
+    return sd, hostsim.flattened_copy(art, sd)
+
+
+def test_scene_library_renders_as_an_instanced_scene_host_simulation(art):
+    """SURVEY 8(f) rank 2 + 4 together: the Hydra library's meshes and <instance>s through the render loop's two-level search (the product's
+    functions compiled for the host) == the oracle's render of the explicitly flattened scene, bits"""
+    import hostsim
+    sd, flat = _hydra_render_scene(art)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=31)
+    acc, rays = hostsim.render(art, sd, p, 72, 54)
+    ref, _, cnt = orc.render(conv.OracleScene(flat).scene, orc.make_params(72, 54, orc.PT_MIS, True, 8, 2, seed=31))
+    assert rays == cnt.rays and np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
+    assert (acc > 0).mean() > 0.3
+
+
+@pytest.mark.gpu
+def test_scene_library_renders_through_art_render_pass_without_flattening(art, backend):
+    """the same through the C ABI: art_upload_scene(meshes + instances from the library) -> art_render_pass (k_trace_coop<.., INST>) == the oracle
+    on the flattened scene, whole frame, and the debug pass sees the three pyramids"""
+    sd, flat = _hydra_render_scene(art)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=31)
+    backend.upload_scene(sd); backend.resize(160, 120)
+    acc, _, spp = backend.render_pass(p, 0)
+    rays = backend.stats().rays
+    dbg = backend.debug_hit_pass(art.Backend.pass_params(art.RT_DEBUG, False, 8, 1))
+    ref, _, cnt = orc.render(conv.OracleScene(flat).scene, orc.make_params(160, 120, orc.PT_MIS, True, 8, 2, seed=31))
+    assert spp == 8 and rays == cnt.rays and backend.stats().lost_paths == 0
+    assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
+    on_mesh = dbg[4] == 2
+    assert on_mesh.sum() > 100 and set(np.unique(dbg[3][on_mesh]).tolist()) == {12}
+    assert set(np.unique(dbg[2][on_mesh] >> 3).tolist()) == {0, 1, 2}      # 8 triangles per mesh: shift 3, all three instances seen
+
+
 @pytest.mark.parametrize("text,why", [
     ("<geometry_lib><mesh loc='x.vsgf'></geometry_lib>", "mismatched closing tag"),
     ("<a b=c/>", "unquoted attribute"),
