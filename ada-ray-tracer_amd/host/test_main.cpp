@@ -1,11 +1,14 @@
 // test_main.cpp -- replay of the reference's driver (test.adb:20-79) on the HIP backend:
 //   Scene.Init -> Init_Render -> Resize_Viewport -> Bitmap.Init -> loop { Render_Pass; GetSPP; copy frame; SaveBMP }.
-// usage: art_test <pyramid2.vsgf> <out.bmp> [width height passes threads_num render_type aa]
+// usage: art_test <pyramid2.vsgf> <out.bmp> [width height passes threads_num render_type aa [hydra scene folder]]
+// With a scene folder (the reference's SCN = "external_cpp" build, art.gpr:6-14: Scene.Init reads <folder>/statex_00001.xml,
+// scene_hydra_embree.adb:303-390) the library's meshes and instances are rendered inside the internal scene (hydra_scene.hpp Build_Render_Desc).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
 #include "art_host.hpp"
+#include "hydra_scene.hpp"
 
 int main(int argc, char** argv) {
   if (argc < 3) { std::fprintf(stderr, "usage: %s <pyramid2.vsgf> <out.bmp> [w h passes threads type aa]\n", argv[0]); return 2; }
@@ -14,7 +17,13 @@ int main(int argc, char** argv) {
   art_host::Scene g_scn; std::string err;
   if (art_init(-1)) { std::fprintf(stderr, "art_init: %s\n", art_last_error()); return 1; }
   if (!g_scn.Init(argv[1], err)) { std::fprintf(stderr, "Scene.Init: %s\n", err.c_str()); return 1; }      // test.adb:32
-  if (art_upload_scene(&g_scn.desc)) { std::fprintf(stderr, "art_upload_scene: %s\n", art_last_error()); return 1; }
+  art_host::Hydra_Scene hydra;
+  const ArtSceneDesc* desc = &g_scn.desc;
+  if (argc > 9) {
+    if (!hydra.Load(argv[9], err) || !hydra.Build_Render_Desc(g_scn, err)) { std::fprintf(stderr, "Scene.Init (%s): %s\n", argv[9], err.c_str()); return 1; }
+    desc = &hydra.r_desc;
+  }
+  if (art_upload_scene(desc)) { std::fprintf(stderr, "art_upload_scene: %s\n", art_last_error()); return 1; }
   art_host::Ray_Tracer rt;
   if (argc > 6) rt.Threads_Num = atoi(argv[6]);
   rt.Init_Render(argc > 7 ? (art_host::Render_Type)atoi(argv[7]) : art_host::PT_MIS);                        // test.adb:35

@@ -28,6 +28,21 @@ def test_test_adb_replay_writes_identical_bmp(art, tmp_path):
     assert open(out, "rb").read() == orc.bmp_bytes(orc.resolve(oacc, 1))
 
 
+def test_test_adb_replay_over_a_hydra_scene_library_writes_the_flattened_scenes_bmp(art, tmp_path):
+    """the reference's SCN = "external_cpp" build of the same driver (art.gpr:6-14): Scene.Init reads a Hydra scene library; here its meshes and
+    <instance>s go through art_upload_scene as instances (host/hydra_scene.cpp Build_Render_Desc) and the BMP is the one the oracle predicts
+    for the explicitly flattened scene"""
+    import conv
+    from test_hydra_scene import SCENE_DIR, _hydra_render_scene
+    exe = os.path.join(art.PKG_DIR, "art_test")
+    out = str(tmp_path / "ART_hydra.bmp")
+    r = subprocess.run([exe, orc.PYRAMID_VSGF, out, "96", "64", "2", "3", "4", "1", SCENE_DIR], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    _, flat = _hydra_render_scene(art)
+    acc, spp, _ = orc.render(conv.OracleScene(flat).scene, orc.make_params(96, 64, orc.PT_MIS, True, 8, 3, seed=1), passes=2)
+    assert spp == 24 and open(out, "rb").read() == orc.bmp_bytes(orc.resolve(acc, spp))
+
+
 def test_python_mirror_of_ray_tracer_package(art, backend):
     """test.adb:32-69 through the Python mirror of package Ray_Tracer: Ada (x,y) buffers, screen copy, SaveBMP."""
     import conv
