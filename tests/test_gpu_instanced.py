@@ -114,6 +114,30 @@ def test_interpenetrating_cluster_is_opened_by_the_build_and_renders_the_flatten
     assert np.array_equal(bits(auto[ys, xs]), bits(oref))
 
 
+def test_four_thousand_small_instances(art, backend):
+    """4096 instances of two ~300-triangle meshes crowding the box (opened into entry points by the build's own rule; a 12-bit instance index
+    over a 9-bit triangle index in the hit key): the cooperative kernel's picture == the flattened 1.2 M-triangle upload's, whole frame"""
+    from ada_ray_tracer_amd import scenes
+    W, H = 256, 144
+    sd = scenes.instanced_scene(4096, 300)
+    flat = hostsim.flattened_copy(art, sd)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 1, seed=9)
+    backend.upload_scene(sd); backend.resize(W, H)
+    n_auto = backend.bvh_info().n_nodes
+    inst, _, spp = backend.render_pass(p, 0)
+    rays = backend.stats().rays
+    assert spp == 4 and backend.stats().lost_paths == 0
+    backend.set_option("inst_open", 1)
+    try:
+        backend.upload_scene(sd)
+        assert backend.bvh_info().n_nodes < n_auto           # (the rule did open them)
+    finally:
+        backend.set_option("inst_open", 0)
+    backend.upload_scene(flat); backend.resize(W, H)
+    ref, _, _ = backend.render_pass(p, 0)
+    assert backend.stats().rays == rays and np.array_equal(bits(inst), bits(ref))
+
+
 def test_64_instances_of_20k_triangles_at_64_spp(art, backend):
     """The review's case: 64 instances x ~20 k triangles (1.28 M triangles flattened), 640x360, PT_MIS depth 8, 64 spp.  Instanced render ==
     render of the flattened upload (whole frame, bits), and == the oracle on 300 sampled pixels (its search walks the flattened tree)."""

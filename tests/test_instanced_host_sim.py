@@ -51,6 +51,19 @@ def test_mirrored_sheared_coincident_tiny_and_huge_instances(art, inst_open):
     assert np.isfinite(acc).mean() > 0.99 and (acc > 0).mean() > 0.3      # (the reference's 1 / max(cos, 1e-20) gives a few pixels of 1e16 .. 1e38 on the mirror and glass triangles: the same bits in both)
 
 
+def test_four_thousand_small_instances(art):
+    """4096 instances of two ~300-triangle meshes crowding the box (every ray inside dozens of instance boxes: the build opens them into
+    entry points by its own rule): the two-level search == the product's own search of the flattened 1.2 M-triangle mesh, bits and ray count"""
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.instanced_scene(4096, 300)
+    flat = hostsim.flattened_copy(art, sd)
+    assert flat.desc.meshes[0].ntris > 1200000
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 1, seed=9)
+    acc, rays = hostsim.render(art, sd, p, 32, 24)
+    acc2, rays2 = hostsim.render(art, flat, p, 32, 24)
+    assert rays == rays2 and np.array_equal(bits(acc), bits(acc2)) and (acc > 0).mean() > 0.05
+
+
 def test_instanced_scene_rejects_what_it_cannot_hold(art):
     from ada_ray_tracer_amd import scenes
     sd = scenes.instanced_scene(4, 100)
