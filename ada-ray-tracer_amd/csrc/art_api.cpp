@@ -426,6 +426,7 @@ static void make_frame(const ArtPassParams* p, DevFrame& f) {
   std::memcpy(f.background, p->background, 12);
   const float fov = kHalfPi;                                   // ray_tracer.adb:63  Pi/2.0
   f.cam_z = -(float)c.width / safe_tan(fov / 2.0f);            // ray_tracer.adb:67
+  f.skip_null_shadow = c.skip_null_shadow ? 1 : 0;
 }
 
 static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout);
@@ -865,7 +866,7 @@ int art_init_devices(int32_t n, const int32_t* ordinals) {
     Ctx& c = g_devs[k];
     c = Ctx();
     c.trace_kernel = opts.trace_kernel; c.batch_paths = opts.batch_paths; c.bvh_params = opts.bvh_params; c.node_min = opts.node_min; c.refill_min = opts.refill_min;
-    c.queue_segments = opts.queue_segments; c.ray_chunk = opts.ray_chunk; c.shadow_anyhit = opts.shadow_anyhit; c.shade_split = opts.shade_split; c.inst_coop = opts.inst_coop; c.opt_shade_per = opts.opt_shade_per; c.lds_stack_cap = opts.lds_stack_cap;
+    c.queue_segments = opts.queue_segments; c.ray_chunk = opts.ray_chunk; c.shadow_anyhit = opts.shadow_anyhit; c.shade_split = opts.shade_split; c.skip_null_shadow = opts.skip_null_shadow; c.inst_coop = opts.inst_coop; c.opt_shade_per = opts.opt_shade_per; c.lds_stack_cap = opts.lds_stack_cap;
     c.opt_blocks_per_cu = opts.opt_blocks_per_cu; c.count_tests = opts.count_tests;
     c.device = ord[k]; c.rank = k; c.nranks = n; c.tile = 32;
     if (use_dev(k) || ensure_device()) { shutdown(); return 1; }
@@ -1042,6 +1043,7 @@ static int set_option_one(const std::string& n, int64_t value) {
   else if (n == "count_tests") { g_ctx.count_tests = value != 0; }
   else if (n == "shadow_anyhit") { g_ctx.shadow_anyhit = value != 0; }
   else if (n == "shade_split") { g_ctx.shade_split = value != 0; }
+  else if (n == "skip_null_shadow") { g_ctx.skip_null_shadow = value != 0; }
   else if (n == "inst_coop") { g_ctx.inst_coop = value != 0; }
   else if (n == "shade_per") { if (value != 0 && value != 2 && value != 4) return fail("shade_per: 0 (measured), 2 or 4"); g_ctx.opt_shade_per = (int)value; }
   else if (n == "ray_chunk") { if (value < 16 || value > 4096 || (value & 15)) return fail("ray_chunk: a multiple of 16, 16..4096"); g_ctx.ray_chunk = (int)value; }

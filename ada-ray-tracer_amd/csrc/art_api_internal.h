@@ -58,6 +58,7 @@ struct Ctx {
   // after a scene upload or a resize runs with 4, the second with 2, HIP events around the shade launches, the faster one is kept.  The
   // picture does not depend on it (the order of the items of a bank carries no meaning).  Option shade_per: 0 automatic, 2, 4.
   int opt_shade_per = 0, auto_per = 0, auto_phase = 0; double auto_ms[2] = {0.0, 0.0};
+  bool skip_null_shadow = false;   // DevFrame::skip_null_shadow: shadow rays that cannot change the picture are not traced (fewer rays than the reference issues: off by default)
   bool inst_coop = true;       // instanced scenes: the cooperative kernel crosses the instance boundary (k_trace_coop<.., INST>); false: k_trace_inst, one ray per lane (A/B, cross-check)
   bool shade_split = false;    // k_shade_compact as one instantiation per register class (light materials / deferred heavy ones); false: the round-4 kernel with every material (A/B)
   // timing

@@ -115,6 +115,10 @@ struct DevFrame {
   uint32_t seed_lo, seed_hi;
   float background[3];
   float cam_z;          // -float(width)/safe_tan(fov/2)   ray_tracer.adb:67 (computed once on the host)
+  // Option skip_null_shadow (default 0 = the reference's work: Compute_Shadow for every surface hit, integrators.adb:270).  1: a shadow ray
+  // whose explicit colour is exactly zero whatever its verdict -- the light sample lies behind the surface (cosTheta1 = 0) or the BxDF is
+  // zero there -- is not traced.  The picture is the same bits (a zero that is not added is a zero); the RAY COUNT is not the reference's.
+  int32_t skip_null_shadow;
 };
 
 // Record schedule (round 5): a bank's per-item arrays are ONE block, field f of item w at hot[f * stride + w] (stride: P rounded up to 64

@@ -749,7 +749,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     fl &= ~FLAG_SHADOW_PENDING;
   }
   // ---- what the output item will hold
-  bool alive = (fl & FLAG_ALIVE) != 0u, shadow = false;
+  bool alive = (fl & FLAG_ALIVE) != 0u, shadow = false, null_shadow = false;
   f3 no = o, nd = d, so = o, sd = d;
   float s_tfar = -1.0f, sh_min = 0.0f, new_pdf = prev_pdf;
   f3 cand = mk3(0.0f, 0.0f, 0.0f);
@@ -837,8 +837,11 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
         const float bound = max_dist - eps2;
         s_tfar = (bound > 0.0f) ? bound : 0.0f;
         sh_min = 10.0f * eps;
-        shadow = true;
-        fl |= FLAG_SHADOW_PENDING;
+        // (DevFrame::skip_null_shadow: a candidate of exactly zero stays zero under either verdict; NaN compares unequal and is traced)
+        null_shadow = f.skip_null_shadow && cand.x == 0.0f && cand.y == 0.0f && cand.z == 0.0f;
+        shadow = !null_shadow;
+        if (shadow) fl |= FLAG_SHADOW_PENDING;
+        else if (!dense) { qi.e_r[li] = cand.x; qi.e_g[li] = cand.y; qi.e_b[li] = cand.z; }      // (nobody will resolve it: the level's explicit light is this zero)
       } else if (!dense) {
         qi.e_r[li] = 0.0f; qi.e_g[li] = 0.0f; qi.e_b[li] = 0.0f;
       }
@@ -881,8 +884,8 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     put_s(hotf<uint32_t>(qo, HF_SLOT), wo, (uint32_t)slot);
     put_s(hotf<uint32_t>(qo, HF_FLAGS), wo, fl);
     put_s(hotf<float>(qo, HF_PDF), wo, new_pdf);
-    if (shadow) {
-      put_s(hotf<float>(qo, HF_SHMIN), wo, sh_min);
+    if (shadow) put_s(hotf<float>(qo, HF_SHMIN), wo, sh_min);
+    if (shadow || null_shadow) {      // (null_shadow: the ray is not traced, DevFrame::skip_null_shadow -- the level's explicit light is still this exact zero)
       put_s(cold_e(qi, 0, bounce + 1), wo, cand.x); put_s(cold_e(qi, 1, bounce + 1), wo, cand.y); put_s(cold_e(qi, 2, bounce + 1), wo, cand.z);
     }
     if (alive && !(ART_DIAG_SKIP & 4)) {
@@ -893,12 +896,12 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
   if (qo.slot_id != nullptr) put(const_cast<uint32_t*>(qo.slot_id), wo, (uint32_t)slot);      // compacted banks: the output item's slot
   put(qo.flags, wo, fl);
   put(qo.prev_pdf, wo, new_pdf);
-  if (shadow) {
-    put(qo.sh_min_t, wo, sh_min);
+  if (shadow || null_shadow) {
+    if (shadow) put(qo.sh_min_t, wo, sh_min);
     if (dense) {      // the explicit colour goes straight to where the fold reads e of this level: level bounce + 1, the successor's index
       const size_t l1 = (size_t)(bounce + 1) * P;
       put(qi.e_r + l1, wo, cand.x); put(qi.e_g + l1, wo, cand.y); put(qi.e_b + l1, wo, cand.z);
-    } else { qo.cand_r[wo] = cand.x; qo.cand_g[wo] = cand.y; qo.cand_b[wo] = cand.z; }
+    } else if (shadow) { qo.cand_r[wo] = cand.x; qo.cand_g[wo] = cand.y; qo.cand_b[wo] = cand.z; }
   }
   if (alive && !(ART_DIAG_SKIP & 4)) {
     put(qo.ray_ox, wo, no.x); put(qo.ray_oy, wo, no.y); put(qo.ray_oz, wo, no.z);
@@ -928,7 +931,7 @@ ART_HD int shade_item(const DevFrame& f, const DevScene& s, const DevPaths& qi, 
     return (alive ? 1 : 0) + (shadow ? 1 : 0);
   }
   qo.ray_tfar[wo] = alive ? kInfinity : -1.0f;
-  qo.ray_tfar[so_i] = s_tfar;
+  qo.ray_tfar[so_i] = shadow ? s_tfar : -1.0f;
   if (shadow) {
     qo.ray_ox[so_i] = so.x; qo.ray_oy[so_i] = so.y; qo.ray_oz[so_i] = so.z;
     qo.ray_dx[so_i] = sd.x; qo.ray_dy[so_i] = sd.y; qo.ray_dz[so_i] = sd.z;

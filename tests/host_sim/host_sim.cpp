@@ -69,6 +69,8 @@ extern "C" long long hs_pixmap(int w, int h, int rank, int nranks, int tile, uns
 // item's index is its slot at every level) instead of the slot-indexed fold stack
 static int g_fold_dense = 0;
 extern "C" void hs_set_fold_dense(int on) { g_fold_dense = on; }
+static int g_skip_null_shadow = 0;
+extern "C" void hs_set_skip_null_shadow(int on) { g_skip_null_shadow = on; }
 
 extern "C" int hs_render(const ArtSceneDesc* sd, const ArtPassParams* p, int w, int h, int spp0, float* accum /*row-major*/,
                          unsigned long long* rays_out) {
@@ -77,7 +79,7 @@ extern "C" int hs_render(const ArtSceneDesc* sd, const ArtPassParams* p, int w, 
   bind_host_pointers(hs);
   DevFrame F; F.width = w; F.height = h; F.render_type = p->render_type; F.aa_on = p->aa_on ? 1 : 0; F.max_depth = p->max_depth;
   F.seed_lo = (uint32_t)p->seed; F.seed_hi = (uint32_t)(p->seed >> 32); std::memcpy(F.background, p->background, 12);
-  F.cam_z = -(float)w / safe_tan(kHalfPi / 2.0f);
+  F.cam_z = -(float)w / safe_tan(kHalfPi / 2.0f); F.skip_null_shadow = g_skip_null_shadow;
   const std::vector<uint32_t> pixmap = build_pixmap(w, h, g_rank, g_nranks, g_tile);   // the product's shard map
   const int per = p->aa_on ? 4 : 1, S = p->vthreads * per, npix = (int)pixmap.size(), P = npix * S, D = p->max_depth;
   std::vector<float> buf((size_t)(14 + 8 + 3 + 3 + 6 * D + 3 + 3) * P, 0.0f);

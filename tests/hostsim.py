@@ -51,6 +51,11 @@ def set_fold_dense(art, on):
     lib(art).hs_set_fold_dense(int(on))
 
 
+def set_skip_null_shadow(art, on):
+    """DevFrame::skip_null_shadow of the following renders"""
+    lib(art).hs_set_skip_null_shadow(int(on))
+
+
 def set_shard(art, rank, nranks, tile=32):
     lib(art).hs_set_shard(rank, nranks, tile)
 
