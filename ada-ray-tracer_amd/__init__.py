@@ -95,7 +95,9 @@ class ArtStageStats(C.Structure):
 
 class ArtReduceInfo(C.Structure):
     _fields_ = [("devices", C.c_int32), ("rccl_ranks", C.c_int32), ("path", C.c_int32), ("reduces", C.c_int32),
-                ("reduce_ms", C.c_double), ("device_pass_ms", C.c_double * 8)]
+                ("reduce_ms", C.c_double), ("device_pass_ms", C.c_double * 8),
+                ("device_busy_ms", C.c_double * 8), ("device_idle_ms", C.c_double * 8), ("device_start_skew_ms", C.c_double * 8),
+                ("passes", C.c_int32), ("passes_overlapped", C.c_int32)]
 
 
 class ArtHit(C.Structure):

@@ -35,12 +35,50 @@ static bool g_comms_ready = false;     // distinct GPUs: the framebuffer reduce 
 // events around every reduce on device 0's stream (art_get_reduce_info: the reduce's GPU time is part of the evidence of a multi-GPU run)
 static std::vector<hipEvent_t> g_reduce_events;
 static double g_reduce_ms = 0.0; static int g_reduces = 0, g_reduce_path = 0;
+static bool g_multi_api = false;       // the process came up through art_init_devices: passes carry host-clock marks (art_get_reduce_info), also with n = 1
+static std::vector<hipEvent_t> g_reduce_free;     // event pairs folded into g_reduce_ms, ready for the next reduce (a host that downloads every frame re-uses two events)
+static int g_passes = 0, g_passes_overlapped = 0;  // multi-device passes folded so far / those in which every device had started before any had finished
 static void reset_reduce_info() {
   for (hipEvent_t e : g_reduce_events) (void)hipEventDestroy(e);
-  g_reduce_events.clear(); g_reduce_ms = 0.0; g_reduces = 0; g_reduce_path = 0;
+  for (hipEvent_t e : g_reduce_free) (void)hipEventDestroy(e);
+  g_reduce_events.clear(); g_reduce_free.clear(); g_reduce_ms = 0.0; g_reduces = 0; g_reduce_path = 0;
+  g_passes = g_passes_overlapped = 0;
+}
+// completed pairs -> g_reduce_ms (device 0 current, its stream idle)
+static void fold_reduce_events() {
+  for (size_t i = 0; i + 1 < g_reduce_events.size(); i += 2) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, g_reduce_events[i], g_reduce_events[i + 1]) == hipSuccess) g_reduce_ms += ms;
+    else (void)hipGetLastError();
+    g_reduce_free.push_back(g_reduce_events[i]); g_reduce_free.push_back(g_reduce_events[i + 1]);
+  }
+  g_reduce_events.clear();
+}
+// multi-device mode: the host clock at which a device's stream reaches a point (hipLaunchHostFunc), so that the devices' pass times share
+// ONE clock -- HIP events of different devices cannot be compared
+static double host_ms() {
+  static const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+static void clock_cb(void* p) { *(double*)p = host_ms(); }
+// every device's passes (all idle) -> busy / idle / start skew per device.  Pass i of every device is one Render_Pass: idle = the slowest
+// device's end - this device's end (what an uneven tile deal costs), start skew = this device's start - the first device's start (what a
+// host that enqueues device after device costs), overlapped = every device had started before any had finished.
+static void fold_pass_clocks() {
+  size_t n = SIZE_MAX;
+  for (int k = 0; k < g_ndev; ++k) n = std::min(n, g_devs[k].pass_clock.size());
+  if (!g_multi_api || n == SIZE_MAX) n = 0;
+  for (size_t i = 0; i < n; ++i) {
+    double first = 1e300, last_start = -1e300, first_end = 1e300, last = -1e300;
+    for (int k = 0; k < g_ndev; ++k) { const Ctx::PassClock& pc = *g_devs[k].pass_clock[i]; first = std::min(first, pc.t0); last_start = std::max(last_start, pc.t0); first_end = std::min(first_end, pc.t1); last = std::max(last, pc.t1); }
+    for (int k = 0; k < g_ndev; ++k) { Ctx& c = g_devs[k]; const Ctx::PassClock& pc = *c.pass_clock[i]; c.busy_ms += pc.t1 - pc.t0; c.idle_ms += last - pc.t1; c.start_skew_ms += pc.t0 - first; }
+    g_passes += 1; if (last_start < first_end) g_passes_overlapped += 1;
+  }
+  for (int k = 0; k < g_ndev; ++k) { for (Ctx::PassClock* pc : g_devs[k].pass_clock) delete pc; g_devs[k].pass_clock.clear(); }
 }
 static bool g_same_gpu = false;        // rehearsal: several contexts on ONE physical GPU, the reduce is a local sum (no collective possible)
 static const bool g_debug_live = getenv("ART_DEBUG_LIVE") != nullptr;   // development aid: work-set sizes per stage on stderr (syncs the stream); read once
+static const bool g_debug_addr = getenv("ART_DEBUG_ADDR") != nullptr;   // development aid: device addresses of the path state per batch layout on stderr (profiles/r6_bimodal)
 static thread_local std::string t_err;
 static std::string g_err;
 
@@ -184,7 +222,7 @@ int upload_scene(const ArtSceneDesc* d) {
     c.bvh_stack_bound = std::max(8, dev_stack);
     c.blocks_per_cu = 0;   // re-query occupancy
     c.scene_ready = true;
-    c.auto_phase = 0;                                    // a new scene: the shade stage measures its items-per-thread choice again
+    c.auto_phase = 0; c.auto_redo = 0; c.auto_gen += 1;  // a new scene: the shade stage measures its items-per-thread choice again
   }
   g_devs[0].host_scene = std::move(hs);
   return 0;
@@ -203,12 +241,14 @@ int resize(int w, int h) {
   if (w <= 0 || h <= 0 || (int64_t)w * h > (1ll << 30)) return fail("art_resize: bad size");
   Dev0Guard guard;
   for (int k = 0; k < g_ndev; ++k) { if (use_dev(k) || resize_one(w, h)) return 1; }
+  for (int k = 0; k < g_ndev; ++k) { Ctx& c = g_devs[k]; c.busy_ms = c.idle_ms = c.start_skew_ms = 0.0; for (Ctx::PassClock* pc : c.pass_clock) delete pc; c.pass_clock.clear(); }
   if (g_devs[0].device_ready && !use_dev(0)) reset_reduce_info();
   return 0;
 }
 static int resize_one(int w, int h) {
   Ctx& c = g_ctx;
   if (ensure_device()) return 1;
+  if (!c.pass_clock.empty()) HIP_TRY(hipStreamSynchronize(c.stream));      // (host callbacks of earlier passes still write into their cells)
   c.width = w; c.height = h;
   const size_t n = (size_t)w * h;
   if (ensure(c.b_accum, n * 12) || ensure(c.b_screen, n * 4)) return 1;
@@ -217,7 +257,8 @@ static int resize_one(int w, int h) {
   c.spp = 0;
   c.stats = ArtStats();
   c.stage = ArtStageStats();
-  c.auto_phase = 0;                                      // (the batch size follows the frame: measure again)
+  c.auto_phase = 0; c.auto_redo = 0; c.auto_gen += 1;    // (the batch size follows the frame: measure again)
+  c.lost_reported = 0;                                   // (the device counters are zeroed below)
   if (c.d_items) HIP_TRY(hipMemsetAsync(c.d_items, 0, 32 * sizeof(unsigned long long), c.stream));
   c.camera_rays = 0;
   HIP_TRY(hipMemsetAsync(c.d_counters, 0, 16 * sizeof(unsigned long long), c.stream));
@@ -341,7 +382,7 @@ static void fill_trace_args(TraceArgs& a, const DevPaths& q, int n_rays) {
 // order (DevPaths::rec, written by the stage that emitted them): no k_analytic pass, the queue is the record array itself.
 struct RecordQueue { int fixed; const int* items; int mul; };
 // event pairs around groups of launches on the launch stream: ev_begin(kind) ... ev_end()
-static int ev_begin(int kind) {
+static int ev_begin(int kind, int trial = 0) {      // trial: 1 / 2 = a shade launch of the items-per-thread trial A / B (Ctx::opt_shade_per)
   Ctx& c = g_ctx;
   if (c.ev_pool.size() < c.ev_used + 2) {
     hipEvent_t e0, e1;
@@ -349,7 +390,7 @@ static int ev_begin(int kind) {
     c.ev_pool.push_back(e0); c.ev_pool.push_back(e1);
   }
   if (c.ev_kind.size() < c.ev_pool.size() / 2) c.ev_kind.resize(c.ev_pool.size() / 2);
-  c.ev_kind[c.ev_used / 2] = (uint8_t)kind;
+  c.ev_kind[c.ev_used / 2] = (uint8_t)(kind | (trial << 4) | (trial ? (c.auto_gen & 3) << 6 : 0));
   HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used], c.stream));
   return 0;
 }
@@ -386,13 +427,18 @@ static int collect_timing() {
   for (size_t i = 0; i + 1 < c.ev_used; i += 2) {
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, c.ev_pool[i], c.ev_pool[i + 1]));
-    const int kind = (i / 2 < c.ev_kind.size()) ? c.ev_kind[i / 2] : 0;
+    const int tagged = (i / 2 < c.ev_kind.size()) ? c.ev_kind[i / 2] : 0;
+    const int kind = tagged & 15, trial = (tagged >> 4) & 3, gen = tagged >> 6;
     if (kind == 0) { c.stats.trace_ms += ms; c.stats.trace_launches += 1; }
-    else if (kind == 1) { c.stage.shade_ms += ms; c.stage.shade_launches += 1; }
+    else if (kind == 1) { c.stage.shade_ms += ms; c.stage.shade_launches += 1; if ((trial == 1 || trial == 2) && gen == (c.auto_gen & 3)) c.auto_ms[trial - 1] += ms; }
     else if (kind == 2) c.stage.raygen_ms += ms;
     else c.stage.fold_ms += ms;
   }
   c.ev_used = 0;
+  if (c.auto_phase == 3) {         // both trial batches are done (the stream is idle): keep the faster setting from here on
+    c.auto_per = (c.auto_ms[1] < c.auto_ms[0]) ? 2 : 4;
+    c.auto_phase = 4;
+  }
   if (c.d_items) {
     unsigned long long it[32];
     HIP_TRY(hipMemcpy(it, c.d_items, sizeof it, hipMemcpyDeviceToHost));
@@ -478,6 +524,12 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
       hipError_t e;
       if (try_alloc(g_ctx.b_paths, path_floats((size_t)pc * sc, p->max_depth, rec_layout) * 4 + 256, e)) {
         if (g_debug_live) std::fprintf(stderr, "path state: %d pixels x %d samples per batch, %.2f GB\n", pc, sc, (double)g_ctx.b_paths.bytes / 1e9);
+        if (g_debug_addr) {
+          DevPaths bk[2]; std::memset(bk, 0, sizeof bk);
+          carve(bk, pc * sc, p->max_depth, rec_layout);
+          std::fprintf(stderr, "ART_DEBUG_ADDR paths %p bytes %zu P %d rec %p hot0 %p hot1 %p stride %d cold %p live %p counters %p cursor %p\n", g_ctx.b_paths.p, g_ctx.b_paths.bytes, pc * sc,
+                       (void*)bk[0].rec, (void*)bk[0].hot, (void*)bk[1].hot, bk[0].stride, (void*)bk[0].cold, (void*)c.d_live, (void*)c.d_counters, (void*)c.d_cursor);
+        }
         break;
       }
       if (g_debug_live) std::fprintf(stderr, "path state: %.2f GB refused (%s)\n", (double)(path_floats((size_t)pc * sc, p->max_depth, rec_layout) * 4 + 256) / 1e9, hipGetErrorString(e));
@@ -491,6 +543,8 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
   } ev;
   HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b));
   HIP_TRY(hipEventRecord(ev.a, c.stream));
+  Ctx::PassClock* clock = nullptr;
+  if (g_multi_api) { clock = new Ctx::PassClock; c.pass_clock.push_back(clock); HIP_TRY(hipLaunchHostFunc(c.stream, clock_cb, &clock->t0)); }
   if (npix > 0) {
     for (int px0 = 0; px0 < npix; px0 += pc) {
       const int pn = std::min(pc, npix - px0);
@@ -500,11 +554,18 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
         for (DevPaths& b : bank) { b.P = pn * sn; b.npix = pn; b.pixmap = (const uint32_t*)c.b_pixmap.p + px0; b.sample_base = (uint32_t)(c.spp + s0); }
         uint4* heavy = nullptr;
         carve(bank, bank[0].P, p->max_depth, c.trace_kernel == TRACE_COOP, &heavy);
-        // items per thread of the shade stage for this batch: the option, the measured choice, or a trial (art_api_internal.h Ctx::opt_shade_per)
-        const bool trial = (c.opt_shade_per == 0 && c.auto_phase < 2 && c.trace_kernel == TRACE_COOP && !c.shade_split);
-        const int shade_per = c.opt_shade_per ? c.opt_shade_per : (c.auto_phase >= 2 ? c.auto_per : (c.auto_phase == 0 ? 4 : 2));
-        double shade_ms_before = 0.0;
-        if (trial) { HIP_TRY(hipStreamSynchronize(c.stream)); if (collect_timing()) return 1; shade_ms_before = c.stage.shade_ms; }
+        // items per thread of the shade stage for this batch: the option, the measured choice, or a trial (art_api_internal.h Ctx::opt_shade_per).
+        // Nothing here waits for the GPU: a trial batch only tags its shade launches' event pairs, and the next call that synchronises
+        // anyway reads them (collect_timing) -- Render_Pass releases all its workers before it waits for any (ray_tracer.adb:271-277).
+        int trial = 0, shade_per = c.opt_shade_per ? c.opt_shade_per : (c.auto_phase >= 4 ? c.auto_per : 4);
+        if (c.opt_shade_per == 0 && c.auto_phase < 3 && c.trace_kernel == TRACE_COOP && !c.shade_split) {
+          const int64_t Pb = (int64_t)pn * sn;
+          if (c.auto_phase == 0) c.auto_phase = 1;                                      // the warm batch: 4 items per thread, not measured
+          else if (c.auto_phase == 1) { trial = 1; c.auto_ms[0] = 0.0; c.auto_P[0] = Pb; c.auto_phase = 2; }
+          else if (Pb == c.auto_P[0]) { trial = 2; shade_per = 2; c.auto_ms[1] = 0.0; c.auto_P[1] = Pb; c.auto_phase = 3; }
+          else if (++c.auto_redo > 3) { c.auto_per = 4; c.auto_phase = 4; }             // batch sizes keep changing: no trial, 4 items per thread
+          else { trial = 1; c.auto_gen += 1; c.auto_ms[0] = 0.0; c.auto_P[0] = Pb; }    // a batch of another size: trial A again, on this size (new generation: the old trial's events no longer count)
+        }
         c.camera_rays += (uint64_t)bank[0].P;
         if (c.trace_kernel == TRACE_COOP) {
           // Compacted work sets: raygen fills bank 0 (one item per slot); stage b shades the items of bank b & 1 and writes the survivors
@@ -528,10 +589,11 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
             bank[out].rec_mode = (p->render_type == ART_PT_STUPID) ? REC_EXT : (last ? REC_SHADOW : REC_BOTH);
             int* const n_in = c.d_live + 32 * b; int* const n_out = c.d_live + 32 * (b + 1);      // per level: the fold walks them again
             HIP_TRY(hipMemsetAsync(n_out, 0, 2 * sizeof(int), c.stream));         // n_out[1]: the items this stage defers to its heavy-material kernel
-            if (ev_begin(1)) return 1;
+            if (ev_begin(1, trial)) return 1;
             launch_shade_compact(c.stream, F, c.scene, qi, bank[out], b, b == 0 ? nullptr : n_in, n_out,
                                  const_cast<uint32_t*>(bank[out].slot_id), c.d_counters + 15, c.d_counters, rays_b, c.shade_split ? heavy : nullptr, n_out + 1, shade_per);
             if (ev_end()) return 1;
+            if (b == 0 && c.inject_lost) { launch_bump(c.stream, c.d_counters + 15, nullptr, 1ull); c.inject_lost = 0; }      // test option: what a stage does when it loses a path
             if (g_debug_live) {
               int n = -1; unsigned long long r0 = 0;
               (void)hipStreamSynchronize(c.stream); (void)hipMemcpy(&n, n_out, 4, hipMemcpyDeviceToHost); (void)hipMemcpy(&r0, c.d_counters, 8, hipMemcpyDeviceToHost);
@@ -551,13 +613,6 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
           if (ev_end()) return 1;
           launch_acc_items(c.stream, c.d_live, p->max_depth, q.P, c.d_items);
           c.stage.batches += 1;
-          if (trial) {                                   // this batch's shade time (same batch size for both trials: consecutive batches of one pass, or of two passes)
-            HIP_TRY(hipStreamSynchronize(c.stream));
-            if (collect_timing()) return 1;
-            const double ms = (c.stage.shade_ms - shade_ms_before) / (double)std::max(1, bank[0].P);
-            c.auto_ms[c.auto_phase] = ms; c.auto_phase += 1;
-            if (c.auto_phase == 2) c.auto_per = (c.auto_ms[1] < c.auto_ms[0]) ? 2 : 4;
-          }
         } else {                                          // one-ray-per-lane cross-check kernel: the plain schedule over all slots, in place
           DevPaths q = bank[0];
           q.slot_id = nullptr;
@@ -576,6 +631,7 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
     }
   }
   HIP_TRY(hipEventRecord(ev.b, c.stream));
+  if (clock) HIP_TRY(hipLaunchHostFunc(c.stream, clock_cb, &clock->t1));
   const hipEvent_t p0 = ev.a, p1 = ev.b; ev.a = ev.b = nullptr;
   c.pass_events.push_back(p0); c.pass_events.push_back(p1);
   c.spp += S;
@@ -587,8 +643,10 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
 static int synchronize_one();
 int synchronize() {
   Dev0Guard guard;
-  for (int k = 0; k < g_ndev; ++k) { if (use_dev(k) || synchronize_one()) return 1; }
-  return 0;
+  int rc = 0;
+  for (int k = 0; k < g_ndev; ++k) { if (use_dev(k) || synchronize_one()) rc = 1; }      // (every device is waited for and checked, also after a failure on one)
+  if (g_devs[0].device_ready && !use_dev(0)) fold_reduce_events();
+  return rc;
 }
 static int synchronize_one() {
   Ctx& c = g_ctx;
@@ -601,13 +659,17 @@ static int synchronize_one() {
     (void)hipEventDestroy(c.pass_events[i]); (void)hipEventDestroy(c.pass_events[i + 1]);
   }
   c.pass_events.clear();
-  const uint64_t lost_before = c.stats.lost_paths;
   if (collect_timing()) return 1;
   // a lost path is a wrong picture, not a statistic -- a stage that found a path without an output item, a ray its bank has no
   // record for, a material its instantiation was not compiled for, or a staged trace record that did not name the hit slot its position
   // implies (art_shade.h emit_ray) fails the call that waits for the render
-  if (c.stats.lost_paths != lost_before)
-    return fail("render self-check: " + std::to_string(c.stats.lost_paths - lost_before) + " path(s) lost by the wavefront stages (ArtStats::lost_paths); the image is not valid");
+  // (the baseline is lost_reported, which only this function advances -- collect_timing may run any number of times between
+  // two synchronises without absorbing a loss)
+  if (c.stats.lost_paths != c.lost_reported) {
+    const uint64_t n = c.stats.lost_paths - c.lost_reported;
+    c.lost_reported = c.stats.lost_paths;
+    return fail("render self-check: " + std::to_string(n) + " path(s) lost by the wavefront stages (ArtStats::lost_paths); the image is not valid");
+  }
   return 0;
 }
 
@@ -622,10 +684,15 @@ static int reduce_accum(const float** out) {
   const size_t count = (size_t)c0.width * c0.height * 3;
   Dev0Guard guard;
   if (use_dev(0) || ensure(c0.b_reduced, count * 4)) return 1;
+  // a pair of events around the reduce: from the pool of folded pairs (synchronize() folds them) when there is one
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
+  if (g_reduce_free.size() >= 2) { ev1 = g_reduce_free.back(); g_reduce_free.pop_back(); ev0 = g_reduce_free.back(); g_reduce_free.pop_back(); }
+  else {
+    HIP_TRY(hipEventCreate(&ev0));
+    if (hipEventCreate(&ev1) != hipSuccess) { (void)hipEventDestroy(ev0); return fail("hipEventCreate failed"); }
+  }
+  if (hipEventRecord(ev0, c0.stream) != hipSuccess) { g_reduce_free.push_back(ev0); g_reduce_free.push_back(ev1); return fail("hipEventRecord failed"); }      // (a pair without a record must not reach the list)
   g_reduce_events.push_back(ev0); g_reduce_events.push_back(ev1);
-  HIP_TRY(hipEventRecord(ev0, c0.stream));
   g_reduces += 1; g_reduce_path = g_comms_ready ? 1 : 2;
   struct Stop { hipEvent_t e; hipStream_t s; ~Stop() { (void)hipEventRecord(e, s); } } stop{ev1, c0.stream};       // recorded on every way out
   if (g_comms_ready) {
@@ -797,7 +864,7 @@ int trace_rays(const float* origins, const float* dirs, const float* tfar, int64
 void shutdown() {
   if (g_devs[0].device_ready && !use_dev(0)) reset_reduce_info();
   if (g_comms_ready) { for (int k = 0; k < g_ndev; ++k) (void)ncclCommDestroy(g_comms[k]); g_comms_ready = false; }
-  g_same_gpu = false;
+  g_same_gpu = false; g_multi_api = false;
   for (int k = g_ndev - 1; k >= 0; --k) {
   g_cur = &g_devs[k];
   Ctx& c = g_ctx;
@@ -816,6 +883,7 @@ void shutdown() {
     if (c.d_items) (void)hipFree(c.d_items);
     for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : c.pass_events) (void)hipEventDestroy(e);
+    for (Ctx::PassClock* pc : c.pass_clock) delete pc;      // (after hipDeviceSynchronize: no callback is pending)
     c.b_reduced.release();
     if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
   }
@@ -883,6 +951,7 @@ int art_init_devices(int32_t n, const int32_t* ordinals) {
     g_comms_ready = true;
   }
   g_same_gpu = (n > 1 && !distinct);
+  g_multi_api = true;
   return 0;
 }
 
@@ -985,19 +1054,13 @@ int art_get_reduce_info(ArtReduceInfo* out) {
   std::memset(out, 0, sizeof *out);
   out->devices = g_ndev;
   if (g_comms_ready) { int n = 0; if (ncclCommCount(g_comms[0], &n) != ncclSuccess) return fail("ncclCommCount failed"); out->rccl_ranks = n; }
-  {
-    Dev0Guard guard;
-    if (use_dev(0)) return 1;
-    for (size_t i = 0; i + 1 < g_reduce_events.size(); i += 2) {
-      float ms = 0.0f;
-      HIP_TRY(hipEventElapsedTime(&ms, g_reduce_events[i], g_reduce_events[i + 1]));
-      g_reduce_ms += ms;
-      (void)hipEventDestroy(g_reduce_events[i]); (void)hipEventDestroy(g_reduce_events[i + 1]);
-    }
-    g_reduce_events.clear();
-  }
+  fold_pass_clocks();                      // (synchronize() above folded the reduces' event pairs and left every stream idle)
   out->path = g_reduce_path; out->reduces = g_reduces; out->reduce_ms = g_reduce_ms;
-  for (int k = 0; k < g_ndev && k < 8; ++k) out->device_pass_ms[k] = g_devs[k].stats.pass_ms;
+  for (int k = 0; k < g_ndev && k < 8; ++k) {
+    const Ctx& c = g_devs[k];
+    out->device_pass_ms[k] = c.stats.pass_ms; out->device_busy_ms[k] = c.busy_ms; out->device_idle_ms[k] = c.idle_ms; out->device_start_skew_ms[k] = c.start_skew_ms;
+  }
+  out->passes = g_passes; out->passes_overlapped = g_passes_overlapped;
   return 0;
 }
 
@@ -1038,7 +1101,8 @@ int art_set_option(const char* name, int64_t value) {      // applies to every d
 static int set_option_one(const std::string& n, int64_t value) {
   if (n == "trace_kernel") { if (value != TRACE_COOP && value != TRACE_SIMPLE) return fail("trace_kernel: 0 (cooperative) or 1 (simple)"); g_ctx.trace_kernel = (int)value; }
   else if (n == "queue_segments") { if (value != 1 && value != 2 && value != 4 && value != 8) return fail("queue_segments: 1, 2, 4 or 8"); g_ctx.queue_segments = (int)value; }
-  else if (n == "batch_paths") { if (value < 1024 || value > (1ll << 27)) return fail("batch_paths: 1024..2^27 (2 rays per path slot; the trace kernel addresses a ray's 16-byte hit record by a 32-bit byte offset)"); g_ctx.batch_paths = value; }
+  else if (n == "batch_paths") { if (value < 1024 || value > (1ll << 27)) return fail("batch_paths: 1024..2^27 (2 rays per path slot; the trace kernel addresses a ray's 16-byte hit record by a 32-bit byte offset)"); g_ctx.batch_paths = value; g_ctx.auto_phase = 0; g_ctx.auto_redo = 0; g_ctx.auto_gen += 1; }
+  else if (n == "inject_lost") { g_ctx.inject_lost = value != 0; }      // test option: the next pass counts one lost path in its first batch
   else if (n == "blocks_per_cu") { g_ctx.opt_blocks_per_cu = (int)value; g_ctx.blocks_per_cu = 0; }
   else if (n == "count_tests") { g_ctx.count_tests = value != 0; }
   else if (n == "shadow_anyhit") { g_ctx.shadow_anyhit = value != 0; }

@@ -54,10 +54,22 @@ struct Ctx {
   int ray_chunk = 48;            // trace records a wave claims per atomic (and prefetches): 16 -> 48 is worth 1 % on C4, 4 % on C3, 10 % on C5 (the claim stalls the wave)
   bool shadow_anyhit = true;   // shadow rays use the visibility rule instead of a full closest-hit search (same decision)
   // Items per thread of k_shade_compact (256 x per items and one global atomic per workgroup): 4 or 2.  Neither wins everywhere (round 5,
-  // profiles/r5_shade/ab12: 2 is 7 % faster on C4 and C3, 10 % slower on C5 and S4), so by default the library MEASURES: the first batch
-  // after a scene upload or a resize runs with 4, the second with 2, HIP events around the shade launches, the faster one is kept.  The
-  // picture does not depend on it (the order of the items of a bank carries no meaning).  Option shade_per: 0 automatic, 2, 4.
-  int opt_shade_per = 0, auto_per = 0, auto_phase = 0; double auto_ms[2] = {0.0, 0.0};
+  // profiles/r5_shade/ab12: 2 is 7 % faster on C4 and C3, 10 % slower on C5 and S4), so by default the library MEASURES -- without ever
+  // waiting for the GPU (round 6; until round 5 the trial blocked the host twice per trial batch, which serialised the devices of a
+  // multi-GPU process during their first two batches): after a scene upload or a resize batch 0 runs warm and unmeasured (code-object load,
+  // first touch of the path state), batch 1 with 4 items per thread, batch 2 with 2 -- their shade launches' event pairs carry the trial's
+  // tag -- and every batch after that with 4 until a synchronize (art_synchronize, art_get_stats, a download: calls that wait anyway) has
+  // read both trials' events; then the faster setting is kept.  Two trials only count when their batches had the same number of paths.
+  // The picture does not depend on it (the order of the items of a bank carries no meaning).  Option shade_per: 0 automatic, 2, 4.
+  int opt_shade_per = 0, auto_per = 0, auto_phase = 0;      // auto_phase: 0 warm batch next, 1 trial A (4) next, 2 trial B (2) next, 3 both enqueued, 4 decided
+  double auto_ms[2] = {0.0, 0.0}; int64_t auto_P[2] = {0, 0}; int auto_redo = 0; unsigned auto_gen = 0;      // auto_gen: a trial's event pairs carry its generation (mod 4); a reset or a re-done trial starts a new one
+  uint64_t lost_reported = 0;    // lost paths (d_counters[15], cumulative) already reported by a synchronize: only synchronize_one advances it
+  int inject_lost = 0;           // test option: the next render pass bumps the self-check counter once in its first batch (tests/test_gpu_parity.py)
+  // multi-device mode: host clock (steady_clock, ms since the process' first use) at which this device's stream reached the start / the end
+  // of its passes -- hipLaunchHostFunc on the stream, so the devices' times share one clock (events of different devices cannot be compared)
+  struct PassClock { double t0 = 0.0, t1 = 0.0; };
+  std::vector<PassClock*> pass_clock;      // one per pass since the last art_get_reduce_info / resize (heap cells: the callbacks write into them)
+  double busy_ms = 0.0, idle_ms = 0.0, start_skew_ms = 0.0;   // folded by art_get_reduce_info
   bool skip_null_shadow = false;   // DevFrame::skip_null_shadow: shadow rays that cannot change the picture are not traced (fewer rays than the reference issues: off by default)
   bool inst_coop = true;       // instanced scenes: the cooperative kernel crosses the instance boundary (k_trace_coop<.., INST>); false: k_trace_inst, one ray per lane (A/B, cross-check)
   bool shade_split = false;    // k_shade_compact as one instantiation per register class (light materials / deferred heavy ones); false: the round-4 kernel with every material (A/B)

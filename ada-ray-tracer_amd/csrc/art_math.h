@@ -123,37 +123,53 @@ ART_HD f3 xform_point(const float* m, f3 v) {
 // ------------------------------------------------------------------------------------------------
 namespace m1 {
 
+// A binary64 coefficient on the device is two s_mov_b32 literals in front of the instruction that uses it.  Left to itself the compiler
+// hoists the pairs out of k_shade_compact's round loop, runs out of SGPRs and keeps them in VGPR lanes (v_writelane / v_readlane: the 70
+// "spilled SGPRs" of the round-5 stage were exactly these constants).  ART_KD pins a coefficient to its use: an empty volatile asm on
+// its two halves, which is neither hoisted nor merged -- the value is the literal's, bit for bit (round 6, review item 6).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ART_F64_CONST_FREE)
+__device__ __forceinline__ double kd_at_use(double c) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, c);
+  uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | (uint64_t)lo);
+}
+#define ART_KD(x) ::art::m1::kd_at_use(x)
+#else
+#define ART_KD(x) (x)
+#endif
+
 ART_HD double poly_sin(double r) {   // |r| <= pi/4, odd Taylor series through r^15
   const double z = r * r;
-  double q = 0x1.ae7f3e733b81fp-41;
-  q = q * z - 0x1.6124613a86d09p-33;
-  q = q * z + 0x1.ae64567f544e4p-26;
-  q = q * z - 0x1.71de3a556c734p-19;
-  q = q * z + 0x1.a01a01a01a01ap-13;
-  q = q * z - 0x1.1111111111111p-7;
-  q = q * z + 0x1.5555555555555p-3;
+  double q = ART_KD(0x1.ae7f3e733b81fp-41);
+  q = q * z - ART_KD(0x1.6124613a86d09p-33);
+  q = q * z + ART_KD(0x1.ae64567f544e4p-26);
+  q = q * z - ART_KD(0x1.71de3a556c734p-19);
+  q = q * z + ART_KD(0x1.a01a01a01a01ap-13);
+  q = q * z - ART_KD(0x1.1111111111111p-7);
+  q = q * z + ART_KD(0x1.5555555555555p-3);
   return r - (r * z) * q;
 }
 
 ART_HD double poly_cos(double r) {   // |r| <= pi/4, even Taylor series through r^16
   const double z = r * r;
-  double q = 0x1.ae7f3e733b81fp-45;
-  q = q * z - 0x1.93974a8c07c9dp-37;
-  q = q * z + 0x1.1eed8eff8d898p-29;
-  q = q * z - 0x1.27e4fb7789f5cp-22;
-  q = q * z + 0x1.a01a01a01a01ap-16;
-  q = q * z - 0x1.6c16c16c16c17p-10;
-  q = q * z + 0x1.5555555555555p-5;
+  double q = ART_KD(0x1.ae7f3e733b81fp-45);
+  q = q * z - ART_KD(0x1.93974a8c07c9dp-37);
+  q = q * z + ART_KD(0x1.1eed8eff8d898p-29);
+  q = q * z - ART_KD(0x1.27e4fb7789f5cp-22);
+  q = q * z + ART_KD(0x1.a01a01a01a01ap-16);
+  q = q * z - ART_KD(0x1.6c16c16c16c17p-10);
+  q = q * z + ART_KD(0x1.5555555555555p-5);
   q = q * z - 0.5;
   return 1.0 + z * q;
 }
 
 // x = k*(pi/2) + r, two-constant Cody-Waite; exact for |x| < 2^20
 ART_HD void sincos(double x, double& s, double& c) {
-  const double v = x * 0x1.45f306dc9c883p-1;
+  const double v = x * ART_KD(0x1.45f306dc9c883p-1);
   const int k = (int)(v + (v >= 0.0 ? 0.5 : -0.5));
   const double kd = (double)k;
-  const double r = (x - kd * 0x1.921fb54400000p+0) - kd * 0x1.0b4611a626331p-34;
+  const double r = (x - kd * ART_KD(0x1.921fb54400000p+0)) - kd * ART_KD(0x1.0b4611a626331p-34);
   const double sr = poly_sin(r), cr = poly_cos(r);
   switch (k & 3) {
     case 0:  s = sr;  c = cr;  break;
@@ -167,40 +183,40 @@ ART_HD double log_pos(double x) {   // x: positive, normal binary64
   uint64_t b = __builtin_bit_cast(uint64_t, x);
   int e = (int)((b >> 52) & 0x7ff) - 1023;
   double m = __builtin_bit_cast(double, (b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
-  if (m > 0x1.6a09e667f3bcdp+0) { m = m * 0.5; e = e + 1; }
+  if (m > ART_KD(0x1.6a09e667f3bcdp+0)) { m = m * 0.5; e = e + 1; }
   const double f = m - 1.0;
   const double s = f / (2.0 + f);
   const double z = s * s;
-  double q = 0x1.8618618618618p-5;
-  q = q * z + 0x1.af286bca1af28p-5;
-  q = q * z + 0x1.e1e1e1e1e1e1ep-5;
-  q = q * z + 0x1.1111111111111p-4;
-  q = q * z + 0x1.3b13b13b13b14p-4;
-  q = q * z + 0x1.745d1745d1746p-4;
-  q = q * z + 0x1.c71c71c71c71cp-4;
-  q = q * z + 0x1.2492492492492p-3;
-  q = q * z + 0x1.999999999999ap-3;
-  q = q * z + 0x1.5555555555555p-2;
+  double q = ART_KD(0x1.8618618618618p-5);
+  q = q * z + ART_KD(0x1.af286bca1af28p-5);
+  q = q * z + ART_KD(0x1.e1e1e1e1e1e1ep-5);
+  q = q * z + ART_KD(0x1.1111111111111p-4);
+  q = q * z + ART_KD(0x1.3b13b13b13b14p-4);
+  q = q * z + ART_KD(0x1.745d1745d1746p-4);
+  q = q * z + ART_KD(0x1.c71c71c71c71cp-4);
+  q = q * z + ART_KD(0x1.2492492492492p-3);
+  q = q * z + ART_KD(0x1.999999999999ap-3);
+  q = q * z + ART_KD(0x1.5555555555555p-2);
   const double lm = 2.0 * s + (2.0 * s) * (z * q);
-  return (double)e * 0x1.62e42fefa39efp-1 + lm;
+  return (double)e * ART_KD(0x1.62e42fefa39efp-1) + lm;
 }
 
 ART_HD double exp_small(double t) {   // |t| <= 200
-  const double v = t * 0x1.71547652b82fep+0;
+  const double v = t * ART_KD(0x1.71547652b82fep+0);
   const int k = (int)(v + (v >= 0.0 ? 0.5 : -0.5));
   const double kd = (double)k;
-  const double r = (t - kd * 0x1.62e42fee00000p-1) - kd * 0x1.a39ef35793c76p-33;
-  double q = 0x1.6124613a86d09p-33;
-  q = q * r + 0x1.1eed8eff8d898p-29;
-  q = q * r + 0x1.ae64567f544e4p-26;
-  q = q * r + 0x1.27e4fb7789f5cp-22;
-  q = q * r + 0x1.71de3a556c734p-19;
-  q = q * r + 0x1.a01a01a01a01ap-16;
-  q = q * r + 0x1.a01a01a01a01ap-13;
-  q = q * r + 0x1.6c16c16c16c17p-10;
-  q = q * r + 0x1.1111111111111p-7;
-  q = q * r + 0x1.5555555555555p-5;
-  q = q * r + 0x1.5555555555555p-3;
+  const double r = (t - kd * ART_KD(0x1.62e42fee00000p-1)) - kd * ART_KD(0x1.a39ef35793c76p-33);
+  double q = ART_KD(0x1.6124613a86d09p-33);
+  q = q * r + ART_KD(0x1.1eed8eff8d898p-29);
+  q = q * r + ART_KD(0x1.ae64567f544e4p-26);
+  q = q * r + ART_KD(0x1.27e4fb7789f5cp-22);
+  q = q * r + ART_KD(0x1.71de3a556c734p-19);
+  q = q * r + ART_KD(0x1.a01a01a01a01ap-16);
+  q = q * r + ART_KD(0x1.a01a01a01a01ap-13);
+  q = q * r + ART_KD(0x1.6c16c16c16c17p-10);
+  q = q * r + ART_KD(0x1.1111111111111p-7);
+  q = q * r + ART_KD(0x1.5555555555555p-5);
+  q = q * r + ART_KD(0x1.5555555555555p-3);
   q = q * r + 0.5;
   q = q * r + 1.0;
   q = q * r + 1.0;

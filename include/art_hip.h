@@ -156,8 +156,13 @@ int  art_reduce(void);                                   /* enqueue the framebuf
 /* What the multi-device path really did (round 5: a bench line has to show how many ranks RCCL saw, not be taken on trust).
  * Filled after art_synchronize: rccl_ranks = ncclCommCount of the communicator the reduces ran on (0: no communicator -- one device
  * without ART_FORCE_RCCL, or n contexts on one GPU, whose sum is a chain of local adds); reduce_ms = GPU time of the reduces on device
- * 0's stream (HIP events around the grouped ncclReduce / the adds), cumulative since art_resize; device_pass_ms[k] = GPU time of
- * device k's render passes (HIP events on its stream), cumulative. */
+ * 0's stream (HIP events around the grouped ncclReduce / the adds; it INCLUDES the time device 0's stream waits in the collective for
+ * the slowest device), cumulative since art_resize; device_pass_ms[k] = GPU time of device k's render passes (HIP events on its stream),
+ * cumulative.  Round 6, n > 1 devices only -- the host clock at which every device's stream reached the start and the end of each pass
+ * (hipLaunchHostFunc: one clock for all devices): device_busy_ms[k] = end - start, device_idle_ms[k] = the slowest device's end - device
+ * k's end (what an uneven tile deal costs), device_start_skew_ms[k] = device k's start - the first device's start (what enqueueing
+ * device after device costs), all summed over the passes; passes_overlapped counts the passes in which every device had started before
+ * any had finished -- Render_Pass releases all its workers before it waits for one, ray_tracer.adb:271-277. */
 typedef struct ArtReduceInfo {
   int32_t devices;               /* contexts of this process (art_init_devices n) */
   int32_t rccl_ranks;            /* ranks of the RCCL communicator, 0 = none */
@@ -165,6 +170,8 @@ typedef struct ArtReduceInfo {
   int32_t reduces;               /* reduces enqueued since art_resize */
   double  reduce_ms;             /* cumulative */
   double  device_pass_ms[8];     /* per device, cumulative */
+  double  device_busy_ms[8], device_idle_ms[8], device_start_skew_ms[8];
+  int32_t passes, passes_overlapped;
 } ArtReduceInfo;
 int  art_get_reduce_info(ArtReduceInfo* out);
 int  art_set_stream(void* hip_stream);                   /* hipStream_t; NULL = default stream */

@@ -23,7 +23,7 @@ def test_struct_layouts_match_the_header(art):
     assert C.sizeof(art.ArtHit) == 44
     assert C.sizeof(art.ArtStats) == 14 * 8
     assert C.sizeof(art.ArtInstance) == 52 and art.ArtSceneDesc.n_instances.offset == art.ArtSceneDesc.cam_matrix.offset + 64
-    assert C.sizeof(art.ArtStageStats) == 3 * 8 + 2 * 8 + 32 * 8 and C.sizeof(art.ArtReduceInfo) == 16 + 8 + 64
+    assert C.sizeof(art.ArtStageStats) == 3 * 8 + 2 * 8 + 32 * 8 and C.sizeof(art.ArtReduceInfo) == 16 + 8 + 4 * 64 + 8
 
 
 def test_no_cpu_fallback(art):

@@ -58,6 +58,24 @@ for name, devs in (("one", None), ("three_contexts", [0, 0, 0])):
 out["instanced_three_contexts"] = bool(np.array_equal(iimgs["one"][0].view(np.uint32), iimgs["three_contexts"][0].view(np.uint32))
                                        and np.array_equal(iimgs["one"][1], iimgs["three_contexts"][1]) and iimgs["one"][2:] == iimgs["three_contexts"][2:]
                                        and float(np.abs(iimgs["one"][0]).sum()) > 0.0)
+# Round 6: the host only enqueues -- no device's pass may wait for another device's (until round 5 the items-per-thread trial of the
+# shade stage blocked the host twice per trial batch, so the first batches of the devices ran one device at a time).  Three contexts, three
+# passes of two batches each enqueued back to back: art_get_reduce_info's host-clock marks (hipLaunchHostFunc on every stream) must show
+# every device started before any finished, in every pass -- Render_Pass releases all its workers before it waits for one
+# (ray_tracer.adb:271-277).
+be = art.Backend(devices=[0, 0, 0])
+be.set_option("batch_paths", 1 << 21)
+be.upload_scene(scenes.synthetic_scene(20000, 3)); be.resize(1280, 720)
+p4 = art.Backend.pass_params(art.PT_MIS, True, 8, 4, seed=5)
+spp = 0
+for _ in range(3):
+    spp = be.render_pass_device(p4, spp)
+ri = be.reduce_info()
+out["enqueue"] = {"passes": ri.passes, "overlapped": ri.passes_overlapped, "busy_positive": all(ri.device_busy_ms[k] > 0.0 for k in range(3)),
+                  "idle_nonnegative": all(ri.device_idle_ms[k] >= 0.0 for k in range(3)), "one_device_never_idle": min(ri.device_idle_ms[k] for k in range(3)) == 0.0 or ri.passes > 1,
+                  "skew_below_busy": all(ri.device_start_skew_ms[k] < ri.device_busy_ms[k] for k in range(3)), "first_device_skew_zero": min(ri.device_start_skew_ms[k] for k in range(3)) == 0.0 or ri.passes > 1}
+out["enqueue_ms"] = {"busy": list(ri.device_busy_ms)[:3], "idle": list(ri.device_idle_ms)[:3], "skew": list(ri.device_start_skew_ms)[:3]}
+be.shutdown()
 print(json.dumps(out))
 '''
 
@@ -66,6 +84,9 @@ def test_n_contexts_in_one_process_give_the_single_device_image(art):
     r = subprocess.run([sys.executable, "-c", SCRIPT, art.ROOT], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
+    ms = out.pop("enqueue_ms")
+    assert out.pop("enqueue") == {"passes": 3, "overlapped": 3, "busy_positive": True, "idle_nonnegative": True, "one_device_never_idle": True,
+                                  "skew_below_busy": True, "first_device_skew_zero": True}, ms
     assert out == {"oracle_equal": True, "one": True, "init_devices_1": True, "three_contexts": True, "eight_contexts": True,
                    "three_contexts_set_shard_refused": True, "eight_contexts_set_shard_refused": True, "instanced_three_contexts": True}, out
 
@@ -91,7 +112,8 @@ for force in ("0", "1"):
     be.reduce(); be.synchronize()
     ri = be.reduce_info()
     info.append({"devices": ri.devices, "rccl_ranks": ri.rccl_ranks, "path": ri.path, "reduces_at_least_one": ri.reduces >= 1,
-                 "reduce_ms_positive": ri.reduce_ms > 0.0, "device0_pass_ms_positive": ri.device_pass_ms[0] > 0.0})
+                 "reduce_ms_positive": ri.reduce_ms > 0.0, "device0_pass_ms_positive": ri.device_pass_ms[0] > 0.0,
+                 "passes": ri.passes, "overlapped": ri.passes_overlapped, "busy_positive": ri.device_busy_ms[0] > 0.0, "idle": ri.device_idle_ms[0], "skew": ri.device_start_skew_ms[0]})
     out.append((accum.copy(), screen.copy()))
     be.shutdown()
 print(json.dumps({"same": bool(np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)) and np.array_equal(out[0][1], out[1][1])), "nonzero": bool(out[1][0].any()), "info": info}))
@@ -102,8 +124,10 @@ print(json.dumps({"same": bool(np.array_equal(out[0][0].view(np.uint32), out[1][
     assert got["same"] and got["nonzero"]
     # art_get_reduce_info: without the communicator nothing is reduced (one device); with it the reduce ran on a 1-rank RCCL communicator,
     # took GPU time, and the device's passes were timed -- the fields bench.py --gpus N puts on its line (multi_gpu)
-    assert got["info"][0] == {"devices": 1, "rccl_ranks": 0, "path": 0, "reduces_at_least_one": False, "reduce_ms_positive": False, "device0_pass_ms_positive": True}
-    assert got["info"][1] == {"devices": 1, "rccl_ranks": 1, "path": 1, "reduces_at_least_one": True, "reduce_ms_positive": True, "device0_pass_ms_positive": True}
+    assert got["info"][0] == {"devices": 1, "rccl_ranks": 0, "path": 0, "reduces_at_least_one": False, "reduce_ms_positive": False, "device0_pass_ms_positive": True,
+                              "passes": 1, "overlapped": 1, "busy_positive": True, "idle": 0.0, "skew": 0.0}
+    assert got["info"][1] == {"devices": 1, "rccl_ranks": 1, "path": 1, "reduces_at_least_one": True, "reduce_ms_positive": True, "device0_pass_ms_positive": True,
+                              "passes": 1, "overlapped": 1, "busy_positive": True, "idle": 0.0, "skew": 0.0}
 
 
 def test_bench_under_torchrun_with_one_rank(art):

@@ -707,3 +707,23 @@ def test_skip_null_shadow_option_keeps_the_picture_and_traces_fewer_rays(art, ba
         backend.set_option("skip_null_shadow", 0)
     assert np.array_equal(bits(got), bits(ref)) and backend.stats().lost_paths == 0
     assert 0 < rays < rays_ref
+
+
+def test_a_lost_path_in_the_first_batch_fails_the_call_that_waits(art, backend):
+    """ADVICE r5: the self-check counter (ArtStats::lost_paths) is compared with a baseline that only the synchronising call advances.  Until
+    round 5 the items-per-thread trial of the shade stage read the counter in the first two batches after every upload / resize and absorbed
+    a loss there -- i.e. in the only batches a small render has.  Option inject_lost bumps the counter after bounce 0 of the next pass' first
+    batch, as a stage that lost a path would; the pass must fail, once, and the backend must keep working."""
+    from ada_ray_tracer_amd import scenes
+    backend.upload_scene(scenes.synthetic_scene(2000, 3)); backend.resize(64, 48)
+    p = art.Backend.pass_params(art.PT_MIS, True, 8, 1, seed=3)
+    backend.set_option("inject_lost", 1)
+    with pytest.raises(art.ArtError, match="1 path.s. lost"):
+        backend.render_pass(p, 0)
+    ref, _, spp = backend.render_pass(p, 4)                      # the same loss is not reported twice; the next pass is fine
+    assert spp == 8 and backend.stats().lost_paths == 1
+    backend.set_option("inject_lost", 1)                         # ... and in a later batch of a render, after passes that synchronised
+    with pytest.raises(art.ArtError, match="1 path.s. lost"):
+        backend.render_pass_device(p, spp)
+    backend.resize(64, 48)                                       # (zeroes the counters for the tests that follow)
+    assert backend.stats().lost_paths == 0
