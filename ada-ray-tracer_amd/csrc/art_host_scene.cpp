@@ -86,7 +86,14 @@ bool flatten_scene(const ArtSceneDesc& d, const BvhBuildParams& bp, HostScene& o
       insts[(size_t)i].mesh = in.mesh; std::memcpy(insts[(size_t)i].m, in.m, 48);
     }
     // boxes of the meshes' trees padded for the object-space walk (art_instanced.h instanced_render_closest)
-    if (!build_two_level_host(meshes, insts, out.two, err, false, 1.0e-4f, 1.0e-5f, bp.inst_open)) return false;
+    // (scene_extent: what else a ray of this scene can start at -- the walls, the spheres and lights, the camera; the meshes' absolute pad
+    // follows it and the instances' inverse matrices, art_instanced_build.cpp)
+    float extent = 0.0f;
+    auto reach = [&](float v) { if (std::isfinite(v)) extent = std::max(extent, std::fabs(v)); };
+    for (int k = 0; k < 3; ++k) { reach(d.cam_pos[k]); if (d.has_cornell) { reach(d.cb_min[k]); reach(d.cb_max[k]); } }
+    for (int i = 0; i < d.n_spheres; ++i) for (int k = 0; k < 3; ++k) reach(std::fabs(d.spheres[i].pos[k]) + std::fabs(d.spheres[i].r));
+    for (int i = 0; i < d.n_lights; ++i) for (int k = 0; k < 3; ++k) { reach(d.lights[i].boxMin[k]); reach(d.lights[i].boxMax[k]); reach(std::fabs(d.lights[i].center[k]) + std::fabs(d.lights[i].radius)); }
+    if (!build_two_level_host(meshes, insts, out.two, err, false, 1.0e-4f, 1.0e-5f, bp.inst_open, extent)) return false;
     int shift = 0; while ((1 << shift) < max_tris) ++shift;
     if (shift > 27 || ((uint64_t)d.n_instances << shift) > (1ull << 28)) { err = "scene: instances x triangles per mesh exceed the 28-bit hit index"; return false; }
     int64_t total = 0;

@@ -24,7 +24,7 @@ static bool invert_3x4(const float m[12], float out[12]) {     // world -> objec
 }
 
 bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vector<InstIn>& insts, TwoLevelHost& T, std::string& err,
-                          bool two_sided, float pad_rel, float pad_abs, int open_factor) {
+                          bool two_sided, float pad_rel, float pad_abs, int open_factor, float scene_extent) {
   T = TwoLevelHost();
   BvhBuildParams bp; bp.width = 4;
   if (pad_rel >= 0.0f) bp.inflate_rel = pad_rel;
@@ -35,20 +35,62 @@ bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vect
   std::vector<std::vector<uint32_t>> mesh_q;             // one-sided builds: every mesh's quantised nodes, relocated below
   std::vector<std::vector<float>> mesh_pts(nm);          // the vertices a mesh's triangles use (an instance's world box is the box of their images)
   std::vector<const float*> inst_m;                      // the kept instances' matrices (the caller's arrays)
-  for (size_t mi = 0; mi < nm; ++mi) {
+  for (size_t mi = 0; mi < nm; ++mi) {                   // the meshes' object-space boxes first: the instances' pads below need them
     const InstMeshIn& m = meshes[mi];
     if (m.n_tris == 0 || m.n_verts == 0) { err = "empty mesh"; return false; }
-    std::vector<float> tri9((two_sided ? 18 : 9) * m.n_tris);
     float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (size_t k = 0; k < 3 * m.n_tris; ++k) { const float* P = m.verts + 3 * (size_t)m.idx[k]; for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], P[a]); hi[a] = std::max(hi[a], P[a]); } }
+    mesh_box[mi] = {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]};
+  }
+  // ---- the absolute pad of a mesh's boxes follows its instances (round 6).  The walk tests a mesh's boxes with the ray taken to
+  // object space in binary32: oo = minv * o, dd = minv * d, each coordinate a sum of four / three rounded terms.  Its error grows with
+  // |minv| * |o|, not with the object-space coordinates the relative pad follows: a speck -- scale 5e-4, object coordinates within +-1,
+  // placed at Cornell-box distances -- sees its ray 2000 * 5 * 2^-24 = 6e-4 object units off, five times the fixed pad of 1.1e-4, and the
+  // box test culled triangles the world-space triangle test accepts (holes the flattened scene does not have:
+  // tests/test_instanced_host_sim.py test_a_speck_far_from_the_origin).  Bound per object-space coordinate r along a ray of the scene:
+  //   | err | <= k * 2^-24 * ( sum_j |minv_rj| * (E + L) + |minv_r3| ),   E = the largest |coordinate| a ray can start at, L = the longest ray
+  // (a ray's point at parameter t is oo + t * dd: the origin's error plus t times the direction's).  With k = 8 (four terms, their products
+  // and the running sum each rounded, a factor two to spare), E = the scene's extent and L = 2 E.  The pad of a mesh is the maximum over
+  // its instances and the three coordinates, never below the caller's pad_abs.
+  std::vector<double> mesh_pad(nm, 0.0);
+  {
+    double E = (double)std::max(0.0f, scene_extent);
+    std::vector<std::array<float, 12>> minv(insts.size());
+    std::vector<uint8_t> ok(insts.size(), 0);
+    for (size_t ii = 0; ii < insts.size(); ++ii) {
+      const InstIn& in = insts[ii];
+      if (in.mesh < 0 || (size_t)in.mesh >= nm) continue;                       // (reported below)
+      ok[ii] = invert_3x4(in.m, minv[ii].data()) ? 1 : 0;
+      const std::array<float, 6>& mb = mesh_box[(size_t)in.mesh];
+      for (int r = 0; r < 3; ++r) {                                             // how far out the instance reaches in the world
+        double reach = std::fabs((double)in.m[4 * r + 3]);
+        for (int j = 0; j < 3; ++j) reach += std::fabs((double)in.m[4 * r + j]) * std::max(std::fabs((double)mb[(size_t)j]), std::fabs((double)mb[(size_t)j + 3]));
+        if (std::isfinite(reach)) E = std::max(E, reach);
+      }
+    }
+    for (size_t ii = 0; ii < insts.size(); ++ii) {
+      if (!ok[ii]) continue;
+      for (int r = 0; r < 3; ++r) {
+        const float* q = &minv[ii][4 * (size_t)r];
+        const double bound = 8.0 * 5.9604644775390625e-8 * ((std::fabs((double)q[0]) + std::fabs((double)q[1]) + std::fabs((double)q[2])) * 3.0 * E + std::fabs((double)q[3]));
+        if (std::isfinite(bound)) mesh_pad[(size_t)insts[ii].mesh] = std::max(mesh_pad[(size_t)insts[ii].mesh], bound);
+      }
+    }
+  }
+  for (size_t mi = 0; mi < nm; ++mi) {
+    const InstMeshIn& m = meshes[mi];
+    std::vector<float> tri9((two_sided ? 18 : 9) * m.n_tris);
     for (size_t t = 0; t < m.n_tris; ++t) {
       const float* A = m.verts + 3 * (size_t)m.idx[3 * t]; const float* B = m.verts + 3 * (size_t)m.idx[3 * t + 1]; const float* C = m.verts + 3 * (size_t)m.idx[3 * t + 2];
       float* f = &tri9[(two_sided ? 18 : 9) * t];
       std::memcpy(f, A, 12); std::memcpy(f + 3, B, 12); std::memcpy(f + 6, C, 12);          // record 2t:   front winding
       if (two_sided) { std::memcpy(f + 9, A, 12); std::memcpy(f + 12, C, 12); std::memcpy(f + 15, B, 12); }     // record 2t+1: back winding
-      for (const float* P : {A, B, C}) for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], P[a]); hi[a] = std::max(hi[a], P[a]); }
     }
     Bvh8 b;
-    if (!build_bvh8(tri9.data(), nullptr, (int32_t)((two_sided ? 2 : 1) * m.n_tris), bp, b, err)) return false;
+    BvhBuildParams bm = bp;
+    bm.inflate_abs = std::max(bp.inflate_abs, (float)std::min(mesh_pad[mi], 1.0e30));
+    T.mesh_pad_abs.push_back(bm.inflate_abs);
+    if (!build_bvh8(tri9.data(), nullptr, (int32_t)((two_sided ? 2 : 1) * m.n_tris), bm, b, err)) return false;
     // instanced_closest walks a mesh tree with bvh_closest's private stack of kStackEntries entries and pushes unchecked (like the
     // flattened upload, which art_upload_scene refuses for the same reason)
     if (b.max_stack > kStackEntries) { err = "mesh tree stack bound " + std::to_string(b.max_stack) + " exceeds " + std::to_string(kStackEntries); return false; }
@@ -59,7 +101,6 @@ bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vect
     ntris[mi] = b.n_tris;
     T.blas_nodes.insert(T.blas_nodes.end(), b.nodes.begin(), b.nodes.end());
     T.blas_tris.insert(T.blas_tris.end(), b.tris.begin(), b.tris.end());
-    mesh_box[mi] = {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]};
     std::vector<uint8_t> used(m.n_verts, 0);
     for (size_t k = 0; k < 3 * m.n_tris; ++k) used[(size_t)m.idx[k]] = 1;
     for (size_t v = 0; v < m.n_verts; ++v) if (used[v]) mesh_pts[mi].insert(mesh_pts[mi].end(), m.verts + 3 * v, m.verts + 3 * v + 3);

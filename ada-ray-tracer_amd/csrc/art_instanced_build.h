@@ -27,6 +27,7 @@ struct TwoLevelHost {
   std::vector<EntryPoint> entry;
   int32_t open_factor = 1;              // entry points per instance asked of the build (the automatic choice, if that was left to it)
   int32_t blas_max_stack = 0;           // the largest worst-case traversal stack of the meshes' trees
+  std::vector<float> mesh_pad_abs;      // per mesh: the absolute pad its tree's boxes were built with (>= the caller's; follows the mesh's instances)
   InstScene view() const {
     InstScene S;
     S.tlas_nodes = tlas.nodes.data(); S.tlas_tris = tlas.tris.data(); S.blas_nodes = blas_nodes.data(); S.blas_tris = blas_tris.data();
@@ -42,7 +43,9 @@ struct TwoLevelHost {
 // triangle that the world-space arithmetic would accept), and a singular instance matrix is an error instead of a dropped instance.
 // open_factor > 1 (one-sided builds): the instance tree ends at about open_factor entry points per instance -- subtrees of the meshes'
 // trees under the tight world boxes of their own triangles -- instead of at whole instances.  0: chosen from how much the instances' boxes overlap.
+// scene_extent: the largest |coordinate| of anything a ray can start at besides the instances themselves (walls, spheres, the camera); the
+// absolute pad of a mesh's boxes is derived from it and from the mesh's instances (their inverse matrices): TwoLevelHost::mesh_pad_abs.
 bool build_two_level_host(const std::vector<InstMeshIn>& meshes, const std::vector<InstIn>& insts, TwoLevelHost& out, std::string& err,
-                          bool two_sided = true, float pad_rel = -1.0f, float pad_abs = -1.0f, int open_factor = 1);
+                          bool two_sided = true, float pad_rel = -1.0f, float pad_abs = -1.0f, int open_factor = 1, float scene_extent = 0.0f);
 
 }  // namespace art

@@ -188,6 +188,7 @@ bool Hydra_Scene::Build_Render_Desc(const Scene& base, std::string& err) {
     r_materials.push_back(m);
   }
   r_meshes.assign(meshes.size(), ArtMesh()); r_matids.assign(meshes.size(), {});
+  clamped_material_ids = 0;
   for (size_t i = 0; i < meshes.size(); ++i) {
     const Mesh& me = meshes[i];
     ArtMesh& d = r_meshes[i]; std::memset(&d, 0, sizeof d);
@@ -196,7 +197,9 @@ bool Hydra_Scene::Build_Render_Desc(const Scene& base, std::string& err) {
     r_matids[i].resize(nt);
     for (size_t t = 0; t < nt; ++t) {
       const int32_t id = t < me.material_ids.size() ? me.material_ids[t] : 0;
-      r_matids[i][t] = first + std::min(std::max(id, 0), (int32_t)materials.size() - 1);
+      const int32_t kept = std::min(std::max(id, 0), (int32_t)materials.size() - 1);
+      if (kept != id) clamped_material_ids += 1;
+      r_matids[i][t] = first + kept;
     }
     d.mode = ART_MESH_CLOSEST;
     d.nverts = (int32_t)(me.vert_positions.size() / 3); d.ntris = (int32_t)nt;
@@ -209,7 +212,10 @@ bool Hydra_Scene::Build_Render_Desc(const Scene& base, std::string& err) {
     ArtInstance a; a.mesh = in.mesh_id; std::memcpy(a.m, in.matrix, 48);
     r_instances.push_back(a);
   }
-  r_desc = base.desc;                                          // box, spheres, light, camera of the internal scene
+  if (clamped_material_ids > 0)                                // once per build, not per triangle
+    std::fprintf(stderr, "Hydra_Scene::Build_Render_Desc: %lld triangle(s) name a material outside the library's %zu; they take its nearest one\n",
+                 (long long)clamped_material_ids, materials.size());
+  r_desc = base.desc;                                          // box, spheres, light, camera of the internal scene -- NOT its own mesh (hydra_scene.hpp)
   r_desc.n_materials = (int32_t)r_materials.size(); r_desc.materials = r_materials.data();
   r_desc.n_meshes = (int32_t)r_meshes.size(); r_desc.meshes = r_meshes.data();
   r_desc.n_instances = (int32_t)r_instances.size(); r_desc.instances = r_instances.data();
@@ -234,15 +240,24 @@ extern "C" int art_host_hydra_load(const char* dir, int* counts4 /* meshes, mate
   for (size_t i = 0; i < g_hydra.instances.size() && i < 64; ++i) std::memcpy(matrices + 16 * i, g_hydra.instances[i].matrix, 64);
   return 0;
 }
-// The scene library as a render scene (Hydra_Scene::Build_Render_Desc): the descriptor art_upload_scene takes, valid until the next call.
-// vsgf_path: where the internal scene finds data/pyramid2.vsgf (Scene.Init).  nullptr on failure, message on stderr.
-extern "C" const ArtSceneDesc* art_host_hydra_render_desc(const char* dir, const char* vsgf_path) {
-  static art_host::Scene base; static art_host::Hydra_Scene hy;
+// The scene library as a render scene (Hydra_Scene::Build_Render_Desc) behind a handle that OWNS everything the descriptor points into
+// (round 6, ADVICE r5: the first form returned pointers into function-local statics that the next call invalidated under a caller still
+// holding them).  vsgf_path: where the internal scene finds data/pyramid2.vsgf (Scene.Init).  nullptr on failure, message on stderr.
+namespace { struct HydraRenderScene { art_host::Scene base; art_host::Hydra_Scene hy; }; }
+extern "C" void* art_host_hydra_scene_create(const char* dir, const char* vsgf_path) {
+  HydraRenderScene* h = new HydraRenderScene;
   std::string err;
-  hy = art_host::Hydra_Scene();
-  if (!dir || !vsgf_path || !base.Init(vsgf_path, err) || !hy.Load(dir, err) || !hy.Build_Render_Desc(base, err)) { std::fprintf(stderr, "art_host_hydra_render_desc: %s\n", err.c_str()); return nullptr; }
-  return &hy.r_desc;
+  if (!dir || !vsgf_path || !h->base.Init(vsgf_path, err) || !h->hy.Load(dir, err) || !h->hy.Build_Render_Desc(h->base, err)) {
+    std::fprintf(stderr, "art_host_hydra_scene_create: %s\n", err.c_str());
+    delete h;
+    return nullptr;
+  }
+  return h;
 }
+// the descriptor art_upload_scene takes (it copies): valid until art_host_hydra_scene_destroy(handle)
+extern "C" const ArtSceneDesc* art_host_hydra_scene_desc(void* handle) { return handle ? &static_cast<HydraRenderScene*>(handle)->hy.r_desc : nullptr; }
+extern "C" long long art_host_hydra_scene_clamped_ids(void* handle) { return handle ? static_cast<HydraRenderScene*>(handle)->hy.clamped_material_ids : -1; }
+extern "C" void art_host_hydra_scene_destroy(void* handle) { delete static_cast<HydraRenderScene*>(handle); }
 extern "C" int art_host_hydra_init(const char* dir) {
   std::string err;
   if (!g_hydra.Init(dir, err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }

@@ -42,7 +42,10 @@ struct Hydra_Scene {                    // Render_Scene of scene_hydra_embree.ad
   // of this (Find_Closest_Hit returns matId -1, lights are only counted, no camera is read: scene_hydra_embree.adb:303-390, :426-446), so
   // the surroundings are the internal scene's (`base`: box, spheres, light, camera of Scene.Init) and the materials are its table 0..10
   // followed by ONE Lambert per <material> (the diffuse colour is all Load_Materials reads, :192-225); a triangle takes material
-  // 11 + its VSGF material id, ids past the end of the library the library's last material.
+  // 11 + its VSGF material id, ids outside the library its nearest one (counted in clamped_material_ids, one line on stderr per build).
+  // NOT in the picture: the internal scene's own mesh (data/pyramid2.vsgf, a brute-force mesh in world space) -- an instanced render
+  // scene holds closest-hit prototypes only (art_hip.h ArtSceneDesc::instances), so `base` contributes its analytic surroundings and nothing else.
+  long long clamped_material_ids = 0;
   std::vector<ArtMaterial> r_materials; std::vector<ArtMesh> r_meshes; std::vector<std::vector<int32_t>> r_matids; std::vector<ArtInstance> r_instances;
   ArtSceneDesc r_desc;
   bool Build_Render_Desc(const Scene& base, std::string& err);   // after Load; the descriptor points into this object and into `base`

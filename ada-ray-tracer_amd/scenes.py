@@ -269,14 +269,25 @@ class HydraSceneDesc:
         import ctypes as C
         from . import HOST_LIB_PATH, ArtError, ArtSceneDesc
         lib = C.CDLL(HOST_LIB_PATH)
-        lib.art_host_hydra_render_desc.restype = C.POINTER(ArtSceneDesc)
-        lib.art_host_hydra_render_desc.argtypes = [C.c_char_p, C.c_char_p]
-        p = lib.art_host_hydra_render_desc(str(scene_dir).encode(), (vsgf_path or PYRAMID_VSGF).encode())
-        if not p:
-            raise ArtError("art_host_hydra_render_desc failed for %s" % scene_dir)
+        lib.art_host_hydra_scene_create.restype = C.c_void_p
+        lib.art_host_hydra_scene_create.argtypes = [C.c_char_p, C.c_char_p]
+        lib.art_host_hydra_scene_desc.restype = C.POINTER(ArtSceneDesc)
+        lib.art_host_hydra_scene_desc.argtypes = [C.c_void_p]
+        lib.art_host_hydra_scene_clamped_ids.restype = C.c_longlong
+        lib.art_host_hydra_scene_clamped_ids.argtypes = [C.c_void_p]
+        lib.art_host_hydra_scene_destroy.argtypes = [C.c_void_p]
         self._lib = lib
+        self._handle = lib.art_host_hydra_scene_create(str(scene_dir).encode(), (vsgf_path or PYRAMID_VSGF).encode())
+        if not self._handle:
+            raise ArtError("art_host_hydra_scene_create failed for %s" % scene_dir)
+        self.clamped_material_ids = int(lib.art_host_hydra_scene_clamped_ids(self._handle))
         self.desc = ArtSceneDesc()
-        C.memmove(C.byref(self.desc), p, C.sizeof(ArtSceneDesc))      # pointers stay those of the host layer's static objects
+        C.memmove(C.byref(self.desc), lib.art_host_hydra_scene_desc(self._handle), C.sizeof(ArtSceneDesc))      # its pointers live as long as the handle this object owns
+
+    def __del__(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            self._lib.art_host_hydra_scene_destroy(h)
 
 
 def reference_scene(cam_pos=None):
@@ -297,3 +308,17 @@ def eight_sphere_scene(seed=0xADA5EED0 + 1):
         p = (float(F(-2.0) + F(4.0) * u[i, 0]), float(F(2.3) + F(1.4) * u[i, 1]), float(F(0.6) + F(3.8) * u[i, 2]))
         spheres.append((p, 0.4, (1, 8, 0, 2, 3)[i]))
     return SceneDesc(spheres=spheres, lights=lights, materials=mats, meshes=[], cornell=CORNELL_BOX, cam_pos=REFERENCE_CAMERA)
+
+
+def speck_scene(scale=5.0e-4, centre=(-2.1, 4.4, 0.7), view=(2.0, 1.0), tris=600):
+    """ONE instance of instanced_scene's bumpy grid (object coordinates within +-1) shrunk to a speck of `scale` and placed far from the
+    origin, the camera `view` = (dz, dy) speck sizes in front of / above it so that it fills the frame: the ray taken to object space in
+    binary32 is then |minv| * |o| * 2^-24 = several 1e-4 object units off -- the case the meshes' absolute box pad has to follow
+    (csrc/art_instanced_build.cpp; round 6).  Rendered instanced it must still be the flattened scene's picture, bit for bit."""
+    m = np.zeros((3, 4)); m[:, :3] = np.eye(3) * scale; m[:, 3] = centre
+    sd = instanced_scene(0, tris, transforms=[(1, m)])
+    cam = (centre[0], centre[1] + view[1] * scale, centre[2] + view[0] * scale)
+    for k in range(3):
+        sd.desc.cam_pos[k] = cam[k]
+    sd._kw["cam_pos"] = cam
+    return sd

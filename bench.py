@@ -44,7 +44,7 @@ import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 GATHER_CEILING_GBPS = 8000.0   # MI355X_MICROARCH.md "Indexed rows": random rows out of the Infinity Cache, 8.6 TB/s (38 MB table) .. 7.4-7.9 (151 MB)
-PROFILE_TAG = "r5_final"
+PROFILE_TAG = "r6_final"
 
 # Algorithmic bytes of the wavefront stages per work item (the layout of csrc/art_scene.h HotField).  in: the
 # item's hit record 16 + flags, shadow word, shadow epsilon, previous pdf, slot 20 + extension ray 24 (bounce 0: the hit record alone, the
@@ -294,7 +294,9 @@ def main():
         dist.all_gather(per_rank, torch.tensor([elapsed_local], dtype=torch.float64, device="cuda"))
         multi = {"mode": "one process per GPU (torch.distributed)", "backend": dist.get_backend(), "rccl_ranks": int(dist.get_world_size()),
                  "reduce_ms": round(reduce_ms_torch, 3), "reduce_note": "torch.cuda events around dist.reduce on rank 0 (one reduce per run, inside the timed region)",
-                 "per_device_ms_per_step": [round(float(t.item()) * 1e3 / max(1, args.steps), 3) for t in per_rank]}
+                 "per_device_ms_per_step": [round(float(t.item()) * 1e3 / max(1, args.steps), 3) for t in per_rank],
+                 # what the slowest rank makes the others wait per step (tile-deal imbalance + start skew): max over ranks - own wall time
+                 "per_device_idle_ms_per_step": [round((elapsed - float(t.item())) * 1e3 / max(1, args.steps), 3) for t in per_rank]}
     else:
         total_rays, total_samples = float(rays), float(samples)
         rays_dev0 = rays / n_gpus if in_library else rays          # stats(): trace_ms is device 0's, rays the whole job's
@@ -303,7 +305,15 @@ def main():
             multi = {"mode": "one process (art_init_devices)", "backend": "rccl" if r1.rccl_ranks > 0 else "local adds (contexts on one GPU)",
                      "rccl_ranks": int(r1.rccl_ranks), "devices": int(r1.devices), "reduces": int(r1.reduces - r0.reduces),
                      "reduce_ms": round(r1.reduce_ms - r0.reduce_ms, 3), "reduce_note": "HIP events around the grouped ncclReduce on device 0's stream (inside the timed region)",
-                     "per_device_ms_per_step": [round((r1.device_pass_ms[k] - r0.device_pass_ms[k]) / max(1, args.steps), 3) for k in range(int(r1.devices))]}
+                     "per_device_ms_per_step": [round((r1.device_pass_ms[k] - r0.device_pass_ms[k]) / max(1, args.steps), 3) for k in range(int(r1.devices))],
+                     # host-clock marks on every device's stream (hipLaunchHostFunc: one clock for all devices): busy = end - start of a pass,
+                     # idle = the slowest device's end - this device's end (tile-deal imbalance), start_skew = this device's start - the first
+                     # device's start (the host enqueues device after device); passes_overlapped = passes in which every device had started
+                     # before any had finished (the host never waits between devices: ray_tracer.adb:271-277)
+                     "per_device_busy_ms_per_step": [round((r1.device_busy_ms[k] - r0.device_busy_ms[k]) / max(1, args.steps), 3) for k in range(int(r1.devices))],
+                     "per_device_idle_ms_per_step": [round((r1.device_idle_ms[k] - r0.device_idle_ms[k]) / max(1, args.steps), 3) for k in range(int(r1.devices))],
+                     "per_device_start_skew_ms_per_step": [round((r1.device_start_skew_ms[k] - r0.device_start_skew_ms[k]) / max(1, args.steps), 3) for k in range(int(r1.devices))],
+                     "passes": int(r1.passes - r0.passes), "passes_overlapped": int(r1.passes_overlapped - r0.passes_overlapped)}
 
     if rank == 0:
         # ---- roofline of the dominant kernel (trace): algorithmic bytes / HIP-event time, device 0's launches
@@ -344,8 +354,9 @@ def main():
             over = achieved > HBM_PEAK_GBPS      # only the 8-wide option: its 256-byte binary32 nodes are mostly served by L2, so the
             cands = [("hbm", 0.0 if over else achieved / HBM_PEAK_GBPS)] + ([("issue", issue)] if issue is not None else []) + ([("fabric", fabric)] if fabric is not None else [])
             bound = max(cands, key=lambda kv: kv[1])[0] if prof else "hbm"
-            roofline = {"bound": bound, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",   # algorithmic rate is no HBM rate
-                        "bound_note": "the largest of frac (algorithmic bytes / HBM peak: the contract figure), issue (VALU issue time / SIMD time) and fabric_frac (bytes past L2 / gather ceiling); 'hbm' when no profile of this build is committed",
+            roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",   # the contract's roofline of this path (HBM bandwidth, no MFMA); achieved = ALGORITHMIC bytes per second
+                        "limited_by": bound,
+                        "bound_note": "bound = the roofline the contract prices this path against (HBM bandwidth).  limited_by = the largest of frac (algorithmic bytes / HBM peak), issue (VALU issue time / SIMD time) and fabric_frac (bytes past L2 / gather ceiling) -- what the kernel itself sits on; 'hbm' when no profile of this build is committed",
                         "issue": issue, "fabric_frac": fabric,
                         "device": ("device 0 of %d (one process, art_init_devices); counters summed over the devices" % n_gpus) if in_library else None,
                         "frac": None if over else round(achieved / HBM_PEAK_GBPS, 4),

@@ -51,6 +51,23 @@ def test_mirrored_sheared_coincident_tiny_and_huge_instances(art, inst_open):
     assert np.isfinite(acc).mean() > 0.99 and (acc > 0).mean() > 0.3      # (the reference's 1 / max(cos, 1e-20) gives a few pixels of 1e16 .. 1e38 on the mirror and glass triangles: the same bits in both)
 
 
+@pytest.mark.parametrize("view", [(2.0, 1.0), (1.5, 0.1)])
+def test_a_speck_far_from_the_origin(art, view):
+    """a tiny instance (scale 5e-4) far from the origin seen from two speck sizes away.  Its ray in object space carries a binary32
+    error of |minv| * |o| * 2^-24 = 6e-4 object units, more than the 1.1e-4 the meshes' boxes were padded by until round 5: the box test
+    culled triangles the world-space triangle test accepts (these two views: 2 and 1 pixels of 9216 differed from the flattened scene).  The
+    pad now follows the instances (art_instanced_build.cpp): the flattened scene's picture, bit for bit, grazing rays included."""
+    from ada_ray_tracer_amd import scenes
+    sd = scenes.speck_scene(view=view)
+    flat = hostsim.flattened_copy(art, sd)
+    assert tuple(flat.desc.cam_pos) == tuple(sd.desc.cam_pos)
+    p = art.Backend.pass_params(art.PT_MIS, True, 4, 1, seed=3)
+    acc, rays = hostsim.render(art, sd, p, 96, 96)
+    ref, _, cnt = orc.render(conv.OracleScene(flat).scene, orc.make_params(96, 96, orc.PT_MIS, True, 4, 1, seed=3))      # the oracle's O(N) scan of the flattened mesh
+    assert rays == cnt.rays and np.array_equal(bits(acc), bits(ref))
+    assert (acc > 0).mean() > 0.5
+
+
 def test_four_thousand_small_instances(art):
     """4096 instances of two ~300-triangle meshes crowding the box (every ray inside dozens of instance boxes: the build opens them into
     entry points by its own rule): the two-level search == the product's own search of the flattened 1.2 M-triangle mesh, bits and ray count"""
