@@ -117,7 +117,58 @@ static int ensure(DevBuf& b, size_t bytes) {
   return 0;
 }
 
-void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+void DevBuf::release() {
+  if (reserved) {                                        // a mapped range (alloc_spread)
+    for (size_t i = 0; i < chunks.size(); ++i) { (void)hipMemUnmap((char*)p + i * chunk_bytes, chunk_bytes); (void)hipMemRelease(chunks[i]); }
+    (void)hipMemAddressFree(p, reserved);
+    chunks.clear(); reserved = 0; chunk_bytes = 0;
+  } else if (p) (void)hipFree(p);
+  p = nullptr; bytes = 0;
+}
+
+// `bytes` of device memory as ONE address range over separately created physical chunks with holes between them (Ctx::paths_spread_mb).
+// Every failure undoes what was done and reports it; the caller falls back to hipMalloc.
+static hipError_t alloc_spread(DevBuf& b, size_t bytes, size_t chunk, int device) {
+  hipMemAllocationProp prop; std::memset(&prop, 0, sizeof prop);
+  prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+  size_t gran = 0;
+  hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+  if (e != hipSuccess || gran == 0) return e != hipSuccess ? e : hipErrorNotSupported;
+  chunk = (chunk + gran - 1) / gran * gran;
+  const size_t n = (bytes + chunk - 1) / chunk;
+  void* va = nullptr;
+  e = hipMemAddressReserve(&va, n * chunk, 0, nullptr, 0);
+  if (e != hipSuccess) return e;
+  std::vector<hipMemGenericAllocationHandle_t> got, spacers;
+  size_t mapped = 0;
+  auto undo = [&]() {
+    for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap((char*)va + i * chunk, chunk);
+    for (auto h : got) (void)hipMemRelease(h);
+    for (auto h : spacers) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(va, n * chunk);
+    (void)hipGetLastError();
+  };
+  for (size_t i = 0; i < n; ++i) {
+    hipMemGenericAllocationHandle_t h;
+    e = hipMemCreate(&h, chunk, &prop, 0);
+    if (e != hipSuccess) { undo(); return e; }
+    got.push_back(h);
+    hipMemGenericAllocationHandle_t sp;                  // the hole behind it (none if the device is too full: the layout degrades, nothing fails)
+    if (i + 1 < n) { if (hipMemCreate(&sp, chunk, &prop, 0) == hipSuccess) spacers.push_back(sp); else (void)hipGetLastError(); }
+  }
+  for (size_t i = 0; i < n; ++i) {
+    e = hipMemMap((char*)va + i * chunk, chunk, 0, got[i], 0);
+    if (e != hipSuccess) { undo(); return e; }
+    mapped = i + 1;
+  }
+  hipMemAccessDesc acc; std::memset(&acc, 0, sizeof acc);
+  acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+  e = hipMemSetAccess(va, n * chunk, &acc, 1);
+  if (e != hipSuccess) { undo(); return e; }
+  for (auto h : spacers) (void)hipMemRelease(h);
+  b.p = va; b.bytes = bytes; b.chunks = std::move(got); b.chunk_bytes = chunk; b.reserved = n * chunk;
+  return hipSuccess;
+}
 
 int ensure_device() {
   Ctx& c = g_ctx;
@@ -276,7 +327,7 @@ static int download_from(const float* acc_dev, float* accum_host, uint32_t* scre
 // records in one array shared by the banks.  Plain layout (one-ray-per-lane schedule, debug pass): rays as SoA arrays, 29 words.
 constexpr size_t kRecSlack = 4096;       // records past the last one the trace kernel's chunk prefetch may touch
 // (record schedule: 6 ray words, ONE 16-byte hit record + the shadow ray's result word, 7 per-path words)
-static size_t hot_stride(size_t P) { return (P + 63) & ~(size_t)63; }
+static size_t hot_stride(size_t P) { return ((P + 63) & ~(size_t)63) + (size_t)g_ctx.hot_pad; }      // (+ option hot_pad: items between the fields of a bank's block, Ctx::hot_pad)
 static size_t hot_floats(size_t P, bool rec) { return rec ? (size_t)kHotFields * hot_stride(P) + 64 : (14 + 8 + 7) * P; }
 // (the trace records are not double-banked: a bank's records are dead once its rays are traced, and the next stage reads none of them)
 // cold state: e (depth + 1 levels: dense fold records keep e_k at level k + 1) and w (depth levels) x 3, child (depth levels), term, rad, final flags
@@ -512,7 +563,18 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
       e = hipSuccess;
       if (b.p && b.bytes >= bytes) return true;
       b.release();
-      e = hipMalloc(&b.p, bytes);
+      // physically contiguous if the driver can (option paths_contiguous; art_api_internal.h Ctx::paths_contiguous says why), else as it comes
+      e = hipErrorOutOfMemory; c.paths_are_contiguous = false; c.paths_are_spread = false;
+      if (c.paths_spread_mb > 0) {
+        e = alloc_spread(b, bytes, (size_t)c.paths_spread_mb << 20, c.device);
+        if (e == hipSuccess) { c.paths_are_spread = true; return true; }
+        b.p = nullptr; (void)hipGetLastError();
+      }
+      if (c.paths_contiguous) {
+        e = hipExtMallocWithFlags(&b.p, bytes, hipDeviceMallocContiguous);
+        if (e == hipSuccess) c.paths_are_contiguous = true; else { b.p = nullptr; (void)hipGetLastError(); }
+      }
+      if (e != hipSuccess) e = hipMalloc(&b.p, bytes);
       if (e == hipSuccess) { b.bytes = bytes; return true; }
       b.p = nullptr; (void)hipGetLastError();
       return false;
@@ -527,7 +589,7 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
         if (g_debug_addr) {
           DevPaths bk[2]; std::memset(bk, 0, sizeof bk);
           carve(bk, pc * sc, p->max_depth, rec_layout);
-          std::fprintf(stderr, "ART_DEBUG_ADDR paths %p bytes %zu P %d rec %p hot0 %p hot1 %p stride %d cold %p live %p counters %p cursor %p\n", g_ctx.b_paths.p, g_ctx.b_paths.bytes, pc * sc,
+          std::fprintf(stderr, "ART_DEBUG_ADDR spread %d contiguous %d paths %p bytes %zu P %d rec %p hot0 %p hot1 %p stride %d cold %p live %p counters %p cursor %p\n", c.paths_are_spread ? 1 : 0, c.paths_are_contiguous ? 1 : 0, g_ctx.b_paths.p, g_ctx.b_paths.bytes, pc * sc,
                        (void*)bk[0].rec, (void*)bk[0].hot, (void*)bk[1].hot, bk[0].stride, (void*)bk[0].cold, (void*)c.d_live, (void*)c.d_counters, (void*)c.d_cursor);
         }
         break;
@@ -934,7 +996,7 @@ int art_init_devices(int32_t n, const int32_t* ordinals) {
     Ctx& c = g_devs[k];
     c = Ctx();
     c.trace_kernel = opts.trace_kernel; c.batch_paths = opts.batch_paths; c.bvh_params = opts.bvh_params; c.node_min = opts.node_min; c.refill_min = opts.refill_min;
-    c.queue_segments = opts.queue_segments; c.ray_chunk = opts.ray_chunk; c.shadow_anyhit = opts.shadow_anyhit; c.shade_split = opts.shade_split; c.skip_null_shadow = opts.skip_null_shadow; c.inst_coop = opts.inst_coop; c.opt_shade_per = opts.opt_shade_per; c.lds_stack_cap = opts.lds_stack_cap;
+    c.queue_segments = opts.queue_segments; c.ray_chunk = opts.ray_chunk; c.shadow_anyhit = opts.shadow_anyhit; c.shade_split = opts.shade_split; c.skip_null_shadow = opts.skip_null_shadow; c.inst_coop = opts.inst_coop; c.opt_shade_per = opts.opt_shade_per; c.lds_stack_cap = opts.lds_stack_cap; c.paths_contiguous = opts.paths_contiguous; c.hot_pad = opts.hot_pad; c.paths_spread_mb = opts.paths_spread_mb;
     c.opt_blocks_per_cu = opts.opt_blocks_per_cu; c.count_tests = opts.count_tests;
     c.device = ord[k]; c.rank = k; c.nranks = n; c.tile = 32;
     if (use_dev(k) || ensure_device()) { shutdown(); return 1; }
@@ -1102,6 +1164,9 @@ static int set_option_one(const std::string& n, int64_t value) {
   if (n == "trace_kernel") { if (value != TRACE_COOP && value != TRACE_SIMPLE) return fail("trace_kernel: 0 (cooperative) or 1 (simple)"); g_ctx.trace_kernel = (int)value; }
   else if (n == "queue_segments") { if (value != 1 && value != 2 && value != 4 && value != 8) return fail("queue_segments: 1, 2, 4 or 8"); g_ctx.queue_segments = (int)value; }
   else if (n == "batch_paths") { if (value < 1024 || value > (1ll << 27)) return fail("batch_paths: 1024..2^27 (2 rays per path slot; the trace kernel addresses a ray's 16-byte hit record by a 32-bit byte offset)"); g_ctx.batch_paths = value; g_ctx.auto_phase = 0; g_ctx.auto_redo = 0; g_ctx.auto_gen += 1; }
+  else if (n == "hot_pad") { if (value < 0 || value > (1 << 24) || (value & 63)) return fail("hot_pad: a multiple of 64 items, 0 .. 2^24"); g_ctx.hot_pad = (int)value; g_ctx.b_paths.release(); }
+  else if (n == "paths_spread") { if (value < 0 || value > 65536) return fail("paths_spread: chunk size in MB, 0 = off"); g_ctx.paths_spread_mb = (int)value; g_ctx.b_paths.release(); }
+  else if (n == "paths_contiguous") { g_ctx.paths_contiguous = value != 0; g_ctx.b_paths.release(); }
   else if (n == "inject_lost") { g_ctx.inject_lost = value != 0; }      // test option: the next pass counts one lost path in its first batch
   else if (n == "blocks_per_cu") { g_ctx.opt_blocks_per_cu = (int)value; g_ctx.blocks_per_cu = 0; }
   else if (n == "count_tests") { g_ctx.count_tests = value != 0; }

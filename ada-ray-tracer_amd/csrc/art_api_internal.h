@@ -14,7 +14,12 @@ namespace art {
 constexpr int kMaxDevices = 16;       // art_init_devices: GPUs one process may drive (an MI355X node has 8)
 constexpr int kCursorInts = 32 * 9;   // d_cursor: 3 scalars + one work cursor per queue segment, each on its own 128-byte line
 
-struct DevBuf { void* p = nullptr; size_t bytes = 0; void release(); };
+struct DevBuf {
+  void* p = nullptr; size_t bytes = 0;
+  // option paths_spread: the buffer is a reserved address range backed by separately created physical chunks (HIP virtual memory management)
+  std::vector<hipMemGenericAllocationHandle_t> chunks; size_t chunk_bytes = 0, reserved = 0;
+  void release();
+};
 
 struct Ctx {
   int device = -1; bool device_ready = false; int num_cus = 0; int lds_per_cu = 160 * 1024; std::string arch;
@@ -70,6 +75,19 @@ struct Ctx {
   struct PassClock { double t0 = 0.0, t1 = 0.0; };
   std::vector<PassClock*> pass_clock;      // one per pass since the last art_get_reduce_info / resize (heap cells: the callbacks write into them)
   double busy_ms = 0.0, idle_ms = 0.0, start_skew_ms = 0.0;   // folded by art_get_reduce_info
+  // The path state as PHYSICALLY CONTIGUOUS memory (hipExtMallocWithFlags(hipDeviceMallocContiguous); falls back to hipMalloc when the driver
+  // has no such range).  Round 6, profiles/r6_bimodal: the shade stage -- fifteen input streams, thirteen output streams -- ran 16-20 % slower
+  // in some PROCESSES than in others (same binary, same device addresses), alternating process by process on some boxes: identical
+  // instructions, L2 hits, misses and fabric requests, but 16 % more L1 -> L2 read latency.  Option paths_contiguous: 0 hipMalloc only.
+  bool paths_contiguous = false, paths_are_contiguous = false;
+  // The path state SPREAD over physical memory (round 6, profiles/r6_bimodal): one address range backed by chunks of `paths_spread` MB, created
+  // alternately with spacer chunks of the same size that are released again once everything is mapped -- the physical memory behind the
+  // range then has holes, which is the one layout in which the shade stage was fast every time (probe10: 10.3-10.5 ms per batch on C3 against
+  // 12.1 or 10.4 as the driver places one hipMalloc, 15.0 as contiguous memory).  Needs twice the path state for a moment; any failure falls
+  // back to hipMalloc.  0 = off.
+  int paths_spread_mb = 0; bool paths_are_spread = false;
+  int hot_pad = 0;               // items added to the stride between the fields of a bank's hot block (art_scene.h HotField): the frame sizes make that stride a multiple of 256 KB
+
   bool skip_null_shadow = false;   // DevFrame::skip_null_shadow: shadow rays that cannot change the picture are not traced (fewer rays than the reference issues: off by default)
   bool inst_coop = true;       // instanced scenes: the cooperative kernel crosses the instance boundary (k_trace_coop<.., INST>); false: k_trace_inst, one ray per lane (A/B, cross-check)
   bool shade_split = false;    // k_shade_compact as one instantiation per register class (light materials / deferred heavy ones); false: the round-4 kernel with every material (A/B)
