@@ -489,6 +489,7 @@ static int collect_timing() {
   if (c.auto_phase == 3) {         // both trial batches are done (the stream is idle): keep the faster setting from here on
     c.auto_per = (c.auto_ms[1] < c.auto_ms[0]) ? 2 : 4;
     c.auto_phase = 4;
+    if (g_debug_addr) std::fprintf(stderr, "ART_DEBUG_ADDR shade_per trial: 4 items per thread %.3f ms, 2 items per thread %.3f ms per batch of %lld paths -> %d\n", c.auto_ms[0], c.auto_ms[1], (long long)c.auto_P[0], c.auto_per);
   }
   if (c.d_items) {
     unsigned long long it[32];

@@ -17,6 +17,7 @@ case "$1" in
   python bench.py > gpurun_out/cfg6/c4.json 2> gpurun_out/cfg6/c4.err
   python bench.py --steps 20 --warmup 5 > gpurun_out/cfg6/c4_steps20_warmup5.json 2> gpurun_out/cfg6/c4_steps20.err
   python bench.py --scene c2 --width 512 --height 512 --vthreads 4 --steps 1 --warmup 1 > gpurun_out/cfg6/c2.json 2> gpurun_out/cfg6/c2.err
+  for k in 2 3 4 5; do python bench.py --scene c2 --width 512 --height 512 --vthreads 4 --steps 1 --warmup 1 --no-cpu > gpurun_out/cfg6/c2_rep$k.json 2> gpurun_out/cfg6/c2_rep$k.err; done      # (C2 is a 1.6 ms render: its rate is launch latency, run to run)
   python bench.py --scene c3 --width 1024 --height 1024 --vthreads 16 --steps 4 --warmup 1 > gpurun_out/cfg6/c3.json 2> gpurun_out/cfg6/c3.err
   python bench.py --scene c5 --width 4096 --height 4096 --vthreads 8 --steps 32 --warmup 1 > gpurun_out/cfg6/c5.json 2> gpurun_out/cfg6/c5.err
   python bench.py --scene s4 --no-cpu > gpurun_out/cfg6/s4.json 2> gpurun_out/cfg6/s4.err
