@@ -128,7 +128,7 @@ void DevBuf::release() {
 
 // `bytes` of device memory as ONE address range over separately created physical chunks with holes between them (Ctx::paths_spread_mb).
 // Every failure undoes what was done and reports it; the caller falls back to hipMalloc.
-static hipError_t alloc_spread(DevBuf& b, size_t bytes, size_t chunk, int device) {
+static hipError_t alloc_spread(DevBuf& b, size_t bytes, size_t chunk, int device, bool holes) {
   hipMemAllocationProp prop; std::memset(&prop, 0, sizeof prop);
   prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
   size_t gran = 0;
@@ -154,7 +154,7 @@ static hipError_t alloc_spread(DevBuf& b, size_t bytes, size_t chunk, int device
     if (e != hipSuccess) { undo(); return e; }
     got.push_back(h);
     hipMemGenericAllocationHandle_t sp;                  // the hole behind it (none if the device is too full: the layout degrades, nothing fails)
-    if (i + 1 < n) { if (hipMemCreate(&sp, chunk, &prop, 0) == hipSuccess) spacers.push_back(sp); else (void)hipGetLastError(); }
+    if (holes && i + 1 < n) { if (hipMemCreate(&sp, chunk, &prop, 0) == hipSuccess) spacers.push_back(sp); else (void)hipGetLastError(); }
   }
   for (size_t i = 0; i < n; ++i) {
     e = hipMemMap((char*)va + i * chunk, chunk, 0, got[i], 0);
@@ -566,8 +566,13 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
       b.release();
       // physically contiguous if the driver can (option paths_contiguous; art_api_internal.h Ctx::paths_contiguous says why), else as it comes
       e = hipErrorOutOfMemory; c.paths_are_contiguous = false; c.paths_are_spread = false;
-      if (c.paths_spread_mb > 0) {
-        e = alloc_spread(b, bytes, (size_t)c.paths_spread_mb << 20, c.device);
+      // the default (-1): 64 MB chunks for a path state of a gigabyte or more -- where the mapping granularity decides the stage's rate
+      const int chunk_mb = c.paths_spread_mb > 0 ? c.paths_spread_mb : (c.paths_spread_mb < 0 && !c.paths_contiguous && bytes >= ((size_t)1 << 30)) ? 64 : 0;
+      if (chunk_mb > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        e = alloc_spread(b, bytes, (size_t)chunk_mb << 20, c.device, c.paths_spread_holes);
+        if (g_debug_addr) std::fprintf(stderr, "ART_DEBUG_ADDR alloc_spread %.2f GB in chunks of %d MB: %s, %.1f ms\n", (double)bytes / 1e9, chunk_mb, hipGetErrorString(e),
+                                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         if (e == hipSuccess) { c.paths_are_spread = true; return true; }
         b.p = nullptr; (void)hipGetLastError();
       }
@@ -997,7 +1002,7 @@ int art_init_devices(int32_t n, const int32_t* ordinals) {
     Ctx& c = g_devs[k];
     c = Ctx();
     c.trace_kernel = opts.trace_kernel; c.batch_paths = opts.batch_paths; c.bvh_params = opts.bvh_params; c.node_min = opts.node_min; c.refill_min = opts.refill_min;
-    c.queue_segments = opts.queue_segments; c.ray_chunk = opts.ray_chunk; c.shadow_anyhit = opts.shadow_anyhit; c.shade_split = opts.shade_split; c.skip_null_shadow = opts.skip_null_shadow; c.inst_coop = opts.inst_coop; c.opt_shade_per = opts.opt_shade_per; c.lds_stack_cap = opts.lds_stack_cap; c.paths_contiguous = opts.paths_contiguous; c.hot_pad = opts.hot_pad; c.paths_spread_mb = opts.paths_spread_mb;
+    c.queue_segments = opts.queue_segments; c.ray_chunk = opts.ray_chunk; c.shadow_anyhit = opts.shadow_anyhit; c.shade_split = opts.shade_split; c.skip_null_shadow = opts.skip_null_shadow; c.inst_coop = opts.inst_coop; c.opt_shade_per = opts.opt_shade_per; c.lds_stack_cap = opts.lds_stack_cap; c.paths_contiguous = opts.paths_contiguous; c.hot_pad = opts.hot_pad; c.paths_spread_mb = opts.paths_spread_mb; c.paths_spread_holes = opts.paths_spread_holes;
     c.opt_blocks_per_cu = opts.opt_blocks_per_cu; c.count_tests = opts.count_tests;
     c.device = ord[k]; c.rank = k; c.nranks = n; c.tile = 32;
     if (use_dev(k) || ensure_device()) { shutdown(); return 1; }
@@ -1166,7 +1171,8 @@ static int set_option_one(const std::string& n, int64_t value) {
   else if (n == "queue_segments") { if (value != 1 && value != 2 && value != 4 && value != 8) return fail("queue_segments: 1, 2, 4 or 8"); g_ctx.queue_segments = (int)value; }
   else if (n == "batch_paths") { if (value < 1024 || value > (1ll << 27)) return fail("batch_paths: 1024..2^27 (2 rays per path slot; the trace kernel addresses a ray's 16-byte hit record by a 32-bit byte offset)"); g_ctx.batch_paths = value; g_ctx.auto_phase = 0; g_ctx.auto_redo = 0; g_ctx.auto_gen += 1; }
   else if (n == "hot_pad") { if (value < 0 || value > (1 << 24) || (value & 63)) return fail("hot_pad: a multiple of 64 items, 0 .. 2^24"); g_ctx.hot_pad = (int)value; g_ctx.b_paths.release(); }
-  else if (n == "paths_spread") { if (value < 0 || value > 65536) return fail("paths_spread: chunk size in MB, 0 = off"); g_ctx.paths_spread_mb = (int)value; g_ctx.b_paths.release(); }
+  else if (n == "paths_spread") { if (value < -1 || value > 65536) return fail("paths_spread: chunk size in MB, 0 = off (plain hipMalloc), -1 = automatic"); g_ctx.paths_spread_mb = (int)value; g_ctx.b_paths.release(); }
+  else if (n == "paths_spread_holes") { g_ctx.paths_spread_holes = value != 0; g_ctx.b_paths.release(); }
   else if (n == "paths_contiguous") { g_ctx.paths_contiguous = value != 0; g_ctx.b_paths.release(); }
   else if (n == "inject_lost") { g_ctx.inject_lost = value != 0; }      // test option: the next pass counts one lost path in its first batch
   else if (n == "blocks_per_cu") { g_ctx.opt_blocks_per_cu = (int)value; g_ctx.blocks_per_cu = 0; }

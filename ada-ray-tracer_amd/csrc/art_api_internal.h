@@ -75,17 +75,17 @@ struct Ctx {
   struct PassClock { double t0 = 0.0, t1 = 0.0; };
   std::vector<PassClock*> pass_clock;      // one per pass since the last art_get_reduce_info / resize (heap cells: the callbacks write into them)
   double busy_ms = 0.0, idle_ms = 0.0, start_skew_ms = 0.0;   // folded by art_get_reduce_info
-  // The path state as PHYSICALLY CONTIGUOUS memory (hipExtMallocWithFlags(hipDeviceMallocContiguous); falls back to hipMalloc when the driver
-  // has no such range).  Round 6, profiles/r6_bimodal: the shade stage -- fifteen input streams, thirteen output streams -- ran 16-20 % slower
-  // in some PROCESSES than in others (same binary, same device addresses), alternating process by process on some boxes: identical
-  // instructions, L2 hits, misses and fabric requests, but 16 % more L1 -> L2 read latency.  Option paths_contiguous: 0 hipMalloc only.
+  // HOW THE PATH STATE IS MAPPED decides the shade stage's rate (round 6, profiles/r6_bimodal).  The stage runs about forty concurrent streams
+  // through the 35-74 GB of path state.  As ONE hipMalloc it took 10.4 or 12.1 ms per batch on C3 (31.7 / 35.9 on C4, 22.2 / 26.0 on C5, 28.0 /
+  // 32.5 on S4) depending on the PROCESS -- same binary, same device addresses, same instructions, L2 hits, misses and fabric requests, 16 %
+  // more L1 -> L2 read latency -- and 15.0 as physically contiguous memory: the larger the pieces the driver maps the range in, the slower.
+  // paths_spread_mb: the path state as one address range over separately created physical chunks of that many MB (HIP virtual memory
+  // management, art_api.cpp alloc_spread): the fast mode in every process measured, 13-17 ms to set up, no extra memory; any failure falls
+  // back to hipMalloc.  -1 (default): 64 MB chunks when the path state is 1 GB or more; 0: plain hipMalloc; n > 0: n MB chunks always.
+  // paths_spread_holes: a spacer chunk between two chunks, released after mapping (twice the memory for a moment; measured: not what helps).
+  // paths_contiguous: hipExtMallocWithFlags(hipDeviceMallocContiguous) -- the slowest and the one deterministic placement (A/B tool).
+  int paths_spread_mb = -1; bool paths_are_spread = false; bool paths_spread_holes = false;
   bool paths_contiguous = false, paths_are_contiguous = false;
-  // The path state SPREAD over physical memory (round 6, profiles/r6_bimodal): one address range backed by chunks of `paths_spread` MB, created
-  // alternately with spacer chunks of the same size that are released again once everything is mapped -- the physical memory behind the
-  // range then has holes, which is the one layout in which the shade stage was fast every time (probe10: 10.3-10.5 ms per batch on C3 against
-  // 12.1 or 10.4 as the driver places one hipMalloc, 15.0 as contiguous memory).  Needs twice the path state for a moment; any failure falls
-  // back to hipMalloc.  0 = off.
-  int paths_spread_mb = 0; bool paths_are_spread = false;
   int hot_pad = 0;               // items added to the stride between the fields of a bank's hot block (art_scene.h HotField): the frame sizes make that stride a multiple of 256 KB
 
   bool skip_null_shadow = false;   // DevFrame::skip_null_shadow: shadow rays that cannot change the picture are not traced (fewer rays than the reference issues: off by default)

@@ -219,11 +219,13 @@ int  art_get_stage_stats(ArtStageStats* out);
  * "shade_split" [0], "skip_null_shadow" [0] (1: a shadow ray whose explicit colour is exactly zero under either verdict -- the light sample behind the
  * surface, a BxDF that is zero there -- is not traced: the same picture 7-10 % sooner, but fewer rays than the reference issues, integrators.adb:270).  Instanced scenes: "inst_coop" [1] the cooperative kernel crosses the instance boundary (0: one ray per lane, the cross-check);
  * "inst_open" [0] entry points per instance the instance tree ends at (1 whole instances, n > 1 about n subtrees of the mesh's tree per
- * instance, 0 chosen from how much the instances' boxes overlap; takes effect at the next art_upload_scene).  Where the path state lives
- * (round 6, profiles/r6_bimodal: the shade stage's rate depends on the PHYSICAL placement of its forty streams; the picture never does):
- * "paths_spread" [0] chunk size in MB -- the path state as one address range over separately created physical chunks with holes between
- * them (twice the memory for a moment; falls back to hipMalloc), "paths_contiguous" [0] 1: physically contiguous memory (the slowest and
- * the one deterministic placement: for A/B work on the stage), "hot_pad" [0] items between the fields of a bank's block (a multiple of 64).
+ * instance, 0 chosen from how much the instances' boxes overlap; takes effect at the next art_upload_scene).  How the path state is mapped
+ * (round 6, profiles/r6_bimodal: the shade stage's rate depends on the size of the pieces its 35-74 GB are mapped in; the picture never does):
+ * "paths_spread" [-1] chunk size in MB -- the path state as one address range over separately created physical chunks (HIP virtual memory
+ * management; falls back to hipMalloc); -1: 64 MB chunks for a path state of 1 GB or more, 0: plain hipMalloc (13-17 % slower stages in
+ * about half of the processes); "paths_spread_holes" [0] 1: spacer chunks between the chunks, released after mapping; "paths_contiguous"
+ * [0] 1: physically contiguous memory (the slowest and the one deterministic placement: for A/B work on the stage); "hot_pad" [0] items
+ * between the fields of a bank's block (a multiple of 64; moves nothing).
  * Test options: "inject_lost" (the next pass counts one lost path: art_synchronize must fail), "lds_stack_cap". */
 int  art_set_option(const char* name, int64_t value);
 const char* art_last_error(void);

@@ -729,12 +729,13 @@ def test_a_lost_path_in_the_first_batch_fails_the_call_that_waits(art, backend):
     assert backend.stats().lost_paths == 0
 
 
-@pytest.mark.parametrize("option,value", [("paths_spread", 2), ("paths_spread", 64), ("paths_contiguous", 1), ("hot_pad", 1088), ("hot_pad", 64)])
+@pytest.mark.parametrize("option,value", [("paths_spread", 2), ("paths_spread", 64), ("paths_spread", 0), ("paths_spread_holes", 1), ("paths_contiguous", 1), ("hot_pad", 1088), ("hot_pad", 64)])
 def test_where_the_path_state_lives_does_not_change_the_picture(art, backend, option, value):
-    """Round 6 (profiles/r6_bimodal): the path state as one address range over separately created physical chunks with holes between them
-    (paths_spread = chunk MB; the HIP virtual-memory calls), as physically contiguous memory (paths_contiguous), with a pad between the fields
-    of a bank's block (hot_pad, items): placement options -- the same bits in the frame, the same rays, and the backend goes back to plain
-    hipMalloc afterwards."""
+    """Round 6 (profiles/r6_bimodal): the path state as one address range over separately created physical chunks (paths_spread = chunk MB;
+    the HIP virtual-memory calls -- the default for path states of a gigabyte or more, forced here on a small one; 0 = plain hipMalloc), with
+    spacer chunks between them (paths_spread_holes), as physically contiguous memory (paths_contiguous), with a pad between the fields of a
+    bank's block (hot_pad, items): placement options -- the same bits in the frame, the same rays, and the backend goes back to its default
+    afterwards."""
     from ada_ray_tracer_amd import scenes
     sd = scenes.synthetic_scene(20000, 3)
     p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=11)
@@ -742,6 +743,8 @@ def test_where_the_path_state_lives_does_not_change_the_picture(art, backend, op
     r0 = backend.stats().rays
     ref, _, _ = backend.render_pass(p, 0)
     rays_ref = backend.stats().rays - r0
+    if option == "paths_spread_holes":
+        backend.set_option("paths_spread", 2)
     backend.set_option(option, value)
     try:
         backend.resize(200, 150)
@@ -750,7 +753,8 @@ def test_where_the_path_state_lives_does_not_change_the_picture(art, backend, op
         rays = backend.stats().rays - r0
         got2, _, _ = backend.render_pass(p, spp)                     # (a second pass re-uses the allocation)
     finally:
-        backend.set_option(option, 0)
+        backend.set_option(option, -1 if option == "paths_spread" else 0)
+        backend.set_option("paths_spread", -1)
     assert spp == 8 and rays == rays_ref and backend.stats().lost_paths == 0
     assert np.array_equal(bits(got), bits(ref))
     backend.resize(200, 150)
