@@ -126,8 +126,10 @@ void DevBuf::release() {
   p = nullptr; bytes = 0;
 }
 
-// `bytes` of device memory as ONE address range over separately created physical chunks with holes between them (Ctx::paths_spread_mb).
-// Every failure undoes what was done and reports it; the caller falls back to hipMalloc.
+// `bytes` of device memory as ONE address range over separately created physical chunks of `chunk` bytes (Ctx::paths_spread_mb: the driver
+// then maps the range in pieces no larger than a chunk, which is what the shade stage's forty streams want).  holes: a spacer chunk is
+// created behind every chunk and released at the end (the first form of the experiment; not what helps).  Every failure undoes what was
+// done and reports it; the caller falls back to hipMalloc.
 static hipError_t alloc_spread(DevBuf& b, size_t bytes, size_t chunk, int device, bool holes) {
   hipMemAllocationProp prop; std::memset(&prop, 0, sizeof prop);
   prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
