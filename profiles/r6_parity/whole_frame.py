@@ -36,7 +36,7 @@ def bits(a):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="c3", choices=["c3", "c4", "c5"], help="c3 (default): 100 k triangles, 1024 x 1024; c4: 1 M triangles, 1920 x 1080; c5: mixed scene, 4096 x 4096 "
+    ap.add_argument("--config", default="c3", choices=["c3", "c4", "c5", "i64"], help="c3 (default): 100 k triangles, 1024 x 1024; c4: 1 M triangles, 1920 x 1080; c5: mixed scene, 4096 x 4096 "
                     "(c4 / c5: choose --spp so that the oracle finishes -- about 30 s of 16 cores per 100 M rays at 1 M triangles)")
     ap.add_argument("--spp", type=int, default=64, help="samples per pixel of the whole-frame comparison (C3's stated count: 64)")
     ap.add_argument("--window", type=int, default=48, help="side of the block compared with the oracle's O(N) scan (48 x 48 x 16 spp on C3: 1.8e10 triangle tests)")
@@ -58,10 +58,20 @@ def main():
         W, H, ntris = 1920, 1080, 1000000
         sd = scenes.synthetic_scene(ntris, 4)
         name = "C4: synthetic %d triangles + 3 sphere lights in the Cornell box" % ntris
-    else:
+    elif args.config == "c5":
         W, H, ntris = 4096, 4096, 20000
         sd = scenes.mixed_scene(ntris, 5)
         name = "C5: spheres (glass / Phong / diffuse / emissive) + %d-triangle mesh" % ntris
+    else:
+        # I64: the GPU renders the INSTANCED scene through the two-level tree (k_trace_coop<.., INST>); the oracle has no instancing and
+        # renders the explicitly flattened scene (tests/hostsim.flattened_copy: the product's flatten_instances), its mesh search walking
+        # the tree of the flattened UPLOAD -- checked like the others in step 1.  The picture must be the same bit for bit.
+        import hostsim
+        W, H = 1920, 1080
+        inst_sd = scenes.instanced_scene(64, 20000)
+        sd = hostsim.flattened_copy(art, inst_sd)
+        ntris = int(sd.desc.meshes[0].ntris)
+        name = "I64: 64 instances of two ~20000-triangle meshes (%d triangles flattened) + 3 sphere lights, rendered through the two-level tree; oracle on the flattened scene" % ntris
     be = art.Backend(0)
     be.upload_scene(sd)
     out = {"config": "%s, %dx%d, PT_MIS depth 8, 2x2 AA" % (name, W, H), "seed": 1}
@@ -86,6 +96,8 @@ def main():
     print("tree checked:", out["tree"], flush=True)
 
     # ---- 2. the whole frame
+    if args.config == "i64":
+        be.upload_scene(inst_sd)                         # from here on the GPU renders the instanced scene; `sd` stays the oracle's (flattened) scene
     be.resize(W, H)
     p = art.Backend.pass_params(art.PT_MIS, True, 8, T, seed=1)
     t0 = time.time()
