@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--window", type=int, default=48, help="side of the block compared with the oracle's O(N) scan (48 x 48 x 16 spp on C3: 1.8e10 triangle tests)")
     ap.add_argument("--window-spp", type=int, default=16)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--oracle-chunk", type=int, default=16, help="Threads_Num of one oracle Render_Pass call (4 spp each); the calls accumulate")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     art = ge.load_package()
@@ -108,9 +109,19 @@ def main():
     osc = conv.OracleScene(sd)
     osc.attach_bvh(nodes, tris, info.node_width)
     t0 = time.time()
-    ref, rspp, cnt = orc.render(osc.scene, orc.make_params(W, H, orc.PT_MIS, True, 8, T, seed=1, nthreads=args.threads))
+    # the oracle in Render_Pass calls of at most --oracle-chunk tasks (g_accBuff is cumulative over calls, ray_tracer.adb:281-285: the same sum in
+    # the same order as one pass of T tasks -- tests/test_gpu_stated_spp.py::test_c3_two_passes_of_eight_tasks_equal_one_pass_of_sixteen), so
+    # that a long render says something every minute or two
+    ref = None; rspp = 0; rays_o = 0
+    while rspp < spp:
+        tc = min(args.oracle_chunk, (spp - rspp) // 4)
+        ref, rspp, cnt = orc.render(osc.scene, orc.make_params(W, H, orc.PT_MIS, True, 8, tc, seed=1, nthreads=args.threads), accum=ref, spp0=rspp)
+        rays_o += cnt.rays
+        print("oracle: %d of %d spp, %.0f s" % (rspp, spp, time.time() - t0), flush=True)
     t_cpu = time.time() - t0
     assert rspp == spp
+    class _C: pass
+    cnt = _C(); cnt.rays = rays_o
     diff = bits(gpu) != bits(ref)
     mism_px = int(np.count_nonzero(diff.any(-1)))
     out["whole_frame"] = {"pixels": W * H, "spp": spp, "camera_samples": W * H * spp, "mismatching_pixels": mism_px, "mismatching_channels": int(np.count_nonzero(diff)),

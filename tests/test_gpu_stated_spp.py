@@ -145,7 +145,7 @@ def test_whole_frame_every_pixel_at_4_spp(art, backend, config):
     """Round 6 (review: "one whole BASELINE frame has never been compared pixel for pixel"): C3 1024 x 1024 and C4 1920 x 1080 at 4 spp (one
     Render_Pass, Threads_Num = 1, 2x2 AA), EVERY pixel of the frame against the oracle's orc_render_pass -- accum bits, ray count and the LDR
     frame.  The oracle's mesh search walks the exported tree (checked structurally and against the O(N) scan by
-    test_bench_scale_tree_is_sound_and_hits_equal_brute_force).  The same frames at their stated 64 spp / at 8 spp, and windows of them against
+    test_bench_scale_tree_is_sound_and_hits_equal_brute_force).  The same frames at 64 spp (C3: its stated count; C4: one full batch of its 256), and windows of them against
     the oracle's own O(N) scan, are in profiles/r6_parity/ (profiles/r6_parity/whole_frame.py: minutes of host time, outside this suite)."""
     from ada_ray_tracer_amd import scenes
     build, W, H, _, _ = CONFIGS[config]
