@@ -130,7 +130,7 @@ void DevBuf::release() {
 // then maps the range in pieces no larger than a chunk, which is what the shade stage's forty streams want).  holes: a spacer chunk is
 // created behind every chunk and released at the end (the first form of the experiment; not what helps).  Every failure undoes what was
 // done and reports it; the caller falls back to hipMalloc.
-static hipError_t alloc_spread(DevBuf& b, size_t bytes, size_t chunk, int device, bool holes) {
+static hipError_t alloc_spread(DevBuf& b, size_t bytes, size_t chunk, int device, bool holes, int fail_at = -1) {      // fail_at: test option spread_fail_at -- chunk number whose creation is made to fail
   hipMemAllocationProp prop; std::memset(&prop, 0, sizeof prop);
   prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
   size_t gran = 0;
@@ -152,7 +152,7 @@ static hipError_t alloc_spread(DevBuf& b, size_t bytes, size_t chunk, int device
   };
   for (size_t i = 0; i < n; ++i) {
     hipMemGenericAllocationHandle_t h;
-    e = hipMemCreate(&h, chunk, &prop, 0);
+    e = ((int64_t)i == (int64_t)fail_at) ? hipErrorOutOfMemory : hipMemCreate(&h, chunk, &prop, 0);
     if (e != hipSuccess) { undo(); return e; }
     got.push_back(h);
     hipMemGenericAllocationHandle_t sp;                  // the hole behind it (none if the device is too full: the layout degrades, nothing fails)
@@ -584,7 +584,7 @@ static int render_pass_one(const ArtPassParams* p, int32_t* spp_inout) {
       const int chunk_mb = c.paths_spread_mb > 0 ? c.paths_spread_mb : (c.paths_spread_mb < 0 && !c.paths_contiguous && bytes >= ((size_t)1 << 30)) ? 64 : 0;
       if (chunk_mb > 0) {
         const auto t0 = std::chrono::steady_clock::now();
-        e = alloc_spread(b, bytes, (size_t)chunk_mb << 20, c.device, c.paths_spread_holes);
+        e = alloc_spread(b, bytes, (size_t)chunk_mb << 20, c.device, c.paths_spread_holes, c.spread_fail_at);
         if (g_debug_addr) std::fprintf(stderr, "ART_DEBUG_ADDR alloc_spread %.2f GB in chunks of %d MB: %s, %.1f ms\n", (double)bytes / 1e9, chunk_mb, hipGetErrorString(e),
                                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         if (e == hipSuccess) { c.paths_are_spread = true; return true; }
@@ -1186,6 +1186,7 @@ static int set_option_one(const std::string& n, int64_t value) {
   else if (n == "batch_paths") { if (value < 1024 || value > (1ll << 27)) return fail("batch_paths: 1024..2^27 (2 rays per path slot; the trace kernel addresses a ray's 16-byte hit record by a 32-bit byte offset)"); g_ctx.batch_paths = value; g_ctx.auto_phase = 0; g_ctx.auto_redo = 0; g_ctx.auto_gen += 1; }
   else if (n == "hot_pad") { if (value < 0 || value > (1 << 24) || (value & 63)) return fail("hot_pad: a multiple of 64 items, 0 .. 2^24"); g_ctx.hot_pad = (int)value; g_ctx.b_paths.release(); }
   else if (n == "paths_spread") { if (value < -1 || value > 65536) return fail("paths_spread: chunk size in MB, 0 = off (plain hipMalloc), -1 = automatic"); g_ctx.paths_spread_mb = (int)value; g_ctx.b_paths.release(); }
+  else if (n == "spread_fail_at") { g_ctx.spread_fail_at = (int)value; g_ctx.b_paths.release(); }      // test option: creating chunk number `value` of the path state fails (-1: never)
   else if (n == "paths_spread_holes") { g_ctx.paths_spread_holes = value != 0; g_ctx.b_paths.release(); }
   else if (n == "paths_contiguous") { g_ctx.paths_contiguous = value != 0; g_ctx.b_paths.release(); }
   else if (n == "inject_lost") { g_ctx.inject_lost = value != 0; }      // test option: the next pass counts one lost path in its first batch

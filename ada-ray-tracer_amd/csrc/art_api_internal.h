@@ -85,6 +85,7 @@ struct Ctx {
   // paths_spread_holes: a spacer chunk between two chunks, released after mapping (twice the memory for a moment; measured: not what helps).
   // paths_contiguous: hipExtMallocWithFlags(hipDeviceMallocContiguous) -- the slowest and the one deterministic placement (A/B tool).
   int paths_spread_mb = -1; bool paths_are_spread = false; bool paths_spread_holes = false;
+  int spread_fail_at = -1;       // test option: the creation of this chunk is made to fail, so that the undo + hipMalloc fallback runs (tests/test_gpu_parity.py)
   bool paths_contiguous = false, paths_are_contiguous = false;
   int hot_pad = 0;               // items added to the stride between the fields of a bank's hot block (art_scene.h HotField): the frame sizes make that stride a multiple of 256 KB
 

@@ -226,7 +226,8 @@ int  art_get_stage_stats(ArtStageStats* out);
  * about half of the processes); "paths_spread_holes" [0] 1: spacer chunks between the chunks, released after mapping; "paths_contiguous"
  * [0] 1: physically contiguous memory (the slowest and the one deterministic placement: for A/B work on the stage); "hot_pad" [0] items
  * between the fields of a bank's block (a multiple of 64; moves nothing).
- * Test options: "inject_lost" (the next pass counts one lost path: art_synchronize must fail), "lds_stack_cap". */
+ * Test options: "inject_lost" (the next pass counts one lost path: art_synchronize must fail), "spread_fail_at" (creating that chunk of the
+ * path state fails: everything created so far is undone and the path state comes from hipMalloc), "lds_stack_cap". */
 int  art_set_option(const char* name, int64_t value);
 const char* art_last_error(void);
 void art_shutdown(void);

@@ -760,3 +760,48 @@ def test_where_the_path_state_lives_does_not_change_the_picture(art, backend, op
     backend.resize(200, 150)
     again, _, _ = backend.render_pass(p, 0)
     assert np.array_equal(bits(again), bits(ref))
+
+
+def test_a_failing_chunk_of_the_path_state_is_undone_and_hipmalloc_takes_over(art):
+    """The default backing of a large path state is a reserved address range over separately created chunks (art_api.cpp alloc_spread).  When
+    the device cannot give a chunk -- test option spread_fail_at: chunk 3 of a path state forced into 2 MB chunks -- everything created so
+    far must be released, the range given back, and the pass must run from a plain hipMalloc with the same picture.  In a child process:
+    which backing a batch got is only visible on the library's debug line (ART_DEBUG_ADDR)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import __graft_entry__ as ge
+art = ge.load_package()
+from ada_ray_tracer_amd import scenes
+be = art.Backend(0)
+be.upload_scene(scenes.synthetic_scene(20000, 3)); be.resize(320, 200)
+p = art.Backend.pass_params(art.PT_MIS, True, 8, 2, seed=11)
+out = {}
+for name, opts in (("hipmalloc", {"paths_spread": 0}), ("chunks", {"paths_spread": 2}), ("chunk_3_fails", {"paths_spread": 2, "spread_fail_at": 3}), ("chunk_0_fails", {"paths_spread": 2, "spread_fail_at": 0})):
+    for k, v in opts.items():
+        be.set_option(k, v)
+    be.resize(320, 200)
+    print("CASE", name, file=sys.stderr, flush=True)
+    acc, _, spp = be.render_pass(p, 0)
+    out[name] = [int(np.ascontiguousarray(acc).view(np.uint32).sum(dtype=np.uint64)), int(be.stats().rays), int(be.stats().lost_paths)]
+    be.set_option("spread_fail_at", -1)
+be.shutdown()
+print(json.dumps(out))
+'''
+    r = subprocess.run([sys.executable, "-c", code, art.ROOT], capture_output=True, text=True, timeout=600, env=dict(os.environ, ART_DEBUG_ADDR="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["hipmalloc"] == out["chunks"] == out["chunk_3_fails"] == out["chunk_0_fails"] and out["hipmalloc"][2] == 0 and out["hipmalloc"][1] > 0
+    got = {}
+    case = None
+    for line in r.stderr.splitlines():
+        if line.startswith("CASE "):
+            case = line.split()[1]
+        elif line.startswith("ART_DEBUG_ADDR spread ") and case:
+            got[case] = int(line.split()[2])
+    assert got == {"hipmalloc": 0, "chunks": 1, "chunk_3_fails": 0, "chunk_0_fails": 0}, (got, r.stderr[-1500:])
