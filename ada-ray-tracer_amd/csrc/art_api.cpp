@@ -272,18 +272,6 @@ int upload_scene(const ArtSceneDesc* d) {
       launch_pad_tris(c.stream, (const float*)c.b_blas_tris.p, (float*)c.b_qtris.p, nrec);
       HIP_TRY(hipStreamSynchronize(c.stream));
     }
-    if (const char* e = getenv("ART_SCENE_PLACEMENT")) {      // experiment (profiles/r6_bimodal/probe13.sh): the arrays the trace kernel gathers from, re-placed
-      const int mode = std::atoi(e);                          // 1: physically contiguous, 2: 2 MB chunks, 3: 64 MB chunks
-      for (DevBuf* b : {&c.b_qnodes, &c.b_qtris}) {
-        if (!b->p || mode <= 0) continue;
-        DevBuf nb; hipError_t er = hipErrorUnknown;
-        if (mode == 1) { er = hipExtMallocWithFlags(&nb.p, b->bytes, hipDeviceMallocContiguous); nb.bytes = b->bytes; }
-        else er = alloc_spread(nb, b->bytes, (size_t)(mode == 2 ? 2 : 64) << 20, c.device, false);
-        if (er != hipSuccess) { (void)hipGetLastError(); std::fprintf(stderr, "ART_SCENE_PLACEMENT %d refused: %s\n", mode, hipGetErrorString(er)); continue; }
-        HIP_TRY(hipMemcpy(nb.p, b->p, b->bytes, hipMemcpyDeviceToDevice));
-        b->release(); *b = nb; nb = DevBuf();
-      }
-    }
     c.bvh_stack_bound = std::max(8, dev_stack);
     c.blocks_per_cu = 0;   // re-query occupancy
     c.scene_ready = true;
