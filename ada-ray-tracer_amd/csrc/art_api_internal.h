@@ -58,8 +58,9 @@ struct Ctx {
   int queue_segments = 8;       // the live-ray queue is cut into this many contiguous segments, one per XCD (1 = a single cursor)
   int ray_chunk = 48;            // trace records a wave claims per atomic (and prefetches): 16 -> 48 is worth 1 % on C4, 4 % on C3, 10 % on C5 (the claim stalls the wave)
   bool shadow_anyhit = true;   // shadow rays use the visibility rule instead of a full closest-hit search (same decision)
-  // Items per thread of k_shade_compact (256 x per items and one global atomic per workgroup): 4 or 2.  Neither wins everywhere (round 5,
-  // profiles/r5_shade/ab12: 2 is 7 % faster on C4 and C3, 10 % slower on C5 and S4), so by default the library MEASURES -- without ever
+  // Items per thread of k_shade_compact (256 x per items and one global atomic per workgroup): 4 or 2.  Neither wins everywhere (inside one
+  // process 2 is 5 % faster on C4, 3 % slower on C5, equal on S4: profiles/r6_shade/trial_check_*.txt; round 5's "+7 % / -10 %" of ab12 were
+  // mostly the mapping of the path state, which differed between its processes), so by default the library MEASURES -- without ever
   // waiting for the GPU (round 6; until round 5 the trial blocked the host twice per trial batch, which serialised the devices of a
   // multi-GPU process during their first two batches): after a scene upload or a resize batch 0 runs warm and unmeasured (code-object load,
   // first touch of the path state), batch 1 with 4 items per thread, batch 2 with 2 -- their shade launches' event pairs carry the trial's
@@ -94,7 +95,7 @@ struct Ctx {
   bool shade_split = false;    // k_shade_compact as one instantiation per register class (light materials / deferred heavy ones); false: the round-4 kernel with every material (A/B)
   // timing
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
-  std::vector<uint8_t> ev_kind;                // per event pair: 0 trace kernel, 1 shade stage, 2 raygen, 3 fold group (art_get_stage_stats)
+  std::vector<uint8_t> ev_kind;                // per event pair: 0 trace kernel, 1 shade stage, 2 raygen, 3 fold group (art_get_stage_stats) | trial (1 / 2: A / B of the items-per-thread trial) << 4 | the trial's generation << 6
   ArtStageStats stage = ArtStageStats();
   unsigned long long* d_items = nullptr;       // cumulative items_in[16] | items_out[16] (k_acc_items at the end of every batch)
   std::vector<hipEvent_t> pass_events;
