@@ -93,7 +93,8 @@ def profiled(args, fp):
     """The committed rocprofv3 PMC summary (profiles/collect.sh -> profiles/summarize.py) if it was taken on exactly this source,
     scene and options; None otherwise -- a number measured on another build must not sit next to this run's."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG, "pmc_summary.json")))
+        tag = PROFILE_TAG if args.scene == "c4" else PROFILE_TAG.split("_")[0] + "_" + args.scene      # r6_final for the default workload, r6_c3 / r6_c5 / r6_s4 for the others
+        d = json.load(open(os.path.join(ROOT, "profiles", tag, "pmc_summary.json")))
         if d.get("fingerprint") != fp:
             return None
         return d["k_trace_coop"]
@@ -363,7 +364,7 @@ def main():
                         "frac_note": "algorithmic bytes exceed the HBM peak (cache hits): not a roofline fraction" if over else None,
                         "traffic": round(traffic, 1) if prof else None,
                         "traffic_note": "FETCH_SIZE x 1.0 + WRITE_SIZE per launch / launch time: random 64-byte node packets and triangle records are counted exactly (profiles/r5_calib/calibration; rounds 1-4 doubled FETCH_SIZE on a calibration of 128-byte gathers the kernel no longer does)" if prof else None,
-                        "traffic_source": ("profiles/%s/pmc_summary.json (same source %s, scene, options)" % (PROFILE_TAG, fp["source"])) if prof else None,
+                        "traffic_source": ("profiles/%s/pmc_summary.json (same source %s, scene, options)" % (PROFILE_TAG if args.scene == "c4" else PROFILE_TAG.split("_")[0] + "_" + args.scene, fp["source"])) if prof else None,
                         "kernel": ("k_trace_inst (two-level search, one ray per lane)" if "inst_coop=0" in args.opt else "k_trace_coop<.., INST> (two-level tree)") if args.scene == "i64" else "k_trace_coop" if args.kernel == "coop" else "k_trace_simple",
                         "bound_evidence": "frac = algorithmic bytes against the HBM peak (the contract's roofline).  What limits the kernel itself is VALU issue: "
                                           "issue = SQ_INSTS_VALU per launch / 1024 SIMDs x the mean issue time of the kernel's own instruction mix (profiles/valu_mix.py x "
