@@ -36,6 +36,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
   for (int f = 0; f < T; ++f) __builtin_nontemporal_store(v[f % S] + acc, &out[(size_t)f * n + w]);
 }
 
+// the same bytes in 16-byte fields: S4 float4 streams in (field f of item w at in4[f * n + w]), the dependent second round trip on the first
+// field, T4 float4 non-temporal streams out -- what packing the stage's dword fields four to a field would look like to the memory system
+template <int S4, int T4>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_probe4(const float4* __restrict__ in, float4* __restrict__ out, size_t n) {
+  __shared__ float pad_lds[26 * 256];
+  const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (threadIdx.x == 0) pad_lds[blockIdx.x & 1023] = 0.0f;
+  if (w >= n) return;
+  float4 v[S4];
+#pragma unroll
+  for (int f = 0; f < S4; ++f) v[f] = in[(size_t)f * n + w];
+  float acc = 0.0f;
+#pragma unroll
+  for (int f = 0; f < S4; ++f) acc += v[f].x + v[f].y + v[f].z + v[f].w;
+  const size_t w2 = (w ^ 64) < n ? (w ^ 64) : w;
+  const int sel = (acc == 12345.0f) ? 1 : 0;
+  const float4 nb = in[(size_t)sel * n + w2];
+  acc += nb.x + nb.y + nb.z + nb.w;
+#pragma unroll
+  for (int f = 0; f < T4; ++f) {
+    const float4 o = make_float4(v[f % S4].x + acc, v[f % S4].y + acc, v[f % S4].z + acc, v[f % S4].w + acc);
+    float* dst = reinterpret_cast<float*>(&out[(size_t)f * n + w]);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(v4f{o.x, o.y, o.z, o.w}, reinterpret_cast<v4f*>(dst));
+  }
+}
+
 struct Buf { void* p = nullptr; size_t bytes = 0, chunk = 0, reserved = 0; std::vector<hipMemGenericAllocationHandle_t> h; };
 
 static bool alloc(Buf& b, size_t bytes, int mode) {      // mode 0 malloc, -1 contiguous, > 0 chunk MB
@@ -85,10 +112,34 @@ static void run(const char* name, int mode, size_t n) {
   release(in); release(out);
 }
 
+template <int S4, int T4>
+static void run4(const char* name, int mode, size_t n) {
+  Buf in, out;
+  if (!alloc(in, (size_t)(S4 + 1) * n * 16, mode) || !alloc(out, (size_t)T4 * n * 16, mode)) { std::printf("%-11s S4 %d T4 %d: allocation refused\n", name, S4, T4); release(in); release(out); return; }
+  CK(hipMemset(in.p, 0, in.bytes));
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  std::vector<float> ms;
+  for (int it = 0; it < 8; ++it) {
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL((k_probe4<S4, T4>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const float4*)in.p, (float4*)out.p, n);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float t; CK(hipEventElapsedTime(&t, a, b));
+    if (it) ms.push_back(t);
+  }
+  std::sort(ms.begin(), ms.end());
+  const double bytes = (double)(S4 + 1 + T4) * 16.0 * (double)n;
+  std::printf("%-11s %d + %d float4 streams (= %d + %d dwords per item): best %.3f ms  median %.3f ms  %.0f GB/s\n", name, S4, T4, 4 * S4, 4 * T4, ms[0], ms[ms.size() / 2], bytes / (ms[ms.size() / 2] * 1e-3) / 1e9);
+  std::fflush(stdout);
+  CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+  release(in); release(out);
+}
+
 int main() {
   const size_t n = (size_t)1 << 26;
   const struct { const char* name; int mode; } B[] = {{"malloc", 0}, {"contiguous", -1}, {"vmm2", 2}, {"vmm64", 64}, {"vmm1024", 1024}, {"malloc", 0}};
   for (auto& b : B) run<15, 10>(b.name, b.mode, n);
   for (auto& b : B) run<30, 30>(b.name, b.mode, n);
+  for (auto& b : B) run4<8, 8>(b.name, b.mode, n);          // 32 + 32 dwords per item in 16 streams
+  for (auto& b : B) run4<4, 3>(b.name, b.mode, n);          // 16 + 12: the hot block's 15 + 10
   return 0;
 }
