@@ -44,12 +44,23 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--oracle-chunk", type=int, default=16, help="Threads_Num of one oracle Render_Pass call (4 spp each); the calls accumulate")
     ap.add_argument("--out", default="")
+    # a frame whose oracle render does not fit one gpurun call (20 minutes): the oracle's accum buffer, sample count and ray count are carried
+    # from call to call in a file; every call the GPU renders the whole count so far in ONE pass from zero and the two frames are compared
+    ap.add_argument("--carry-in", default="", help=".npz of an earlier call (accum, spp, rays): the oracle continues from there")
+    ap.add_argument("--carry-out", default="", help="where to leave the oracle's state for the next call")
+    ap.add_argument("--oracle-spp", type=int, default=0, help="samples per pixel the oracle adds in this call (0: all of --spp); the GPU renders carried + added")
+    ap.add_argument("--skip-tree", action="store_true", help="skip step 1 (done by the first call of a chain)")
     args = ap.parse_args()
     art = ge.load_package()
     import bvh_check
     import conv
     import orc
     from ada_ray_tracer_amd import scenes
+    carried = np.load(args.carry_in) if args.carry_in else None
+    spp_in = int(carried["spp"]) if carried is not None else 0
+    add = args.oracle_spp if args.oracle_spp > 0 else args.spp
+    if carried is not None or args.oracle_spp > 0:
+        args.spp = spp_in + add                          # this call compares the frame at carried + added samples
     T = args.spp // 4
     if args.config == "c3":
         W, H, ntris = 1024, 1024, 100000
@@ -80,9 +91,9 @@ def main():
     # ---- 1. the tree the oracle is going to walk, checked without any traversal, and the product's hits against the O(N) scan
     nodes, tris, info = be.export_bvh()
     pos, _, idx, _, _ = [a for a, m in zip(sd._mesh_arrays, sd.meshes) if m.mode == art.MESH_CLOSEST][0]
-    r = bvh_check.check_tree(nodes, tris, info.n_nodes, info.max_stack, info.node_width, pos, idx)
+    r = bvh_check.check_tree(nodes, tris, info.n_nodes, info.max_stack, info.node_width, pos, idx) if not args.skip_tree else {"records": int(info.n_tris), "depth": -1, "worst_stack": -1}
     rng = np.random.default_rng(20260)
-    n_rays = 20000 if ntris <= 100000 else 4000
+    n_rays = (20000 if ntris <= 100000 else 4000) if not args.skip_tree else 8
     o = np.stack([rng.uniform(-2.4, 2.4, n_rays), rng.uniform(0.1, 4.9, n_rays), rng.uniform(0.1, 4.9, n_rays)], 1).astype(np.float32)
     d = rng.normal(size=(n_rays, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
     osc_bf = conv.OracleScene(sd)                       # no tree attached: the oracle's own O(N) scan
@@ -92,7 +103,7 @@ def main():
     for k in (0, 3, 4, 5):
         a, b = np.asarray(hg[k])[is_hit], np.asarray(ho[k])[is_hit]
         same_hits = same_hits and bool(np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b))
-    out["tree"] = {"nodes": int(info.n_nodes), "records": int(r["records"]), "depth": int(r["depth"]), "worst_stack": int(r["worst_stack"]), "structural_check": "passed",
+    out["tree"] = {"nodes": int(info.n_nodes), "records": int(r["records"]), "depth": int(r["depth"]), "worst_stack": int(r["worst_stack"]), "structural_check": "passed" if not args.skip_tree else "skipped (first call of the chain)",
                    "random_rays_vs_O(N)_scan": n_rays, "random_rays_hitting": int(is_hit.sum()), "random_rays_equal": bool(same_hits)}
     print("tree checked:", out["tree"], flush=True)
 
@@ -113,6 +124,9 @@ def main():
     # the same order as one pass of T tasks -- tests/test_gpu_stated_spp.py::test_c3_two_passes_of_eight_tasks_equal_one_pass_of_sixteen), so
     # that a long render says something every minute or two
     ref = None; rspp = 0; rays_o = 0
+    if carried is not None:
+        ref = np.ascontiguousarray(carried["accum"], np.float32); rspp = spp_in; rays_o = int(carried["rays"])
+        print("oracle: continuing from %d spp (%d rays so far)" % (rspp, rays_o), flush=True)
     while rspp < spp:
         tc = min(args.oracle_chunk, (spp - rspp) // 4)
         ref, rspp, cnt = orc.render(osc.scene, orc.make_params(W, H, orc.PT_MIS, True, 8, tc, seed=1, nthreads=args.threads), accum=ref, spp0=rspp)
@@ -120,6 +134,9 @@ def main():
         print("oracle: %d of %d spp, %.0f s" % (rspp, spp, time.time() - t0), flush=True)
     t_cpu = time.time() - t0
     assert rspp == spp
+    if args.carry_out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.carry_out)), exist_ok=True)
+        np.savez(args.carry_out, accum=ref, spp=np.int64(rspp), rays=np.int64(rays_o))
     class _C: pass
     cnt = _C(); cnt.rays = rays_o
     diff = bits(gpu) != bits(ref)
@@ -130,7 +147,8 @@ def main():
                           "ldr_frame_equal": bool(np.array_equal(screen, orc.resolve(ref, spp))),
                           "sha256_gpu_accum": hashlib.sha256(bits(gpu).tobytes()).hexdigest(), "sha256_oracle_accum": hashlib.sha256(bits(ref).tobytes()).hexdigest(),
                           "nonblack_fraction": float((ref.sum(-1) > 0).mean()), "gpu_s": round(t_gpu, 3), "oracle_s": round(t_cpu, 1),
-                          "oracle_mesh_search": "walk of the product's exported tree (checked in step 1)"}
+                          "oracle_mesh_search": "walk of the product's exported tree (checked in step 1)",
+                          "oracle_samples_carried_in": spp_in, "oracle_samples_added_in_this_call": spp - spp_in}
     print("whole frame:", out["whole_frame"], flush=True)
 
     # ---- 3. a window of the frame with the oracle's own O(N) closest-hit scan (no product tree on the oracle's side)
